@@ -1,0 +1,110 @@
+"""ctypes binding of lib3dvnet_hip.so (C ABI declared in include/v3d.h).
+
+The product path has no CPU fallback: if the shared library is missing or fails to load, every
+operator raises ``V3DLibraryError``.  ``load()`` never builds implicitly -- run
+``python 3dvnet_amd/build.py`` (or ``__graft_entry__.build()``) first.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
+ABI_VERSION = 1
+
+c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_double, ctypes.c_size_t)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_float_pp = ctypes.POINTER(c_float_p)
+
+# name -> (restype, argtypes); mirrors include/v3d.h exactly (tests/test_cabi.py checks the list)
+SIGNATURES = {
+    'v3d_version': (c_int, []),
+    'v3d_last_error': (ctypes.c_char_p, []),
+    'v3d_timing_enable': (c_int, [c_int]),
+    'v3d_timing_collect': (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_float),
+                                   ctypes.POINTER(c_int)]),
+    'v3d_psv_workspace_bytes': (c_size_t, [c_int] * 4),
+    'v3d_psv_variance_f32': (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_double] * 2 + [c_int] * 3 +
+                             [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_costreg_pack': (c_int, [c_float_pp] * 5 + [c_float_p, c_float_p, c_int, c_int, c_float,
+                                                     ctypes.POINTER(c_void_p)]),
+    'v3d_costreg_free': (None, [c_void_p]),
+    'v3d_costreg_workspace_bytes': (c_size_t, [c_void_p] + [c_int] * 4),
+    'v3d_costreg_depth_f32': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p,
+                                                                    c_size_t, c_void_p]),
+    'v3d_costreg_layer_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
+                              [c_void_p, c_void_p]),
+}
+
+
+class V3DLibraryError(RuntimeError):
+    """lib3dvnet_hip.so is missing / unloadable, or a call returned an error code."""
+
+
+_ERR_NAMES = {-1: 'V3D_ERR_BAD_SHAPE', -2: 'V3D_ERR_BAD_ARG', -3: 'V3D_ERR_WORKSPACE_TOO_SMALL',
+              -4: 'V3D_ERR_HIP', -5: 'V3D_ERR_UNSUPPORTED'}
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises V3DLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise V3DLibraryError('%s not found: the HIP extension is not built (run '
+                              '`python 3dvnet_amd/build.py`); there is no CPU fallback' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise V3DLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise V3DLibraryError('%s does not export %s' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.v3d_version() != ABI_VERSION:
+        raise V3DLibraryError('ABI version mismatch: library %d, binding %d'
+                              % (lib.v3d_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().v3d_last_error()
+        raise V3DLibraryError('%s failed: %s (%s)' % (what, _ERR_NAMES.get(rc, rc),
+                                                      msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor passed to the C ABI must be contiguous'
+    return t.data_ptr()
+
+
+def stream_ptr(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def timing_enable(on=True):
+    load().v3d_timing_enable(1 if on else 0)
+
+
+def timing_collect(max_entries=64):
+    """-> {kernel name: (total_ms, launches)} since the last collect; synchronises the events."""
+    lib = load()
+    stride = 64
+    names = ctypes.create_string_buffer(max_entries * stride)
+    ms = (c_float * max_entries)()
+    cnt = (c_int * max_entries)()
+    n = lib.v3d_timing_collect(max_entries, names, stride, ms, cnt)
+    out = {}
+    for i in range(n):
+        out[names.raw[i * stride:(i + 1) * stride].split(b'\0')[0].decode()] = (float(ms[i]), int(cnt[i]))
+    return out

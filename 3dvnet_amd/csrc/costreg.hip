@@ -1,0 +1,481 @@
+// Rows A5-A6 of SURVEY.md §8a: CostRegNet (dense 3D-conv U-Net, eval-mode BatchNorm folded) and the
+// soft-argmin depth.  Reference semantics: mv3d/subnetworks/mvsnet.py:18-36,133-163,219-227.
+//
+// All ten conv / transposed-conv layers run through ONE templated implicit-GEMM kernel on the
+// exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain, so the 1e-4 depth parity
+// gate is met with fp32 operands and fp32 accumulation):
+//
+//   D[co, voxel] += W'[co, k] * X[k, voxel],  k = (input channel, kernel tap)
+//
+//   * A operand = BN-folded weights, pre-packed on the host into MFMA fragment order (one coalesced
+//     256-B global load per fragment, L2-resident, shared by every workgroup);
+//   * B operand = activations: a halo'd input tile of CK channels is staged in LDS channel-major
+//     ([ck][z][y][x], plane stride chosen so the 4 k-lanes x 16 voxel-lanes of a ds_read_b32 hit
+//     distinct banks); zero padding is materialised in the tile so the inner loop has no bounds
+//     checks; every output voxel of the tile owns a per-lane LDS base offset, every kernel tap is a
+//     wave-uniform offset on top of it;
+//   * each wave keeps NBW voxel blocks x MB channel blocks of 16x16 accumulators in registers
+//     across all input-channel chunks; epilogue = +bias, ReLU, optional skip add (after the ReLU,
+//     mvsnet.py:159-161), store in the reference's [n, C, D, H, W] layout (16 consecutive voxels
+//     per store row);
+//   * stride-2 conv reads the tile with stride 2; the stride-2 transposed conv (k3, p1,
+//     output_padding 1) is decomposed into its 8 output-parity classes, each a dense gather with
+//     1..8 taps (out[o] = sum_k in[(o+1-k)/2] W[k] for (o+1-k) even).
+//
+// The final `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
+// and the depth softmax + expectation is a per-pixel streaming reduction.
+#include <vector>
+
+#include "v3d_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { kConvS1 = 0, kConvS2 = 1, kDeconvS2 = 2 };
+
+struct ConvParams {
+  const float* in;
+  const float* wp;     // packed A fragments
+  const float* bias;   // [COUT]
+  const float* skip;   // [n, COUT, Do, Ho, Wo] or null
+  float* out;
+  int n, Di, Hi, Wi, Do, Ho, Wo, ntz, nty, ntx;
+  int relu;
+};
+
+template <int MODE_, int CIN_, int COUT_, int TD_, int TH_, int TW_, int CK_>
+struct ConvCfg {
+  static constexpr int MODE = MODE_, CIN = CIN_, COUT = COUT_, TD = TD_, TH = TH_, TW = TW_, CK = CK_;
+  static constexpr int MB = (COUT + 15) / 16;
+  static constexpr int ID = MODE == kConvS1 ? TD + 2 : MODE == kConvS2 ? 2 * TD + 1 : TD / 2 + 1;
+  static constexpr int IH = MODE == kConvS1 ? TH + 2 : MODE == kConvS2 ? 2 * TH + 1 : TH / 2 + 1;
+  static constexpr int IW = MODE == kConvS1 ? TW + 2 : MODE == kConvS2 ? 2 * TW + 1 : TW / 2 + 1;
+  static constexpr int PLANE = ID * IH * IW;
+  // channel-plane stride in LDS: odd for the stride-2 read pattern, == 16 (mod 32) otherwise
+  static constexpr int S = MODE == kConvS2 ? (PLANE | 1) : ((PLANE - 16 + 31) / 32) * 32 + 16;
+  static constexpr int NVOX = TD * TH * TW;
+  static constexpr int NCLS = MODE == kDeconvS2 ? 8 : 1;
+  static constexpr int NVC = NVOX / NCLS;
+  static constexpr int CD = MODE == kDeconvS2 ? TD / 2 : TD;   // lattice the N-blocks enumerate
+  static constexpr int CH = MODE == kDeconvS2 ? TH / 2 : TH;
+  static constexpr int CW = MODE == kDeconvS2 ? TW / 2 : TW;
+  static constexpr int NBC = (NVC + 15) / 16;
+  static constexpr int NBT = NBC * NCLS;
+  static constexpr int NBW = (NBT + 3) / 4;
+  static constexpr int NCHUNK = CIN / CK;
+  static constexpr int C4 = CK / 4;
+  static constexpr int LDS_BYTES = CK * S * 4;
+  static_assert(CIN % CK == 0 && CK % 4 == 0, "channel chunking");
+  static_assert(MODE != kDeconvS2 || (TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0), "even tile");
+  static_assert(MODE != kDeconvS2 || NBW == 2 * NBC, "two parity classes per wave");
+  static_assert(LDS_BYTES <= 64 * 1024, "LDS tile");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvParams p) {
+  constexpr int MODE = C::MODE;
+  __shared__ float xs[C::CK * C::S];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * C::TD, oy0 = ty * C::TH, ox0 = tx * C::TW;
+  const int iz0 = MODE == kConvS1 ? oz0 - 1 : MODE == kConvS2 ? 2 * oz0 - 1 : oz0 / 2;
+  const int iy0 = MODE == kConvS1 ? oy0 - 1 : MODE == kConvS2 ? 2 * oy0 - 1 : oy0 / 2;
+  const int ix0 = MODE == kConvS1 ? ox0 - 1 : MODE == kConvS2 ? 2 * ox0 - 1 : ox0 / 2;
+
+  // per-lane LDS base offset of each of this wave's voxel blocks
+  int boff[C::NBW];
+#pragma unroll
+  for (int j = 0; j < C::NBW; ++j) {
+    int i = MODE == kDeconvS2 ? (j % C::NBC) : (wave * C::NBW + j);
+    int v = min(i * 16 + jn, C::NVC - 1);
+    int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
+    int off = MODE == kConvS2 ? ((2 * z) * C::IH + 2 * y) * C::IW + 2 * x
+                              : (z * C::IH + y) * C::IW + x;
+    boff[j] = off + kq * C::S;
+  }
+
+  f32x4 acc[C::NBW][C::MB];
+#pragma unroll
+  for (int j = 0; j < C::NBW; ++j)
+#pragma unroll
+    for (int m = 0; m < C::MB; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
+  const float* inb = p.in + (size_t)n * C::CIN * in_plane;
+  const float* wl = p.wp + lane;
+
+  for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
+    __syncthreads();
+    for (int idx = tid; idx < C::CK * C::PLANE; idx += 256) {
+      const int ck = idx / C::PLANE, rem = idx % C::PLANE;
+      const int zz = rem / (C::IH * C::IW), yy = (rem / C::IW) % C::IH, xx = rem % C::IW;
+      const int gz = iz0 + zz, gy = iy0 + yy, gx = ix0 + xx;
+      float v = 0.f;
+      if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+        v = inb[(size_t)(chunk * C::CK + ck) * in_plane + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
+      xs[ck * C::S + rem] = v;
+    }
+    __syncthreads();
+
+    if constexpr (MODE != kDeconvS2) {
+#pragma unroll 1
+      for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+        for (int kyx = 0; kyx < 9; ++kyx) {
+          const int ky = kyx / 3, kx = kyx % 3;
+          const int tap = kz * 9 + kyx;
+          const int tapoff = (kz * C::IH + ky) * C::IW + kx;
+#pragma unroll
+          for (int c4 = 0; c4 < C::C4; ++c4) {
+            float a[C::MB];
+#pragma unroll
+            for (int m = 0; m < C::MB; ++m)
+              a[m] = wl[(size_t)((((chunk * 27 + tap) * C::C4 + c4) * C::MB + m)) * 64];
+#pragma unroll
+            for (int j = 0; j < C::NBW; ++j) {
+              const float bv = xs[boff[j] + tapoff + c4 * 4 * C::S];
+#pragma unroll
+              for (int m = 0; m < C::MB; ++m)
+                acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[j][m], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        const int cls = wave * 2 + cl;
+        const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll 1
+        for (int tap = 0; tap < 27; ++tap) {
+          const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+          // parity p == 0 (even output): only k = 1; p == 1: k = 0 (input c+1) and k = 2 (input c)
+          if ((pz == 0) != (kz == 1)) continue;
+          if ((py == 0) != (ky == 1)) continue;
+          if ((px == 0) != (kx == 1)) continue;
+          const int dz = kz == 0 ? 1 : 0, dy = ky == 0 ? 1 : 0, dx = kx == 0 ? 1 : 0;
+          const int tapoff = (dz * C::IH + dy) * C::IW + dx;
+#pragma unroll
+          for (int c4 = 0; c4 < C::C4; ++c4) {
+            float a[C::MB];
+#pragma unroll
+            for (int m = 0; m < C::MB; ++m)
+              a[m] = wl[(size_t)((((chunk * 27 + tap) * C::C4 + c4) * C::MB + m)) * 64];
+#pragma unroll
+            for (int i = 0; i < C::NBC; ++i) {
+              const float bv = xs[boff[cl * C::NBC + i] + tapoff + c4 * 4 * C::S];
+#pragma unroll
+              for (int m = 0; m < C::MB; ++m)
+                acc[cl * C::NBC + i][m] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[cl * C::NBC + i][m], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, ReLU, skip, store ([n, COUT, Do, Ho, Wo]) -------------------------------
+  const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < C::NBW; ++j) {
+    int i, pz = 0, py = 0, px = 0;
+    if constexpr (MODE == kDeconvS2) {
+      const int cls = wave * 2 + j / C::NBC;
+      pz = (cls >> 2) & 1; py = (cls >> 1) & 1; px = cls & 1;
+      i = j % C::NBC;
+    } else {
+      i = wave * C::NBW + j;
+    }
+    const int v = i * 16 + jn;
+    if (v >= C::NVC) continue;
+    int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
+    if constexpr (MODE == kDeconvS2) { z = 2 * z + pz; y = 2 * y + py; x = 2 * x + px; }
+    const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+    if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+    const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+    for (int m = 0; m < C::MB; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m * 16 + kq * 4 + r;
+        if (co < C::COUT) {
+          float val = acc[j][m][r] + p.bias[co];
+          if (p.relu) val = fmaxf(val, 0.f);
+          const size_t o = ((size_t)n * C::COUT + co) * out_plane + sp;
+          if (p.skip) val += p.skip[o];
+          p.out[o] = val;
+        }
+      }
+    }
+  }
+}
+
+// ---- prob conv (base -> 1 channel, bias, no BN/ReLU; mvsnet.py:152,162) ---------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out, int n, int D, int H,
+                                                        int W) {
+  __shared__ float sw[CIN * 27];
+  for (int i = threadIdx.x; i < CIN * 27; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const size_t plane = (size_t)D * H * W;
+  const size_t total = (size_t)n * plane;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int x = gid % W, y = (gid / W) % H, z = (gid / ((size_t)W * H)) % D;
+  const int b = gid / plane;
+  const float* inb = in + (size_t)b * CIN * plane;
+  float acc = 0.f;
+  for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const int gz = z + kz - 1;
+      if (gz < 0 || gz >= D) continue;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int gy = y + ky - 1;
+        if (gy < 0 || gy >= H) continue;
+        const float* row = inb + (size_t)ci * plane + ((size_t)gz * H + gy) * W;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int gx = x + kx - 1;
+          if (gx >= 0 && gx < W) acc += row[gx] * sw[ci * 27 + (kz * 3 + ky) * 3 + kx];
+        }
+      }
+    }
+  }
+  out[gid] = acc + bias[0];
+}
+
+// ---- soft-argmin over D (mvsnet.py:219-227): p = softmax(-x), depth = sum_d vals[d] p[d] ----------
+__global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restrict__ reg,
+                                                          const float* __restrict__ vals,
+                                                          float* __restrict__ depth, int n, int D,
+                                                          int HW) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)n * HW) return;
+  const int b = gid / HW, pix = gid % HW;
+  const float* col = reg + (size_t)b * D * HW + pix;
+  float m = -INFINITY;
+  for (int d = 0; d < D; ++d) m = fmaxf(m, -col[(size_t)d * HW]);
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) s += expf(-col[(size_t)d * HW] - m);
+  float e = 0.f;
+  for (int d = 0; d < D; ++d) e += vals[d] * (expf(-col[(size_t)d * HW] - m) / s);
+  depth[gid] = e;
+}
+
+// ---- layer table ---------------------------------------------------------------------------------
+//                       mode      Cin Cout  TD TH  TW  CK
+typedef ConvCfg<kConvS1, 32, 8, 4, 8, 56, 4> L0;
+typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
+typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
+typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
+typedef ConvCfg<kConvS1, 32, 32, 4, 7, 14, 8> L4;
+typedef ConvCfg<kConvS2, 32, 64, 2, 7, 7, 8> L5;
+typedef ConvCfg<kConvS1, 64, 64, 4, 7, 7, 16> L6;
+typedef ConvCfg<kDeconvS2, 64, 32, 4, 14, 14, 16> L7;
+typedef ConvCfg<kDeconvS2, 32, 16, 4, 14, 28, 8> L8;
+typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 56, 8> L9;
+
+struct LayerDesc { int mode, cin, cout, ck; };
+const LayerDesc kLayers[10] = {
+    {kConvS1, 32, 8, L0::CK},   {kConvS2, 8, 16, L1::CK},   {kConvS1, 16, 16, L2::CK},
+    {kConvS2, 16, 32, L3::CK},  {kConvS1, 32, 32, L4::CK},  {kConvS2, 32, 64, L5::CK},
+    {kConvS1, 64, 64, L6::CK},  {kDeconvS2, 64, 32, L7::CK}, {kDeconvS2, 32, 16, L8::CK},
+    {kDeconvS2, 16, 8, L9::CK}};
+
+template <class C>
+int launch_conv(const char* name, const float* in, const float* wp, const float* bias,
+                const float* skip, float* out, int n, int Di, int Hi, int Wi, hipStream_t s) {
+  ConvParams p;
+  p.in = in; p.wp = wp; p.bias = bias; p.skip = skip; p.out = out; p.n = n;
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  if (C::MODE == kConvS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
+  else if (C::MODE == kConvS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
+  else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
+  p.ntz = (p.Do + C::TD - 1) / C::TD; p.nty = (p.Ho + C::TH - 1) / C::TH; p.ntx = (p.Wo + C::TW - 1) / C::TW;
+  p.relu = 1;
+  const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
+  V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv3d: bad grid");
+  {
+    v3d::TimedScope ts(name, s);
+    conv3d_mfma_kernel<C><<<(unsigned)blocks, 256, 0, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH("conv3d_mfma_kernel");
+  return V3D_OK;
+}
+
+}  // namespace
+
+struct v3d_costreg_weights {
+  int in_channels, base;
+  float* dev;                 // one allocation holding everything below
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, total;
+};
+
+extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
+                                const float* const* bn_b, const float* const* bn_m,
+                                const float* const* bn_v, const float* prob_w, const float* prob_b,
+                                int in_channels, int base, float eps,
+                                v3d_costreg_weights** out_handle) {
+  V3D_REQUIRE(conv_w && bn_w && bn_b && bn_m && bn_v && prob_w && prob_b && out_handle,
+              V3D_ERR_BAD_ARG, "v3d_costreg_pack: null argument");
+  V3D_REQUIRE(in_channels == 32 && base == 8, V3D_ERR_UNSUPPORTED,
+              "v3d_costreg_pack: only CostRegNet(32, 8) is built (got %d, %d)", in_channels, base);
+  v3d_costreg_weights* h = new v3d_costreg_weights();
+  h->in_channels = in_channels; h->base = base;
+  std::vector<float> host;
+  auto reserve = [&](size_t nfloat) { size_t o = host.size(); host.resize(o + (nfloat + 63) / 64 * 64, 0.f); return o; };
+  for (int l = 0; l < 10; ++l) {
+    const LayerDesc& L = kLayers[l];
+    const int MB = (L.cout + 15) / 16, C4 = L.ck / 4, nchunk = L.cin / L.ck;
+    h->wp_ofs[l] = reserve((size_t)nchunk * 27 * C4 * MB * 64);
+    h->bias_ofs[l] = reserve(L.cout);
+    float* wp = host.data() + h->wp_ofs[l];
+    float* bias = host.data() + h->bias_ofs[l];
+    std::vector<float> scale(L.cout);
+    for (int co = 0; co < L.cout; ++co) {
+      // eval-mode BatchNorm: y = (x - mean) / sqrt(var + eps) * gamma + beta   (mvsnet.py:22,33)
+      scale[co] = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+      bias[co] = bn_b[l][co] - bn_m[l][co] * scale[co];
+    }
+    for (int chunk = 0; chunk < nchunk; ++chunk)
+      for (int tap = 0; tap < 27; ++tap)
+        for (int c4 = 0; c4 < C4; ++c4)
+          for (int m = 0; m < MB; ++m)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int co = m * 16 + (lane & 15);
+              const int ci = chunk * L.ck + c4 * 4 + (lane >> 4);
+              float v = 0.f;
+              if (co < L.cout) {
+                // Conv3d weight [Co, Ci, 3,3,3]; ConvTranspose3d weight [Ci, Co, 3,3,3]
+                const size_t idx = L.mode == kDeconvS2 ? ((size_t)ci * L.cout + co) * 27 + tap
+                                                       : ((size_t)co * L.cin + ci) * 27 + tap;
+                v = conv_w[l][idx] * scale[co];
+              }
+              wp[((((size_t)chunk * 27 + tap) * C4 + c4) * MB + m) * 64 + lane] = v;
+            }
+  }
+  h->prob_w_ofs = reserve((size_t)base * 27);
+  memcpy(host.data() + h->prob_w_ofs, prob_w, sizeof(float) * base * 27);
+  h->prob_b_ofs = reserve(1);
+  host[h->prob_b_ofs] = prob_b[0];
+  h->total = host.size();
+  hipError_t e = hipMalloc((void**)&h->dev, h->total * sizeof(float));
+  if (e != hipSuccess) { delete h; return v3d::fail(V3D_ERR_HIP, "hipMalloc(weights): %s", hipGetErrorString(e)); }
+  e = hipMemcpy(h->dev, host.data(), h->total * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return v3d::fail(V3D_ERR_HIP, "hipMemcpy(weights): %s", hipGetErrorString(e)); }
+  *out_handle = h;
+  return V3D_OK;
+}
+
+extern "C" void v3d_costreg_free(v3d_costreg_weights* h) {
+  if (!h) return;
+  if (h->dev) (void)hipFree(h->dev);
+  delete h;
+}
+
+static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, const float* skip,
+                     float* out, int n, int Di, int Hi, int Wi, hipStream_t s) {
+  const float* wp = h->dev + h->wp_ofs[layer];
+  const float* bias = h->dev + h->bias_ofs[layer];
+  switch (layer) {
+    case 0: return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 1: return launch_conv<L1>("costreg_conv1", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 2: return launch_conv<L2>("costreg_conv2", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 3: return launch_conv<L3>("costreg_conv3", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 4: return launch_conv<L4>("costreg_conv4", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 5: return launch_conv<L5>("costreg_conv5", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 6: return launch_conv<L6>("costreg_conv6", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 7: return launch_conv<L7>("costreg_conv7", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 8: return launch_conv<L8>("costreg_conv8", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 9: return launch_conv<L9>("costreg_conv9", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+  }
+  return v3d::fail(V3D_ERR_BAD_ARG, "costreg: layer %d out of range", layer);
+}
+
+extern "C" int v3d_costreg_layer_f32(const v3d_costreg_weights* h, int layer, const float* in,
+                                     const float* skip, int n, int Di, int Hi, int Wi, float* out,
+                                     void* stream) {
+  V3D_REQUIRE(h && in && out, V3D_ERR_BAD_ARG, "v3d_costreg_layer_f32: null argument");
+  V3D_REQUIRE(n > 0 && Di > 0 && Hi > 0 && Wi > 0, V3D_ERR_BAD_SHAPE, "v3d_costreg_layer_f32: bad shape");
+  return run_layer(h, layer, in, skip, out, n, Di, Hi, Wi, (hipStream_t)stream);
+}
+
+namespace {
+struct WsPlan { size_t c0, c1, c2, c3, c4, c5, c6, u7, u8, u9, reg, total; };
+WsPlan plan_ws(int n, int D, int h, int w) {
+  const size_t V0 = (size_t)D * h * w, V1 = V0 / 8, V2 = V1 / 8, V3 = V2 / 8;
+  WsPlan p; size_t o = 0;
+  auto take = [&](size_t nf) { size_t r = o; o += v3d::align_up(nf * sizeof(float), 256); return r; };
+  p.c0 = take(n * 8 * V0); p.c1 = take(n * 16 * V1); p.c2 = take(n * 16 * V1);
+  p.c3 = take(n * 32 * V2); p.c4 = take(n * 32 * V2); p.c5 = take(n * 64 * V3);
+  p.c6 = take(n * 64 * V3); p.u7 = take(n * 32 * V2); p.u8 = take(n * 16 * V1);
+  p.u9 = take(n * 8 * V0); p.reg = take(n * V0); p.total = o;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights*, int n_ref, int D, int h, int w) {
+  if (n_ref <= 0 || D <= 0 || h <= 0 || w <= 0) return 0;
+  return plan_ws(n_ref, D, h, w).total;
+}
+
+extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var,
+                                     const float* depth_vals, int n, int D, int H, int W,
+                                     float* depth, float* reg, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(h && var && depth_vals && depth && workspace, V3D_ERR_BAD_ARG,
+              "v3d_costreg_depth_f32: null argument");
+  V3D_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0,
+              V3D_ERR_BAD_SHAPE, "v3d_costreg_depth_f32: D,h,w must be positive multiples of 8 (got %d,%d,%d)", D, H, W);
+  const WsPlan ws = plan_ws(n, D, H, W);
+  V3D_REQUIRE(workspace_bytes >= ws.total, V3D_ERR_WORKSPACE_TOO_SMALL,
+              "v3d_costreg_depth_f32: workspace %zu < %zu", workspace_bytes, ws.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  auto F = [&](size_t o) { return (float*)(base + o); };
+  float* xreg = reg ? reg : F(ws.reg);
+  int rc;
+#define RUN(layer, in, skip, out, d, hh, ww) \
+  if ((rc = run_layer(h, layer, in, skip, out, n, d, hh, ww, s)) != V3D_OK) return rc;
+  RUN(0, var, nullptr, F(ws.c0), D, H, W);
+  RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
+  RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
+  RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
+  RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
+  RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
+  RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
+  RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
+  RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
+  RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
+#undef RUN
+  const size_t total = (size_t)n * D * H * W;
+  {
+    v3d::TimedScope ts("costreg_prob", s);
+    prob_conv_kernel<8><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
+        F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W);
+  }
+  V3D_CHECK_LAUNCH("prob_conv_kernel");
+  const size_t npix = (size_t)n * H * W;
+  {
+    v3d::TimedScope ts("soft_argmin", s);
+    soft_argmin_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(xreg, depth_vals, depth, n, D, H * W);
+  }
+  V3D_CHECK_LAUNCH("soft_argmin_kernel");
+  return V3D_OK;
+}

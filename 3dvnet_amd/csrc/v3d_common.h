@@ -1,0 +1,65 @@
+// Shared helpers for lib3dvnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "v3d.h"
+
+namespace v3d {
+
+inline char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define V3D_CHECK_HIP(expr)                                                                    \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return v3d::fail(V3D_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                       __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define V3D_CHECK_LAUNCH(name)                                                                 \
+  do {                                                                                         \
+    hipError_t e_ = hipGetLastError();                                                         \
+    if (e_ != hipSuccess)                                                                      \
+      return v3d::fail(V3D_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_));   \
+  } while (0)
+
+#define V3D_REQUIRE(cond, code, ...)                                                           \
+  do {                                                                                         \
+    if (!(cond)) return v3d::fail(code, __VA_ARGS__);                                          \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Optional per-kernel timing (v3d_timing_* in include/v3d.h): when enabled every launch made through
+// V3D_LAUNCH is bracketed by hipEvents on its own stream.  Off by default (zero overhead).
+bool timing_enabled();
+void timing_begin(const char* name, hipStream_t s);
+void timing_end(hipStream_t s);
+
+struct TimedScope {
+  hipStream_t s;
+  bool on;
+  TimedScope(const char* name, hipStream_t s_) : s(s_), on(timing_enabled()) {
+    if (on) timing_begin(name, s);
+  }
+  ~TimedScope() {
+    if (on) timing_end(s);
+  }
+};
+
+}  // namespace v3d

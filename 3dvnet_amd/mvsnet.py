@@ -1,0 +1,278 @@
+"""Host-side mirror of ``mv3d/subnetworks/mvsnet.py`` for the cost-volume path (SURVEY.md §8a rows
+A1-A7, §8b).  Same class names, constructor arguments, ``forward`` signatures, return tuples,
+tensor layouts and ``state_dict`` keys as the reference; the arithmetic runs in
+``lib3dvnet_hip.so`` (hand-written gfx950 kernels) through the C ABI of ``include/v3d.h``.
+
+There is NO CPU / eager-PyTorch fallback: without the built HIP library every forward raises
+``V3DLibraryError``.  Inference only (the reference's benchmark path runs under
+``torch.no_grad()``, mv3d/eval-3dvnet.py:27).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _Workspace:
+    """Grow-only device scratch buffers keyed by name (the C ABI never allocates tensor memory)."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name, nbytes, device):
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[name] = buf
+        return buf
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.V3DLibraryError('%s: tensors must live on a HIP device (no CPU fallback)' % what)
+
+
+class ConvBnRelu3d(nn.Module):
+    """Parameter container with the reference's keys ``conv.weight`` / ``bn.*`` (mvsnet.py:18-25).
+    The arithmetic is executed by the fused HIP layer kernel, not by these modules."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride, padding, bias=False)
+        self.bn = nn.BatchNorm3d(out_channels)
+
+
+class DeconvBnRelu3d(nn.Module):
+    """Parameter container with keys ``deconv.weight`` / ``bn.*`` (mvsnet.py:28-36)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=2, padding=1,
+                 output_padding=1):
+        super().__init__()
+        self.deconv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride, padding,
+                                         output_padding, bias=False)
+        self.bn = nn.BatchNorm3d(out_channels)
+
+
+class CostRegNet(nn.Module):
+    """Dense 3D-conv regulariser, reference ``CostRegNet(in_channels, base_channels)``
+    (mvsnet.py:133-163).  ``forward(x[B,Cin,D,h,w]) -> [B,1,D,h,w]``."""
+
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        b = base_channels
+        self.in_channels, self.base_channels = in_channels, base_channels
+        self.conv0 = ConvBnRelu3d(in_channels, b)
+        self.conv1 = ConvBnRelu3d(b, 2 * b, stride=2)
+        self.conv2 = ConvBnRelu3d(2 * b, 2 * b)
+        self.conv3 = ConvBnRelu3d(2 * b, 4 * b, stride=2)
+        self.conv4 = ConvBnRelu3d(4 * b, 4 * b)
+        self.conv5 = ConvBnRelu3d(4 * b, 8 * b, stride=2)
+        self.conv6 = ConvBnRelu3d(8 * b, 8 * b)
+        self.conv7 = DeconvBnRelu3d(8 * b, 4 * b, output_padding=1)
+        self.conv8 = DeconvBnRelu3d(4 * b, 2 * b)
+        self.conv9 = DeconvBnRelu3d(2 * b, b, output_padding=1)
+        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1)
+        self._handle = None
+        self._packed_key = None
+        self._ws = _Workspace()
+
+    # -- weight packing (BN fold + MFMA fragment order happen inside the library) ---------------
+    def _layers(self):
+        return [getattr(self, 'conv%d' % i) for i in range(10)]
+
+    def _state_key(self):
+        return tuple(int(p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def packed_handle(self):
+        key = self._state_key()
+        if self._handle is not None and key == self._packed_key:
+            return self._handle
+        self.release()
+        lib = _lib.load()
+        keep = []
+
+        def host(t):
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_float_p)
+
+        def parray(ts):
+            arr = (_lib.c_float_p * len(ts))(*[host(t) for t in ts])
+            keep.append(arr)
+            return arr
+
+        layers = self._layers()
+        convs = [(l.conv if hasattr(l, 'conv') else l.deconv).weight for l in layers]
+        eps = {float(l.bn.eps) for l in layers}
+        assert len(eps) == 1
+        handle = ctypes.c_void_p()
+        rc = lib.v3d_costreg_pack(parray(convs), parray([l.bn.weight for l in layers]),
+                                  parray([l.bn.bias for l in layers]),
+                                  parray([l.bn.running_mean for l in layers]),
+                                  parray([l.bn.running_var for l in layers]),
+                                  host(self.prob.weight), host(self.prob.bias),
+                                  self.in_channels, self.base_channels, eps.pop(),
+                                  ctypes.byref(handle))
+        _lib.check(rc, 'v3d_costreg_pack')
+        self._handle, self._packed_key = handle, key
+        return handle
+
+    def release(self):
+        if self._handle is not None:
+            _lib.load().v3d_costreg_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # -- execution --------------------------------------------------------------------------------
+    def regularize_depth(self, x, depth_vals, return_reg=False):
+        """Rows A5-A6 fused: x [B,Cin,D,h,w] variance volume, depth_vals [D] ->
+        depth [B,h,w] (and x_reg [B,D,h,w] when return_reg)."""
+        _require_cuda(x, 'CostRegNet')
+        assert not self.training, 'inference only: BatchNorm is folded with running statistics'
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, C, D, h, w = x.shape
+        assert C == self.in_channels
+        handle = self.packed_handle()
+        depth = torch.empty((B, h, w), dtype=torch.float32, device=x.device)
+        reg = torch.empty((B, D, h, w), dtype=torch.float32, device=x.device) if return_reg else None
+        nbytes = lib.v3d_costreg_workspace_bytes(handle, B, D, h, w)
+        ws = self._ws.get('costreg', nbytes, x.device)
+        depth_vals = depth_vals.to(device=x.device, dtype=torch.float32).contiguous()
+        rc = lib.v3d_costreg_depth_f32(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w,
+                                       _lib.ptr(depth), _lib.ptr(reg), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(x.device))
+        _lib.check(rc, 'v3d_costreg_depth_f32')
+        return (depth, reg) if return_reg else depth
+
+    def run_layer(self, layer, x, skip=None):
+        """One conv/deconv + folded BN + ReLU (+ skip) layer, for per-layer parity tests."""
+        _require_cuda(x, 'CostRegNet')
+        lib = _lib.load()
+        x = x.contiguous().float()
+        n, _, Di, Hi, Wi = x.shape
+        mod = self._layers()[layer]
+        if hasattr(mod, 'deconv'):
+            co, shape = mod.deconv.out_channels, (2 * Di, 2 * Hi, 2 * Wi)
+        else:
+            s = mod.conv.stride[0]
+            co, shape = mod.conv.out_channels, tuple((d - 1) // s + 1 for d in (Di, Hi, Wi))
+        out = torch.empty((n, co) + shape, dtype=torch.float32, device=x.device)
+        if skip is not None:
+            skip = skip.contiguous().float()
+            assert skip.shape == out.shape
+        rc = lib.v3d_costreg_layer_f32(self.packed_handle(), layer, _lib.ptr(x), _lib.ptr(skip), n,
+                                       Di, Hi, Wi, _lib.ptr(out), _lib.stream_ptr(x.device))
+        _lib.check(rc, 'v3d_costreg_layer_f32')
+        return out
+
+    def forward(self, x):
+        D = x.shape[2]
+        zeros = torch.zeros(D, dtype=torch.float32, device=x.device)
+        _, reg = self.regularize_depth(x, zeros, return_reg=True)
+        return reg.unsqueeze(1)
+
+
+def edges_to_csr(ref_src_edges):
+    """ref_src_edges [2,E] -> (ref_idx [n_ref] int64 sorted unique, ref_img i32, edge_ofs i32
+    [n_ref+1], edge_src i32 [E] grouped per reference in original edge order).  Mirrors
+    ``torch.unique(edges[0], return_inverse=True)`` + scatter-by-``gather_idx`` (mvsnet.py:179,
+    214-215) so the per-reference sums run over the same edges in the same order."""
+    ref_idx, gather_idx = torch.unique(ref_src_edges[0], return_inverse=True)
+    n_ref = ref_idx.shape[0]
+    order = torch.sort(gather_idx, stable=True).indices
+    edge_src = ref_src_edges[1][order].to(torch.int32).contiguous()
+    counts = torch.bincount(gather_idx, minlength=n_ref)
+    edge_ofs = torch.zeros(n_ref + 1, dtype=torch.int32, device=ref_src_edges.device)
+    edge_ofs[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ref_idx, ref_idx.to(torch.int32).contiguous(), edge_ofs, edge_src
+
+
+def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, depth_start,
+                         depth_interval, n_planes, img_size, depth_img_size, workspace=None,
+                         csr=None):
+    """Rows A1-A4 (mvsnet.py:186-216): variance cost volume [n_ref, C, D, h, w]."""
+    _require_cuda(features_quarter, 'plane_sweep_variance')
+    lib = _lib.load()
+    feat = features_quarter.contiguous().float()
+    dev = feat.device
+    n_img, C, Hf, Wf = feat.shape
+    if csr is None:
+        csr = edges_to_csr(ref_src_edges.to(dev))
+    _, ref_img, edge_ofs, edge_src = csr
+    n_ref, n_edges = ref_img.shape[0], edge_src.shape[0]
+    h, w = depth_img_size
+    var = torch.empty((n_ref, C, n_planes, h, w), dtype=torch.float32, device=dev)
+    nbytes = lib.v3d_psv_workspace_bytes(n_img, C, Hf, Wf)
+    ws = (workspace or _Workspace()).get('psv', nbytes, dev)
+    Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
+    rc = lib.v3d_psv_variance_f32(_lib.ptr(feat), _lib.ptr(Kc), _lib.ptr(Rc), _lib.ptr(tc),
+                                  _lib.ptr(ref_img), _lib.ptr(edge_ofs), _lib.ptr(edge_src),
+                                  n_img, n_ref, n_edges, C, Hf, Wf, int(img_size[0]),
+                                  int(img_size[1]), float(depth_start), float(depth_interval),
+                                  int(n_planes), int(h), int(w), _lib.ptr(var), _lib.ptr(ws),
+                                  ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, 'v3d_psv_variance_f32')
+    return var
+
+
+class MVSNet(nn.Module):
+    """Reference ``MVSNet(feat_dim=32, img_size=(240, 320))`` (mvsnet.py:166-229).
+
+    ``forward(batch, depth_start, depth_interval, n_planes, depth_img_size) ->
+    (depth_img[n_ref,h,w], features_half, features_quarter, features_eighth)``.
+
+    ``feat_extractor`` / ``feat_shrinker`` (the 2D MnasNet + FPN backbone, stock PyTorch modules in
+    the reference) are injected; when they are ``None`` the batch must carry
+    pre-computed ``features_half / features_quarter / features_eighth`` attributes."""
+
+    def __init__(self, feat_dim=32, img_size=(240, 320), feat_extractor=None, feat_shrinker=None):
+        super().__init__()
+        self.feat_dim = feat_dim
+        self.img_size = img_size
+        self.feat_extractor = feat_extractor
+        self.feat_shrinker = feat_shrinker
+        self.cnn_3d = CostRegNet(feat_dim, 8)
+        self._ws = _Workspace()
+        self._depth_vals = {}
+
+    def depth_values(self, depth_start, depth_interval, n_planes, device):
+        """torch.linspace(depth_start, depth_end, n_planes) built on the CPU then moved, exactly
+        like mvsnet.py:223 (`.type_as(batch.images)`), cached per configuration."""
+        key = (float(depth_start), float(depth_interval), int(n_planes), str(device))
+        if key not in self._depth_vals:
+            depth_end = depth_start + depth_interval * (n_planes - 1)
+            self._depth_vals[key] = torch.linspace(depth_start, depth_end, n_planes).to(device)
+        return self._depth_vals[key]
+
+    def cost_volume_depth(self, features_quarter, batch, depth_start, depth_interval, n_planes,
+                          depth_img_size, return_intermediates=False, csr=None):
+        """Rows A1-A6 from quarter-resolution features."""
+        var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
+                                   batch.ref_src_edges, depth_start, depth_interval, n_planes,
+                                   self.img_size, depth_img_size, workspace=self._ws, csr=csr)
+        vals = self.depth_values(depth_start, depth_interval, n_planes, var.device)
+        if return_intermediates:
+            depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True)
+            return depth, var, reg
+        return self.cnn_3d.regularize_depth(var, vals)
+
+    def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size):
+        if self.feat_extractor is not None:
+            features_half, features_quarter, features_eighth, _, _ = \
+                self.feat_shrinker(*self.feat_extractor(batch.images))
+        else:
+            features_half = getattr(batch, 'features_half', None)
+            features_quarter = batch.features_quarter
+            features_eighth = getattr(batch, 'features_eighth', None)
+        depth_img = self.cost_volume_depth(features_quarter, batch, depth_start, depth_interval,
+                                           n_planes, depth_img_size)
+        return depth_img, features_half, features_quarter, features_eighth

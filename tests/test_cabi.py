@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/v3d.h declares (no compute
+calls without a GPU), and the product path fails loudly without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, v3d
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'v3d.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(v3d_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib_mod = v3d('_lib')
+    if not os.path.exists(lib_mod.LIB_PATH):
+        v3d('build').build()
+    names = _declared_symbols()
+    assert len(names) >= 9
+    raw = ctypes.CDLL(lib_mod.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), 'library does not export %s' % n
+        assert n in lib_mod.SIGNATURES, 'no ctypes signature for %s' % n
+    assert set(lib_mod.SIGNATURES) == set(names)
+    lib = lib_mod.load()
+    assert lib.v3d_version() == lib_mod.ABI_VERSION
+
+
+def test_host_side_argument_validation():
+    """Error paths that return before touching the device."""
+    lib_mod = v3d('_lib')
+    lib = lib_mod.load()
+    assert lib.v3d_psv_workspace_bytes(8, 32, 64, 80) == 8 * 32 * 64 * 80 * 4
+    rc = lib.v3d_psv_variance_f32(None, None, None, None, None, None, None, 1, 1, 1, 32, 4, 4, 8, 8,
+                                  0.5, 0.05, 8, 8, 8, None, None, 0, None)
+    assert rc == -2 and b'null' in lib.v3d_last_error()
+    with pytest.raises(lib_mod.V3DLibraryError):
+        lib_mod.check(rc, 'psv')
+
+
+def test_no_cpu_fallback():
+    mvs = v3d('mvsnet')
+    lib_mod = v3d('_lib')
+    net = mvs.CostRegNet(32, 8).eval()
+    with pytest.raises(lib_mod.V3DLibraryError):
+        net(torch.zeros(1, 32, 8, 8, 8))
+    with pytest.raises(lib_mod.V3DLibraryError):
+        mvs.plane_sweep_variance(torch.zeros(2, 32, 4, 4), torch.eye(3).repeat(2, 1, 1),
+                                 torch.zeros(2, 3), torch.eye(3).repeat(2, 1, 1),
+                                 torch.tensor([[0, 0], [0, 1]]), 0.5, 0.05, 8, (16, 16), (8, 8))
+
+
+def test_state_dict_keys_match_reference_naming():
+    """CostRegNet keys enumerated in SURVEY.md §8b (mvsnet.py:133-163)."""
+    mvs, syn = v3d('mvsnet'), v3d('synthetic')
+    net = mvs.CostRegNet(32, 8)
+    sd = syn.costregnet_weights()
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.endswith('num_batches_tracked') for k in res.missing_keys)
+    assert net.conv7.deconv.weight.shape == (64, 32, 3, 3, 3)
+    assert net.prob.weight.shape == (1, 8, 3, 3, 3)
+
+
+def test_edges_to_csr_matches_unique_semantics():
+    mvs = v3d('mvsnet')
+    e = torch.tensor([[5, 2, 5, 2, 9, 5], [0, 1, 2, 3, 4, 5]])
+    ref_idx, ref_img, ofs, src = mvs.edges_to_csr(e)
+    assert ref_idx.tolist() == [2, 5, 9]
+    assert ofs.tolist() == [0, 2, 5, 6]
+    assert src.tolist() == [1, 3, 0, 2, 5, 4]

@@ -1,0 +1,180 @@
+"""GPU parity tests, rows A1-A6: the HIP path (through the C ABI) against the golden vectors
+captured from the reference and against the oracle on the same seeded inputs.
+
+Tolerances (fp32 path, BASELINE.json north_star: depth within 1e-4 relative):
+  variance volume  : 2e-5 absolute (values are O(0.1); bilinear weights/coordinates are fp32)
+  regularised vol. : 2e-4 * max|x_reg|
+  depth            : 1e-4 relative
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import v3d
+from helpers import golden_costreg_weights, load_golden, t
+from oracle import costvolume as ocv
+
+pytestmark = pytest.mark.gpu
+
+VAR_ATOL = 2e-5
+DEPTH_RTOL = 1e-4
+
+
+def _net(sd, dev, img_size):
+    mvs = v3d('mvsnet')
+    net = mvs.MVSNet(32, img_size).eval()
+    net.cnn_3d.load_state_dict(sd, strict=False)
+    return net.to(dev)
+
+
+def _run_hip(net, feat, R, tv, K, edges, depth_cfg, plane_size, dev):
+    Batch = v3d('batch').Batch
+    b = Batch(None, R, tv, K, None, edges).to(dev)
+    d0, dd, D = depth_cfg
+    with torch.no_grad():
+        depth, var, reg = net.cost_volume_depth(feat.to(dev), b, float(d0), float(dd), int(D),
+                                                tuple(plane_size), return_intermediates=True)
+    torch.cuda.synchronize()
+    return depth.cpu(), var.cpu(), reg.cpu()
+
+
+@pytest.mark.parametrize('name', ['A_tiny_flat', 'A_tiny_sharp', 'A_tiny_rotated'])
+def test_hip_matches_reference_golden_tiny(name, cuda):
+    g = load_golden(name)
+    sd = golden_costreg_weights(g)
+    img_size = tuple(int(v) for v in g['img_size'])
+    plane_size = tuple(int(v) for v in g['plane_size'])
+    net = _net(sd, cuda, img_size)
+    depth, var, reg = _run_hip(net, t(g['feat']), t(g['rotmats']), t(g['tvecs']), t(g['K']),
+                               t(g['edges']), g['depth_cfg'], plane_size, cuda)
+    np.testing.assert_allclose(var.numpy(), g['var'], rtol=0, atol=VAR_ATOL)
+    scale = float(np.abs(g['reg']).max())
+    np.testing.assert_allclose(reg.numpy(), g['reg'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=DEPTH_RTOL, atol=0)
+
+
+@pytest.mark.parametrize('name,cfg', [('A_cfg1', 'cfg1'), ('A_cfg2', 'cfg2')])
+def test_hip_matches_reference_golden_cfg(name, cfg, cuda):
+    g = load_golden(name)
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs(cfg, n_ref=int(g['n_ref']))
+    assert abs(float(inp['feat'].double().sum()) - float(g['feat_checksum'])) < 1e-6
+    sd = golden_costreg_weights(g)
+    net = _net(sd, cuda, inp['img_size'])
+    depth, var, reg = _run_hip(net, inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                               inp['edges'], inp['depth'], inp['plane_size'], cuda)
+    if cfg == 'cfg1':
+        vs, rs = var[:, ::4, ::3, ::5, ::7], reg[:, ::3, ::5, ::7]
+    else:
+        vs, rs = var[:, ::4, ::5, ::7, ::7], reg[:, ::5, ::7, ::7]
+    np.testing.assert_allclose(vs.numpy(), g['var_sub'], rtol=0, atol=VAR_ATOL)
+    assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-4 * abs(float(g['var_sum']))
+    scale = float(np.abs(g['reg_sub']).max())
+    np.testing.assert_allclose(rs.numpy(), g['reg_sub'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=DEPTH_RTOL, atol=0)
+    # the gate is not vacuous: the sharpened weights give a wide depth range
+    assert g['depth'].max() - g['depth'].min() > 1.0
+
+
+def test_hip_matches_oracle_multi_ref(cuda):
+    """Several reference views per launch (sliding window), cfg1 shape, vs the oracle."""
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=77)
+    sd = syn.costregnet_weights(seed=4, sharpen=200.0)
+    d0, dd, D = inp['depth']
+    with torch.no_grad():
+        depth_o, var_o, reg_o = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                                                 inp['edges'], sd, d0, dd, D, inp['img_size'],
+                                                 inp['plane_size'])
+    net = _net(sd, cuda, inp['img_size'])
+    depth, var, reg = _run_hip(net, inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                               inp['edges'], inp['depth'], inp['plane_size'], cuda)
+    np.testing.assert_allclose(var.numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
+    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=2e-4 * float(reg_o.abs().max()))
+    np.testing.assert_allclose(depth.numpy(), depth_o.numpy(), rtol=DEPTH_RTOL, atol=0)
+
+
+def test_psv_ragged_edges_and_odd_grid(cuda):
+    """Ragged edge lists (1, 3 and 10 sources -- more than one LDS pass), a plane grid that is not
+    a multiple of the 64-pixel tile, D not a multiple of the plane chunk, unsorted edge order."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    img_size, feat_size, plane_size = (64, 80), (16, 20), (7, 9)
+    R, tv, K = syn.make_cameras(12, img_size, seed=3)
+    feat = syn.make_features(12, 32, *feat_size, seed=3)
+    refs = [4] + [7] * 3 + [2] * 10
+    srcs = [4] + [6, 7, 8] + list(range(0, 10))
+    perm = torch.randperm(len(refs), generator=torch.Generator().manual_seed(0))
+    edges = torch.tensor([refs, srcs])[:, perm]
+    var_o = ocv.warp_variance(feat, R, tv, K, edges, 0.5, 0.3, 6, img_size, plane_size)
+    var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 6, img_size,
+                                   plane_size)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
+
+
+def test_psv_feat_dim_16(cuda):
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    img_size, plane_size = (64, 80), (8, 8)
+    e, n_img = syn.make_edges(2, 1, 1)
+    R, tv, K = syn.make_cameras(n_img, img_size, seed=9)
+    feat = syn.make_features(n_img, 16, 16, 20, seed=9)
+    var_o = ocv.warp_variance(feat, R, tv, K, e, 0.5, 0.25, 8, img_size, plane_size)
+    var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, e.to(cuda), 0.5, 0.25, 8, img_size, plane_size)
+    np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
+
+
+@pytest.mark.parametrize('layer', list(range(10)))
+def test_costreg_single_layers(layer, cuda):
+    """Each conv / stride-2 conv / transposed conv layer (+folded BN, ReLU, skip) vs torch CPU,
+    on a volume whose sizes are NOT multiples of the kernel's tile (partial tiles, halos)."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    sd = syn.costregnet_weights(seed=5)
+    net = mvs.CostRegNet(32, 8).eval()
+    net.load_state_dict(sd, strict=False)
+    net = net.to(cuda)
+    cin = [32, 8, 16, 16, 32, 32, 64, 64, 32, 16][layer]
+    g = torch.Generator().manual_seed(layer)
+    shape = (2, cin, 6, 10, 12) if layer < 7 else (2, cin, 3, 5, 6)
+    x = torch.randn(shape, generator=g)
+    name = 'conv%d' % layer
+    if layer < 7:
+        ref = ocv.conv_bn_relu3d(x, sd, name, stride=2 if layer in (1, 3, 5) else 1)
+        skip = None
+    else:
+        ref = ocv.deconv_bn_relu3d(x, sd, name)
+        skip = torch.randn(ref.shape, generator=g)
+        ref = skip + ref
+    out = net.run_layer(layer, x.to(cuda), None if skip is None else skip.to(cuda))
+    torch.cuda.synchronize()
+    tol = 1e-5 * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=tol)
+
+
+def test_full_size_properties_cfg2_batch(cuda):
+    """BASELINE config-2 size, several references per launch: size-independent properties.
+    (1) a reference whose sources are all the reference itself has zero variance everywhere the
+        samples are in range; (2) depth lies within the plane range; (3) results do not depend on
+        how many references share a launch (batch of 4 == 4 single launches)."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg2', n_ref=4)
+    sd = syn.costregnet_weights(seed=0, sharpen=200.0)
+    net = _net(sd, cuda, inp['img_size'])
+    d0, dd, D = inp['depth']
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    feat = inp['feat'].to(cuda)
+    with torch.no_grad():
+        depth, var, reg = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'],
+                                                return_intermediates=True)
+        assert torch.isfinite(var).all() and torch.isfinite(depth).all()
+        assert depth.min() >= d0 - 1e-4 and depth.max() <= d0 + dd * (D - 1) + 1e-4
+        per = inp['edges'].shape[1] // 4
+        for i in range(4):
+            bi = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None,
+                       inp['edges'][:, i * per:(i + 1) * per]).to(cuda)
+            di = net.cost_volume_depth(feat, bi, d0, dd, D, inp['plane_size'])
+            assert torch.equal(di[0], depth[i])
+        self_edges = torch.tensor([[3] * 5, [3] * 5])
+        v_self = mvs.plane_sweep_variance(feat, b.rotmats, b.tvecs, b.K, self_edges.to(cuda), d0, dd, D,
+                                          inp['img_size'], inp['plane_size'])
+        assert float(v_self.abs().max()) < 1e-6

@@ -1,0 +1,62 @@
+"""CPU: the oracle restatement reproduces the golden vectors captured from the reference's own
+Python (tests/golden/make_golden.py).  Rows A1-A6."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import v3d
+from helpers import golden_costreg_weights, load_golden, t
+from oracle import costvolume as ocv
+
+
+def _run_tiny(g):
+    sd = golden_costreg_weights(g)
+    d0, dd, D = g['depth_cfg']
+    return ocv.mvsnet_depth(t(g['feat']), t(g['rotmats']), t(g['tvecs']), t(g['K']), t(g['edges']),
+                            sd, float(d0), float(dd), int(D), tuple(int(v) for v in g['img_size']),
+                            tuple(int(v) for v in g['plane_size']))
+
+
+@pytest.mark.parametrize('name', ['A_tiny_flat', 'A_tiny_sharp', 'A_tiny_rotated'])
+def test_oracle_matches_reference_tiny(name):
+    g = load_golden(name)
+    with torch.no_grad():
+        depth, var, reg = _run_tiny(g)
+    # same torch CPU ops as the reference => essentially bit-exact
+    np.testing.assert_allclose(var.numpy(), g['var'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reg.numpy(), g['reg'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=1e-5, atol=0)
+
+
+def test_rotated_fixture_exercises_mirroring_and_padding():
+    """The 'rotated' fixture must really contain points behind a source camera (|z| mirroring,
+    mvsnet.py:201) and samples falling outside the source image (zero padding)."""
+    g = load_golden('A_tiny_rotated')
+    d0, dd, D = g['depth_cfg']
+    img_size = tuple(int(v) for v in g['img_size'])
+    R, tv, K, e = t(g['rotmats']), t(g['tvecs']), t(g['K']), t(g['edges'])
+    pts = ocv.plane_sweep_points(float(d0), float(dd), int(D), R, tv, K, img_size,
+                                 tuple(int(v) for v in g['plane_size']))
+    P = torch.bmm(K, torch.cat((R, tv[..., None]), 2))
+    q = torch.bmm(P[e[1]], torch.cat((pts[e[0]], torch.ones(e.shape[1], 1, pts.shape[2])), 1))
+    assert (q[:, 2] < 0).any()
+    grid = ocv.project_to_grid(pts[e[0]], R, tv, K, e[1], img_size)
+    assert (grid.abs() > 1).any()
+
+
+@pytest.mark.parametrize('name,cfg', [('A_cfg1', 'cfg1')])
+def test_oracle_matches_reference_cfg(name, cfg):
+    g = load_golden(name)
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs(cfg, n_ref=int(g['n_ref']))
+    assert abs(float(inp['feat'].double().sum()) - float(g['feat_checksum'])) < 1e-6
+    sd = golden_costreg_weights(g)
+    d0, dd, D = inp['depth']
+    with torch.no_grad():
+        depth, var, reg = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                                           inp['edges'], sd, d0, dd, D, inp['img_size'],
+                                           inp['plane_size'])
+    np.testing.assert_allclose(var[:, ::4, ::3, ::5, ::7].numpy(), g['var_sub'], rtol=0, atol=1e-6)
+    assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-3
+    np.testing.assert_allclose(reg[:, ::3, ::5, ::7].numpy(), g['reg_sub'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=1e-5, atol=0)
