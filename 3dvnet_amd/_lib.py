@@ -7,6 +7,10 @@ operator raises ``V3DLibraryError``.  ``load()`` never builds implicitly -- run
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the library binds to the
+#               HIP runtime (libamdhip64) that PyTorch already loaded; loading ours first would
+#               bring a second, uninitialised runtime into the process.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
 ABI_VERSION = 1
@@ -88,7 +92,6 @@ def ptr(t):
 
 
 def stream_ptr(device):
-    import torch
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -44,8 +44,9 @@ struct ConvParams {
   int relu;
 };
 
-template <int MODE_, int CIN_, int COUT_, int TD_, int TH_, int TW_, int CK_>
+template <int MODE_, int CIN_, int COUT_, int TD_, int TH_, int TW_, int CK_, int OCC_ = 2>
 struct ConvCfg {
+  static constexpr int OCC = OCC_;   // min waves per SIMD (register budget 512 / OCC)
   static constexpr int MODE = MODE_, CIN = CIN_, COUT = COUT_, TD = TD_, TH = TH_, TW = TW_, CK = CK_;
   static constexpr int MB = (COUT + 15) / 16;
   static constexpr int ID = MODE == kConvS1 ? TD + 2 : MODE == kConvS2 ? 2 * TD + 1 : TD / 2 + 1;
@@ -66,6 +67,13 @@ struct ConvCfg {
   static constexpr int NCHUNK = CIN / CK;
   static constexpr int C4 = CK / 4;
   static constexpr int LDS_BYTES = CK * S * 4;
+  // staging geometry
+  static constexpr int IWP = IW <= 8 ? 8 : IW <= 16 ? 16 : IW <= 32 ? 32 : 64;
+  static constexpr int RPW = 64 / IWP;                     // rows per wave per iteration
+  static constexpr int ROWS = CK * ID * IH;
+  static constexpr int NIT = (ROWS + 4 * RPW - 1) / (4 * RPW);
+  static constexpr int SU = NIT < 10 ? NIT : 10;           // rows in flight per lane
+  static_assert(IW <= 64, "tile row wider than a wave");
   static_assert(CIN % CK == 0 && CK % 4 == 0, "channel chunking");
   static_assert(MODE != kDeconvS2 || (TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0), "even tile");
   static_assert(MODE != kDeconvS2 || NBW == 2 * NBC, "two parity classes per wave");
@@ -73,7 +81,7 @@ struct ConvCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) {
   constexpr int MODE = C::MODE;
   __shared__ float xs[C::CK * C::S];
 
@@ -114,26 +122,47 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvParams p) {
   const float* inb = p.in + (size_t)n * C::CIN * in_plane;
   const float* wl = p.wp + lane;
 
+#pragma unroll 1
   for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
     __syncthreads();
-    for (int idx = tid; idx < C::CK * C::PLANE; idx += 256) {
-      const int ck = idx / C::PLANE, rem = idx % C::PLANE;
-      const int zz = rem / (C::IH * C::IW), yy = (rem / C::IW) % C::IH, xx = rem % C::IW;
-      const int gz = iz0 + zz, gy = iy0 + yy, gx = ix0 + xx;
-      float v = 0.f;
-      if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
-        v = inb[(size_t)(chunk * C::CK + ck) * in_plane + ((size_t)gz * p.Hi + gy) * p.Wi + gx];
-      xs[ck * C::S + rem] = v;
+    // Row-based staging: a group of IWP lanes (IWP = IW rounded up to a power of two) copies one
+    // (channel, z, y) row of the halo'd tile; U independent rows are in flight per lane before the
+    // LDS writes, so global latency is paid once per batch rather than once per element.
+    {
+      const float* inc = inb + (size_t)chunk * C::CK * in_plane;
+      const int lrow = lane / C::IWP, lx = lane % C::IWP;
+      const int gx = ix0 + lx;
+      const bool xok = lx < C::IW;
+      const bool xin = xok && gx >= 0 && gx < p.Wi;
+#pragma unroll 1
+      for (int it0 = 0; it0 < C::NIT; it0 += C::SU) {
+        float v[C::SU];
+        int dst[C::SU];
+#pragma unroll
+        for (int u = 0; u < C::SU; ++u) {
+          const int row = ((it0 + u) * 4 + wave) * C::RPW + lrow;
+          const int ck = row / (C::ID * C::IH), rz = (row / C::IH) % C::ID, ry = row % C::IH;
+          const int gz = iz0 + rz, gy = iy0 + ry;
+          const bool rok = (it0 + u) < C::NIT && row < C::ROWS;
+          v[u] = 0.f;
+          if (rok && xin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi)
+            v[u] = inc[ck * (int)in_plane + (gz * p.Hi + gy) * p.Wi + gx];
+          dst[u] = (rok && xok) ? ck * C::S + (rz * C::IH + ry) * C::IW + lx : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < C::SU; ++u)
+          if (dst[u] >= 0) xs[dst[u]] = v[u];
+      }
     }
     __syncthreads();
 
     if constexpr (MODE != kDeconvS2) {
 #pragma unroll 1
-      for (int kz = 0; kz < 3; ++kz) {
+      for (int kzy = 0; kzy < 9; ++kzy) {
+        const int kz = kzy / 3, ky = kzy % 3;
 #pragma unroll
-        for (int kyx = 0; kyx < 9; ++kyx) {
-          const int ky = kyx / 3, kx = kyx % 3;
-          const int tap = kz * 9 + kyx;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = kzy * 3 + kx;
           const int tapoff = (kz * C::IH + ky) * C::IW + kx;
 #pragma unroll
           for (int c4 = 0; c4 < C::C4; ++c4) {
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
 
 // ---- layer table ---------------------------------------------------------------------------------
 //                       mode      Cin Cout  TD TH  TW  CK
-typedef ConvCfg<kConvS1, 32, 8, 4, 8, 56, 4> L0;
+typedef ConvCfg<kConvS1, 32, 8, 4, 8, 28, 4, 3> L0;
 typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
 typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
 typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
@@ -311,6 +340,8 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
   p.relu = 1;
   const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv3d: bad grid");
+  V3D_REQUIRE((long long)C::CK * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE,
+              "conv3d: input volume too large for 32-bit tile offsets");
   {
     v3d::TimedScope ts(name, s);
     conv3d_mfma_kernel<C><<<(unsigned)blocks, 256, 0, s>>>(p);

@@ -29,9 +29,11 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3  # dense fp32 MFMA == fp32 vector peak
 
-COSTREG_LAYERS = [  # (Cin, Cout, output-volume divisor) per conv0..conv9 (mvsnet.py:136-150)
+# (Cin, Cout, divisor of D*h*w giving the voxel count the 27*Cin*Cout MACs are spent on): output voxels
+# for the convs, INPUT voxels for the stride-2 transposed convs (SURVEY.md §8a row A5 MAC table)
+COSTREG_LAYERS = [
     (32, 8, 1), (8, 16, 8), (16, 16, 8), (16, 32, 64), (32, 32, 64), (32, 64, 512), (64, 64, 512),
-    (64, 32, 64), (32, 16, 8), (16, 8, 1)]
+    (64, 32, 512), (32, 16, 64), (16, 8, 8)]
 
 
 def kernel_roofline(name, avg_ms, shape):

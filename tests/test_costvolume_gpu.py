@@ -2,7 +2,10 @@
 captured from the reference and against the oracle on the same seeded inputs.
 
 Tolerances (fp32 path, BASELINE.json north_star: depth within 1e-4 relative):
-  variance volume  : 2e-5 absolute (values are O(0.1); bilinear weights/coordinates are fp32)
+  variance volume  : 5e-5 absolute.  Values are O(0.1) on U[0,1) features whose gradient is O(1)
+                     per feature pixel; sample coordinates reach ~160 px where one fp32 ulp is
+                     1.5e-5 px, so two correct fp32 evaluation orders of the projection differ by
+                     a few 1e-5 (observed max 2.4e-5 on 4M voxels)
   regularised vol. : 2e-4 * max|x_reg|
   depth            : 1e-4 relative
 """
@@ -16,7 +19,7 @@ from oracle import costvolume as ocv
 
 pytestmark = pytest.mark.gpu
 
-VAR_ATOL = 2e-5
+VAR_ATOL = 5e-5
 DEPTH_RTOL = 1e-4
 
 
