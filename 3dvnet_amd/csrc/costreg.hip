@@ -32,7 +32,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { kConvS1 = 0, kConvS2 = 1, kDeconvS2 = 2 };
+// kConvS1 / kConvS2: k3 p1 conv with stride 1 / 2.  kDeconvS2: k3 s2 p1 output_padding-1 transposed
+// conv.  kConvS1Pair: stride-1 conv for COUT == 8 -- the 16 MFMA rows hold 2 x-shifts x 8 output
+// channels over a 4-wide x window (36 "virtual taps", the weight image is zero where the shifted
+// kernel does not reach), each voxel block is 16 x-PAIRS: 18 MFMAs per 16 output voxels instead of
+// the 27 a half-empty 16-row tile would cost.
+enum { kConvS1 = 0, kConvS2 = 1, kDeconvS2 = 2, kConvS1Pair = 3 };
 
 struct ConvParams {
   const float* in;
@@ -48,19 +53,24 @@ template <int MODE_, int CIN_, int COUT_, int TD_, int TH_, int TW_, int CK_, in
 struct ConvCfg {
   static constexpr int OCC = OCC_;   // min waves per SIMD (register budget 512 / OCC)
   static constexpr int MODE = MODE_, CIN = CIN_, COUT = COUT_, TD = TD_, TH = TH_, TW = TW_, CK = CK_;
-  static constexpr int MB = (COUT + 15) / 16;
-  static constexpr int ID = MODE == kConvS1 ? TD + 2 : MODE == kConvS2 ? 2 * TD + 1 : TD / 2 + 1;
-  static constexpr int IH = MODE == kConvS1 ? TH + 2 : MODE == kConvS2 ? 2 * TH + 1 : TH / 2 + 1;
-  static constexpr int IW = MODE == kConvS1 ? TW + 2 : MODE == kConvS2 ? 2 * TW + 1 : TW / 2 + 1;
+  static constexpr bool S1LIKE = MODE == kConvS1 || MODE == kConvS1Pair;
+  static constexpr int MB = MODE == kConvS1Pair ? 1 : (COUT + 15) / 16;
+  static constexpr int ID = S1LIKE ? TD + 2 : MODE == kConvS2 ? 2 * TD + 1 : TD / 2 + 1;
+  static constexpr int IH = S1LIKE ? TH + 2 : MODE == kConvS2 ? 2 * TH + 1 : TH / 2 + 1;
+  static constexpr int IW = S1LIKE ? TW + 2 : MODE == kConvS2 ? 2 * TW + 1 : TW / 2 + 1;
   static constexpr int PLANE = ID * IH * IW;
-  // channel-plane stride in LDS: odd for the stride-2 read pattern, == 16 (mod 32) otherwise
-  static constexpr int S = MODE == kConvS2 ? (PLANE | 1) : ((PLANE - 16 + 31) / 32) * 32 + 16;
+  // channel-plane stride in LDS: odd where lanes read with x stride 2, == 16 (mod 32) otherwise
+  static constexpr int S = (MODE == kConvS2 || MODE == kConvS1Pair)
+                               ? (PLANE | 1) : ((PLANE - 16 + 31) / 32) * 32 + 16;
+  static constexpr int KXN = MODE == kConvS1Pair ? 4 : 3;   // x taps
+  static constexpr int NT = 9 * KXN;                        // (virtual) taps per input channel
   static constexpr int NVOX = TD * TH * TW;
   static constexpr int NCLS = MODE == kDeconvS2 ? 8 : 1;
-  static constexpr int NVC = NVOX / NCLS;
-  static constexpr int CD = MODE == kDeconvS2 ? TD / 2 : TD;   // lattice the N-blocks enumerate
+  // lattice the voxel blocks enumerate: parity sub-lattice (deconv), x pairs (pair mode)
+  static constexpr int CD = MODE == kDeconvS2 ? TD / 2 : TD;
   static constexpr int CH = MODE == kDeconvS2 ? TH / 2 : TH;
-  static constexpr int CW = MODE == kDeconvS2 ? TW / 2 : TW;
+  static constexpr int CW = (MODE == kDeconvS2 || MODE == kConvS1Pair) ? TW / 2 : TW;
+  static constexpr int NVC = CD * CH * CW;
   static constexpr int NBC = (NVC + 15) / 16;
   static constexpr int NBT = NBC * NCLS;
   static constexpr int NBW = (NBT + 3) / 4;
@@ -77,6 +87,7 @@ struct ConvCfg {
   static_assert(CIN % CK == 0 && CK % 4 == 0, "channel chunking");
   static_assert(MODE != kDeconvS2 || (TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0), "even tile");
   static_assert(MODE != kDeconvS2 || NBW == 2 * NBC, "two parity classes per wave");
+  static_assert(MODE != kConvS1Pair || (COUT == 8 && TW % 2 == 0), "pair mode: 8 channels, even TW");
   static_assert(LDS_BYTES <= 64 * 1024, "LDS tile");
 };
 
@@ -96,9 +107,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   const int tz = b % p.ntz;
   const int n = b / p.ntz;
   const int oz0 = tz * C::TD, oy0 = ty * C::TH, ox0 = tx * C::TW;
-  const int iz0 = MODE == kConvS1 ? oz0 - 1 : MODE == kConvS2 ? 2 * oz0 - 1 : oz0 / 2;
-  const int iy0 = MODE == kConvS1 ? oy0 - 1 : MODE == kConvS2 ? 2 * oy0 - 1 : oy0 / 2;
-  const int ix0 = MODE == kConvS1 ? ox0 - 1 : MODE == kConvS2 ? 2 * ox0 - 1 : ox0 / 2;
+  const int iz0 = C::S1LIKE ? oz0 - 1 : MODE == kConvS2 ? 2 * oz0 - 1 : oz0 / 2;
+  const int iy0 = C::S1LIKE ? oy0 - 1 : MODE == kConvS2 ? 2 * oy0 - 1 : oy0 / 2;
+  const int ix0 = C::S1LIKE ? ox0 - 1 : MODE == kConvS2 ? 2 * ox0 - 1 : ox0 / 2;
 
   // per-lane LDS base offset of each of this wave's voxel blocks
   int boff[C::NBW];
@@ -108,7 +119,8 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
     int v = min(i * 16 + jn, C::NVC - 1);
     int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
     int off = MODE == kConvS2 ? ((2 * z) * C::IH + 2 * y) * C::IW + 2 * x
-                              : (z * C::IH + y) * C::IW + x;
+            : MODE == kConvS1Pair ? (z * C::IH + y) * C::IW + 2 * x
+                                  : (z * C::IH + y) * C::IW + x;
     boff[j] = off + kq * C::S;
   }
 
@@ -122,11 +134,23 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   const float* inb = p.in + (size_t)n * C::CIN * in_plane;
   const float* wl = p.wp + lane;
 
+  // A fragments (weights) are software-pipelined one tap ahead: fragment index f = chunk*NT + tap
+  // walks the packed image linearly, so "next tap" also crosses chunk boundaries.
+  constexpr int kLastFrag = C::NCHUNK * C::NT - 1;
+  float a_cur[C::C4][C::MB], a_nxt[C::C4][C::MB];
+  auto load_a = [&](float (&a)[C::C4][C::MB], int f) {
+#pragma unroll
+    for (int c4 = 0; c4 < C::C4; ++c4)
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) a[c4][m] = wl[((size_t)(f * C::C4 + c4) * C::MB + m) * 64];
+  };
+  if constexpr (MODE != kDeconvS2) load_a(a_cur, 0);
+
 #pragma unroll 1
   for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
     __syncthreads();
     // Row-based staging: a group of IWP lanes (IWP = IW rounded up to a power of two) copies one
-    // (channel, z, y) row of the halo'd tile; U independent rows are in flight per lane before the
+    // (channel, z, y) row of the halo'd tile; SU independent rows are in flight per lane before the
     // LDS writes, so global latency is paid once per batch rather than once per element.
     {
       const float* inc = inb + (size_t)chunk * C::CK * in_plane;
@@ -161,23 +185,24 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
       for (int kzy = 0; kzy < 9; ++kzy) {
         const int kz = kzy / 3, ky = kzy % 3;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tap = kzy * 3 + kx;
+        for (int kx = 0; kx < C::KXN; ++kx) {
+          const int tap = kzy * C::KXN + kx;
           const int tapoff = (kz * C::IH + ky) * C::IW + kx;
+          load_a(a_nxt, min(chunk * C::NT + tap + 1, kLastFrag));
 #pragma unroll
           for (int c4 = 0; c4 < C::C4; ++c4) {
-            float a[C::MB];
-#pragma unroll
-            for (int m = 0; m < C::MB; ++m)
-              a[m] = wl[(size_t)((((chunk * 27 + tap) * C::C4 + c4) * C::MB + m)) * 64];
 #pragma unroll
             for (int j = 0; j < C::NBW; ++j) {
               const float bv = xs[boff[j] + tapoff + c4 * 4 * C::S];
 #pragma unroll
               for (int m = 0; m < C::MB; ++m)
-                acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[j][m], 0, 0, 0);
+                acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c4][m], bv, acc[j][m], 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int c4 = 0; c4 < C::C4; ++c4)
+#pragma unroll
+            for (int m = 0; m < C::MB; ++m) a_cur[c4][m] = a_nxt[c4][m];
         }
       }
     } else {
@@ -194,19 +219,16 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
           if ((px == 0) != (kx == 1)) continue;
           const int dz = kz == 0 ? 1 : 0, dy = ky == 0 ? 1 : 0, dx = kx == 0 ? 1 : 0;
           const int tapoff = (dz * C::IH + dy) * C::IW + dx;
+          load_a(a_cur, chunk * 27 + tap);
 #pragma unroll
           for (int c4 = 0; c4 < C::C4; ++c4) {
-            float a[C::MB];
-#pragma unroll
-            for (int m = 0; m < C::MB; ++m)
-              a[m] = wl[(size_t)((((chunk * 27 + tap) * C::C4 + c4) * C::MB + m)) * 64];
 #pragma unroll
             for (int i = 0; i < C::NBC; ++i) {
               const float bv = xs[boff[cl * C::NBC + i] + tapoff + c4 * 4 * C::S];
 #pragma unroll
               for (int m = 0; m < C::MB; ++m)
-                acc[cl * C::NBC + i][m] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[cl * C::NBC + i][m], 0, 0, 0);
+                acc[cl * C::NBC + i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    a_cur[c4][m], bv, acc[cl * C::NBC + i][m], 0, 0, 0);
             }
           }
         }
@@ -216,34 +238,82 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
 
   // ---- epilogue: bias, ReLU, skip, store ([n, COUT, Do, Ho, Wo]) -------------------------------
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+  if constexpr (MODE == kDeconvS2) {
+    // This wave owns output parities (pz, py) = (wave >> 1, wave & 1) and BOTH x parities
+    // (accumulator halves cl = 0 / 1), so lane jn holds x = 2 xc and 2 xc + 1: one float2 store per
+    // (channel, voxel pair) -> 16 lanes write 128 contiguous bytes.
+    const int pz = (wave >> 1) & 1, py = wave & 1;
 #pragma unroll
-  for (int j = 0; j < C::NBW; ++j) {
-    int i, pz = 0, py = 0, px = 0;
-    if constexpr (MODE == kDeconvS2) {
-      const int cls = wave * 2 + j / C::NBC;
-      pz = (cls >> 2) & 1; py = (cls >> 1) & 1; px = cls & 1;
-      i = j % C::NBC;
-    } else {
-      i = wave * C::NBW + j;
+    for (int i = 0; i < C::NBC; ++i) {
+      const int v = i * 16 + jn;
+      if (v >= C::NVC) continue;
+      const int z = 2 * (v / (C::CH * C::CW)) + pz, y = 2 * ((v / C::CW) % C::CH) + py;
+      const int x = 2 * (v % C::CW);
+      const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;      // Wo is even: gx + 1 < Wo too
+      const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = m * 16 + kq * 4 + r;
+          if (co < C::COUT) {
+            const float bsv = p.bias[co];
+            float2 val = make_float2(acc[i][m][r] + bsv, acc[C::NBC + i][m][r] + bsv);
+            if (p.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); }
+            const size_t o = ((size_t)n * C::COUT + co) * out_plane + sp;
+            if (p.skip) {
+              const float2 sk = *reinterpret_cast<const float2*>(p.skip + o);
+              val.x += sk.x; val.y += sk.y;
+            }
+            *reinterpret_cast<float2*>(p.out + o) = val;
+          }
+        }
+      }
     }
-    const int v = i * 16 + jn;
-    if (v >= C::NVC) continue;
-    int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
-    if constexpr (MODE == kDeconvS2) { z = 2 * z + pz; y = 2 * y + py; x = 2 * x + px; }
-    const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
-    if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
-    const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+  } else if constexpr (MODE == kConvS1Pair) {
+    // rows 0-7: x shift 0, rows 8-15: x shift 1 -> lane quarter kq holds channels 4*(kq&1)+r at
+    // x = 2*pair + (kq >> 1); quarters kq and kq+2 interleave into full 128-B runs per channel.
+    const int sx = kq >> 1, cbase = 4 * (kq & 1);
 #pragma unroll
-    for (int m = 0; m < C::MB; ++m) {
+    for (int j = 0; j < C::NBW; ++j) {
+      const int v = (wave * C::NBW + j) * 16 + jn;
+      if (v >= C::NVC) continue;
+      const int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = 2 * (v % C::CW) + sx;
+      const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+      const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = m * 16 + kq * 4 + r;
-        if (co < C::COUT) {
-          float val = acc[j][m][r] + p.bias[co];
-          if (p.relu) val = fmaxf(val, 0.f);
-          const size_t o = ((size_t)n * C::COUT + co) * out_plane + sp;
-          if (p.skip) val += p.skip[o];
-          p.out[o] = val;
+        const int co = cbase + r;
+        float val = acc[j][0][r] + p.bias[co];
+        if (p.relu) val = fmaxf(val, 0.f);
+        const size_t o = ((size_t)n * C::COUT + co) * out_plane + sp;
+        if (p.skip) val += p.skip[o];
+        p.out[o] = val;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < C::NBW; ++j) {
+      const int v = (wave * C::NBW + j) * 16 + jn;
+      if (v >= C::NVC) continue;
+      const int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
+      const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+      const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = m * 16 + kq * 4 + r;
+          if (co < C::COUT) {
+            float val = acc[j][m][r] + p.bias[co];
+            if (p.relu) val = fmaxf(val, 0.f);
+            const size_t o = ((size_t)n * C::COUT + co) * out_plane + sp;
+            if (p.skip) val += p.skip[o];
+            p.out[o] = val;
+          }
         }
       }
     }
@@ -251,42 +321,100 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
 }
 
 // ---- prob conv (base -> 1 channel, bias, no BN/ReLU; mvsnet.py:152,162) ---------------------------
+// A 1-channel output would waste 15/16 of an MFMA, so this layer is register-blocked VALU work:
+// a workgroup owns a PT_D x PT_H x (PT_XG*PT_RX) output tile; CK input channels of the halo'd tile
+// are staged in LDS (row stride == 8 (mod 32) floats so the 8 x-groups x 4 rows of a half-wave hit 32
+// distinct banks); each thread produces PT_RX consecutive x outputs from a sliding 9-float window,
+// weights come in through the scalar cache (wave-uniform addresses).
+constexpr int PT_D = 4, PT_H = 8, PT_XG = 8, PT_RX = 7, PT_W = PT_XG * PT_RX;   // 4 x 8 x 56 tile
+constexpr int PT_CK = 2;
+constexpr int PT_ID = PT_D + 2, PT_IH = PT_H + 2, PT_IW = PT_W + 2, PT_RS = 72;
+constexpr int PT_PLANE = PT_ID * PT_IH * PT_RS;
+
 template <int CIN>
 __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ in,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out, int n, int D, int H,
-                                                        int W) {
-  __shared__ float sw[CIN * 27];
-  for (int i = threadIdx.x; i < CIN * 27; i += 256) sw[i] = w[i];
-  __syncthreads();
+                                                        int W, int ntz, int nty, int ntx) {
+  __shared__ float xs[PT_CK * PT_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int tx = b % ntx; b /= ntx;
+  const int ty = b % nty; b /= nty;
+  const int tz = b % ntz;
+  const int bn = b / ntz;
+  const int oz0 = tz * PT_D, oy0 = ty * PT_H, ox0 = tx * PT_W;
   const size_t plane = (size_t)D * H * W;
-  const size_t total = (size_t)n * plane;
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int x = gid % W, y = (gid / W) % H, z = (gid / ((size_t)W * H)) % D;
-  const int b = gid / plane;
-  const float* inb = in + (size_t)b * CIN * plane;
-  float acc = 0.f;
-  for (int ci = 0; ci < CIN; ++ci) {
+  const float* inb = in + (size_t)bn * CIN * plane;
+
+  // compute role: one z per wave, lane = y * 8 + xg
+  const int cz = wave, cy = lane >> 3, cxg = lane & 7;
+  const int cbase = (cz * PT_IH + cy) * PT_RS + cxg * PT_RX;
+  float acc[PT_RX];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      const int gz = z + kz - 1;
-      if (gz < 0 || gz >= D) continue;
+  for (int i = 0; i < PT_RX; ++i) acc[i] = 0.f;
+
+  constexpr int ROWS = PT_CK * PT_ID * PT_IH;          // one 64-lane group per row
+  constexpr int NIT = (ROWS + 3) / 4;
+  constexpr int SU = 10;
+#pragma unroll 1
+  for (int c0 = 0; c0 < CIN; c0 += PT_CK) {
+    __syncthreads();
+    {
+      const int gx = ox0 - 1 + lane;
+      const bool xok = lane < PT_IW;
+      const bool xin = xok && gx >= 0 && gx < W;
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += SU) {
+        float v[SU];
+        int dst[SU];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int gy = y + ky - 1;
-        if (gy < 0 || gy >= H) continue;
-        const float* row = inb + (size_t)ci * plane + ((size_t)gz * H + gy) * W;
+        for (int u = 0; u < SU; ++u) {
+          const int row = (it0 + u) * 4 + wave;
+          const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
+          const int gz = oz0 - 1 + rz, gy = oy0 - 1 + ry;
+          const bool rok = (it0 + u) < NIT && row < ROWS;
+          v[u] = 0.f;
+          if (rok && xin && gz >= 0 && gz < D && gy >= 0 && gy < H)
+            v[u] = inb[(size_t)(c0 + ck) * plane + ((size_t)gz * H + gy) * W + gx];
+          dst[u] = (rok && xok) ? ck * PT_PLANE + (rz * PT_IH + ry) * PT_RS + lane : -1;
+        }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int gx = x + kx - 1;
-          if (gx >= 0 && gx < W) acc += row[gx] * sw[ci * 27 + (kz * 3 + ky) * 3 + kx];
+        for (int u = 0; u < SU; ++u)
+          if (dst[u] >= 0) xs[dst[u]] = v[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ck = 0; ck < PT_CK; ++ck) {
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = xs + ck * PT_PLANE + cbase + (kz * PT_IH + ky) * PT_RS;
+          float win[PT_RX + 2];
+#pragma unroll
+          for (int i = 0; i < PT_RX + 2; ++i) win[i] = row[i];
+          const float* wk = w + (c0 + ck) * 27 + (kz * 3 + ky) * 3;   // wave-uniform -> s_load
+          const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+#pragma unroll
+          for (int i = 0; i < PT_RX; ++i) acc[i] += win[i] * w0 + win[i + 1] * w1 + win[i + 2] * w2;
         }
       }
     }
   }
-  out[gid] = acc + bias[0];
+  const int gz = oz0 + cz, gy = oy0 + cy;
+  if (gz < D && gy < H) {
+    const float bsv = bias[0];
+    float* o = out + (size_t)bn * plane + ((size_t)gz * H + gy) * W;
+#pragma unroll
+    for (int i = 0; i < PT_RX; ++i) {
+      const int gx = ox0 + cxg * PT_RX + i;
+      if (gx < W) o[gx] = acc[i] + bsv;
+    }
+  }
 }
 
 // ---- soft-argmin over D (mvsnet.py:219-227): p = softmax(-x), depth = sum_d vals[d] p[d] ----------
@@ -309,7 +437,7 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
 
 // ---- layer table ---------------------------------------------------------------------------------
 //                       mode      Cin Cout  TD TH  TW  CK
-typedef ConvCfg<kConvS1, 32, 8, 4, 8, 28, 4, 3> L0;
+typedef ConvCfg<kConvS1Pair, 32, 8, 8, 8, 28, 4, 3> L0;
 typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
 typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
 typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
@@ -322,7 +450,7 @@ typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 56, 8> L9;
 
 struct LayerDesc { int mode, cin, cout, ck; };
 const LayerDesc kLayers[10] = {
-    {kConvS1, 32, 8, L0::CK},   {kConvS2, 8, 16, L1::CK},   {kConvS1, 16, 16, L2::CK},
+    {L0::MODE, 32, 8, L0::CK},   {kConvS2, 8, 16, L1::CK},   {kConvS1, 16, 16, L2::CK},
     {kConvS2, 16, 32, L3::CK},  {kConvS1, 32, 32, L4::CK},  {kConvS2, 32, 64, L5::CK},
     {kConvS1, 64, 64, L6::CK},  {kDeconvS2, 64, 32, L7::CK}, {kDeconvS2, 32, 16, L8::CK},
     {kDeconvS2, 16, 8, L9::CK}};
@@ -333,7 +461,7 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
   ConvParams p;
   p.in = in; p.wp = wp; p.bias = bias; p.skip = skip; p.out = out; p.n = n;
   p.Di = Di; p.Hi = Hi; p.Wi = Wi;
-  if (C::MODE == kConvS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
+  if (C::S1LIKE) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
   else if (C::MODE == kConvS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
   else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
   p.ntz = (p.Do + C::TD - 1) / C::TD; p.nty = (p.Ho + C::TH - 1) / C::TH; p.ntx = (p.Wo + C::TW - 1) / C::TW;
@@ -373,8 +501,10 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
   auto reserve = [&](size_t nfloat) { size_t o = host.size(); host.resize(o + (nfloat + 63) / 64 * 64, 0.f); return o; };
   for (int l = 0; l < 10; ++l) {
     const LayerDesc& L = kLayers[l];
-    const int MB = (L.cout + 15) / 16, C4 = L.ck / 4, nchunk = L.cin / L.ck;
-    h->wp_ofs[l] = reserve((size_t)nchunk * 27 * C4 * MB * 64);
+    const bool pair = L.mode == kConvS1Pair;
+    const int MB = pair ? 1 : (L.cout + 15) / 16, C4 = L.ck / 4, nchunk = L.cin / L.ck;
+    const int KXN = pair ? 4 : 3, NT = 9 * KXN;
+    h->wp_ofs[l] = reserve((size_t)nchunk * NT * C4 * MB * 64);
     h->bias_ofs[l] = reserve(L.cout);
     float* wp = host.data() + h->wp_ofs[l];
     float* bias = host.data() + h->bias_ofs[l];
@@ -385,20 +515,25 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
       bias[co] = bn_b[l][co] - bn_m[l][co] * scale[co];
     }
     for (int chunk = 0; chunk < nchunk; ++chunk)
-      for (int tap = 0; tap < 27; ++tap)
+      for (int tap = 0; tap < NT; ++tap)
         for (int c4 = 0; c4 < C4; ++c4)
           for (int m = 0; m < MB; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-              const int co = m * 16 + (lane & 15);
+              const int row = m * 16 + (lane & 15);
               const int ci = chunk * L.ck + c4 * 4 + (lane >> 4);
               float v = 0.f;
-              if (co < L.cout) {
+              if (pair) {
+                // row = x-shift * 8 + channel; virtual tap = (kz, ky, kx') with kx' in 0..3
+                const int sx = row >> 3, co = row & 7, kzy = tap / 4, kx = tap % 4 - sx;
+                if (kx >= 0 && kx <= 2)
+                  v = conv_w[l][((size_t)co * L.cin + ci) * 27 + kzy * 3 + kx] * scale[co];
+              } else if (row < L.cout) {
                 // Conv3d weight [Co, Ci, 3,3,3]; ConvTranspose3d weight [Ci, Co, 3,3,3]
-                const size_t idx = L.mode == kDeconvS2 ? ((size_t)ci * L.cout + co) * 27 + tap
-                                                       : ((size_t)co * L.cin + ci) * 27 + tap;
-                v = conv_w[l][idx] * scale[co];
+                const size_t idx = L.mode == kDeconvS2 ? ((size_t)ci * L.cout + row) * 27 + tap
+                                                       : ((size_t)row * L.cin + ci) * 27 + tap;
+                v = conv_w[l][idx] * scale[row];
               }
-              wp[((((size_t)chunk * 27 + tap) * C4 + c4) * MB + m) * 64 + lane] = v;
+              wp[((((size_t)chunk * NT + tap) * C4 + c4) * MB + m) * 64 + lane] = v;
             }
   }
   h->prob_w_ofs = reserve((size_t)base * 27);
@@ -495,11 +630,11 @@ extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* 
   RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
 #undef RUN
-  const size_t total = (size_t)n * D * H * W;
   {
     v3d::TimedScope ts("costreg_prob", s);
-    prob_conv_kernel<8><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
-        F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W);
+    const int ntz = (D + PT_D - 1) / PT_D, nty = (H + PT_H - 1) / PT_H, ntx = (W + PT_W - 1) / PT_W;
+    prob_conv_kernel<8><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(
+        F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
   }
   V3D_CHECK_LAUNCH("prob_conv_kernel");
   const size_t npix = (size_t)n * H * W;

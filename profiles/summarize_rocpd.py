@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's rocpd SQLite output into the small CSV summaries committed under profiles/.
+
+    python profiles/summarize_rocpd.py stats <results.db> <out.csv>          # --kernel-trace --stats
+    python profiles/summarize_rocpd.py pmc   <results.db> <out.csv>          # --pmc COUNTER pass
+"""
+import csv
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([\w:]+(?:<[^()]*>)?)', name)
+    return (m.group(1) if m else name)[:110]
+
+
+def main():
+    mode, db, out = sys.argv[1:4]
+    cur = sqlite3.connect(db).cursor()
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        if mode == 'stats':
+            w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'percent'])
+            for name, calls, total, avg, pct in cur.execute(
+                    'select name, total_calls, total_duration, average, percentage from top_kernels'):
+                w.writerow([short(name), calls, '%.1f' % (total), '%.2f' % (avg), '%.2f' % pct])
+        else:
+            w.writerow(['kernel', 'counter', 'dispatches', 'avg_value_per_dispatch'])
+            for name, ctr, n, avg in cur.execute(
+                    'select kernel_name, counter_name, count(*), avg(value) from counters_collection '
+                    'group by kernel_name, counter_name order by avg(value) desc'):
+                if avg and avg > 1000:
+                    w.writerow([short(name), ctr, n, '%.1f' % avg])
+
+
+if __name__ == '__main__':
+    main()
