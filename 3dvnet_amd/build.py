@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib3dvnet_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+         '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + os.environ.get('V3D_EXTRA_FLAGS', '').split()
 
 
 def sources():

@@ -28,6 +28,10 @@
 
 #include "v3d_common.h"
 
+#ifndef V3D_ABLATE
+#define V3D_ABLATE 0   // developer ablations of the conv kernel (1: no MFMA loop, 2: no restaging)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -83,18 +87,31 @@ struct ConvCfg {
   static constexpr int ROWS = CK * ID * IH;
   static constexpr int NIT = (ROWS + 4 * RPW - 1) / (4 * RPW);
   static constexpr int SU = NIT < 10 ? NIT : 10;           // rows in flight per lane
+  // Prefetch mode: the next channel chunk's tile rows AND its weight fragments are loaded into
+  // registers right after the barrier and stay in flight during the whole MFMA loop; A fragments are
+  // then served from LDS (lgkmcnt) so that no vmcnt wait inside the loop drains the prefetch.
+  static constexpr int WCH = NT * C4 * MB * 64;            // packed weight floats per chunk
+  static constexpr int NWIT = (WCH + 255) / 256;
+  static constexpr bool PF = WCH <= 8192 && (NIT + NWIT) <= 64 && (NIT + NWIT + 4 * NBW * MB) <= 150;
+  static constexpr int TROWS = NIT * 4 * RPW;              // staging row-table entries (>= ROWS)
+  static constexpr int LDS_FLOATS = CK * S + (PF ? WCH : 0) + 2 * TROWS;
   static_assert(IW <= 64, "tile row wider than a wave");
   static_assert(CIN % CK == 0 && CK % 4 == 0, "channel chunking");
   static_assert(MODE != kDeconvS2 || (TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0), "even tile");
   static_assert(MODE != kDeconvS2 || NBW == 2 * NBC, "two parity classes per wave");
   static_assert(MODE != kConvS1Pair || (COUT == 8 && TW % 2 == 0), "pair mode: 8 channels, even TW");
-  static_assert(LDS_BYTES <= 64 * 1024, "LDS tile");
+  static_assert(LDS_FLOATS * 4 <= 64 * 1024, "LDS tile");
 };
 
 template <class C>
 __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) {
   constexpr int MODE = C::MODE;
-  __shared__ float xs[C::CK * C::S];
+  __shared__ float xs[C::LDS_FLOATS];
+  float* const ws = xs + C::CK * C::S;   // weight fragments of the current chunk (PF mode)
+  // per-row staging tables, built once: global element offset of the row start (kRowOob if the
+  // row lies outside the volume in z/y) and LDS element offset of the row (-1 = no such row)
+  int* const rowg = reinterpret_cast<int*>(xs + C::CK * C::S + (C::PF ? C::WCH : 0));
+  int* const rowd = rowg + C::TROWS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -144,42 +161,90 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
       for (int m = 0; m < C::MB; ++m) a[c4][m] = wl[((size_t)(f * C::C4 + c4) * C::MB + m) * 64];
   };
-  if constexpr (MODE != kDeconvS2) load_a(a_cur, 0);
+  if constexpr (MODE != kDeconvS2 && !C::PF) load_a(a_cur, 0);
+
+  // staging lane role: a group of IWP lanes (IWP = IW rounded up to a power of two) copies one
+  // (channel, z, y) row of the halo'd tile
+  const int lrow = lane / C::IWP, lx = lane % C::IWP;
+  const int sgx = ix0 + lx;
+  const bool xok = lx < C::IW;
+  const bool xin = xok && sgx >= 0 && sgx < p.Wi;
+  constexpr int kRowOob = -2147483647 - 1;
+  for (int r = tid; r < C::TROWS; r += 256) {
+    const int ck = r / (C::ID * C::IH), rz = (r / C::IH) % C::ID, ry = r % C::IH;
+    const int gz = iz0 + rz, gy = iy0 + ry;
+    const bool in_vol = gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+    rowg[r] = (r < C::ROWS && in_vol) ? ck * (int)in_plane + (gz * p.Hi + gy) * p.Wi + ix0 : kRowOob;
+    rowd[r] = r < C::ROWS ? ck * C::S + (rz * C::IH + ry) * C::IW : -1;
+  }
+  __syncthreads();
+  const int myrow0 = wave * C::RPW + lrow;        // this lane's rows: myrow0 + it * 4 * RPW
+
+  float pre[C::PF ? C::NIT : 1], wreg[C::PF ? C::NWIT : 1];
+  auto pf_issue = [&](int chunk) {
+    const float* inc = inb + (size_t)chunk * C::CK * in_plane + lx;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int g = rowg[myrow0 + it * 4 * C::RPW];
+      pre[it] = (g != kRowOob && xin) ? inc[g] : 0.f;
+    }
+    const float* wc = p.wp + (size_t)chunk * C::WCH + tid;
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i) wreg[i] = (i * 256 + tid < C::WCH) ? wc[i * 256] : 0.f;
+  };
+  auto pf_commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int d = rowd[myrow0 + it * 4 * C::RPW];
+      if (d >= 0 && xok) xs[d + lx] = pre[it];
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i)
+      if (i * 256 + tid < C::WCH) ws[i * 256 + tid] = wreg[i];
+  };
+  if constexpr (C::PF) pf_issue(0);
 
 #pragma unroll 1
   for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
     __syncthreads();
-    // Row-based staging: a group of IWP lanes (IWP = IW rounded up to a power of two) copies one
-    // (channel, z, y) row of the halo'd tile; SU independent rows are in flight per lane before the
-    // LDS writes, so global latency is paid once per batch rather than once per element.
-    {
-      const float* inc = inb + (size_t)chunk * C::CK * in_plane;
-      const int lrow = lane / C::IWP, lx = lane % C::IWP;
-      const int gx = ix0 + lx;
-      const bool xok = lx < C::IW;
-      const bool xin = xok && gx >= 0 && gx < p.Wi;
+    if constexpr (C::PF) {
+#if V3D_ABLATE == 2
+      if (chunk == 0) pf_commit();
+      __syncthreads();
+#else
+      pf_commit();
+      __syncthreads();
+      if (chunk + 1 < C::NCHUNK) pf_issue(chunk + 1);
+#endif
+    } else {
+      // batched staging: SU independent rows are in flight per lane before the LDS writes, so
+      // global latency is paid once per batch rather than once per element
+      const float* inc = inb + (size_t)chunk * C::CK * in_plane + lx;
 #pragma unroll 1
       for (int it0 = 0; it0 < C::NIT; it0 += C::SU) {
         float v[C::SU];
-        int dst[C::SU];
 #pragma unroll
         for (int u = 0; u < C::SU; ++u) {
-          const int row = ((it0 + u) * 4 + wave) * C::RPW + lrow;
-          const int ck = row / (C::ID * C::IH), rz = (row / C::IH) % C::ID, ry = row % C::IH;
-          const int gz = iz0 + rz, gy = iy0 + ry;
-          const bool rok = (it0 + u) < C::NIT && row < C::ROWS;
           v[u] = 0.f;
-          if (rok && xin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi)
-            v[u] = inc[ck * (int)in_plane + (gz * p.Hi + gy) * p.Wi + gx];
-          dst[u] = (rok && xok) ? ck * C::S + (rz * C::IH + ry) * C::IW + lx : -1;
+          if (it0 + u < C::NIT) {
+            const int g = rowg[myrow0 + (it0 + u) * 4 * C::RPW];
+            if (g != kRowOob && xin) v[u] = inc[g];
+          }
         }
 #pragma unroll
-        for (int u = 0; u < C::SU; ++u)
-          if (dst[u] >= 0) xs[dst[u]] = v[u];
+        for (int u = 0; u < C::SU; ++u) {
+          if (it0 + u < C::NIT) {
+            const int d = rowd[myrow0 + (it0 + u) * 4 * C::RPW];
+            if (d >= 0 && xok) xs[d + lx] = v[u];
+          }
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
 
+#if V3D_ABLATE == 1
+    if (p.relu == 12345)
+#endif
     if constexpr (MODE != kDeconvS2) {
 #pragma unroll 1
       for (int kzy = 0; kzy < 9; ++kzy) {
@@ -188,7 +253,15 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
         for (int kx = 0; kx < C::KXN; ++kx) {
           const int tap = kzy * C::KXN + kx;
           const int tapoff = (kz * C::IH + ky) * C::IW + kx;
-          load_a(a_nxt, min(chunk * C::NT + tap + 1, kLastFrag));
+          if constexpr (C::PF) {
+#pragma unroll
+            for (int c4 = 0; c4 < C::C4; ++c4)
+#pragma unroll
+              for (int m = 0; m < C::MB; ++m)
+                a_cur[c4][m] = ws[((tap * C::C4 + c4) * C::MB + m) * 64 + lane];
+          } else {
+            load_a(a_nxt, min(chunk * C::NT + tap + 1, kLastFrag));
+          }
 #pragma unroll
           for (int c4 = 0; c4 < C::C4; ++c4) {
 #pragma unroll
@@ -199,10 +272,12 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
                 acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c4][m], bv, acc[j][m], 0, 0, 0);
             }
           }
+          if constexpr (!C::PF) {
 #pragma unroll
-          for (int c4 = 0; c4 < C::C4; ++c4)
+            for (int c4 = 0; c4 < C::C4; ++c4)
 #pragma unroll
-            for (int m = 0; m < C::MB; ++m) a_cur[c4][m] = a_nxt[c4][m];
+              for (int m = 0; m < C::MB; ++m) a_cur[c4][m] = a_nxt[c4][m];
+          }
         }
       }
     } else {
@@ -219,7 +294,15 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
           if ((px == 0) != (kx == 1)) continue;
           const int dz = kz == 0 ? 1 : 0, dy = ky == 0 ? 1 : 0, dx = kx == 0 ? 1 : 0;
           const int tapoff = (dz * C::IH + dy) * C::IW + dx;
-          load_a(a_cur, chunk * 27 + tap);
+          if constexpr (C::PF) {
+#pragma unroll
+            for (int c4 = 0; c4 < C::C4; ++c4)
+#pragma unroll
+              for (int m = 0; m < C::MB; ++m)
+                a_cur[c4][m] = ws[((tap * C::C4 + c4) * C::MB + m) * 64 + lane];
+          } else {
+            load_a(a_cur, chunk * 27 + tap);
+          }
 #pragma unroll
           for (int c4 = 0; c4 < C::C4; ++c4) {
 #pragma unroll
@@ -437,7 +520,10 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
 
 // ---- layer table ---------------------------------------------------------------------------------
 //                       mode      Cin Cout  TD TH  TW  CK
-typedef ConvCfg<kConvS1Pair, 32, 8, 8, 8, 28, 4, 3> L0;
+#ifndef V3D_L0_CFG
+#define V3D_L0_CFG kConvS1Pair, 32, 8, 4, 8, 28, 4, 3
+#endif
+typedef ConvCfg<V3D_L0_CFG> L0;
 typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
 typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
 typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
@@ -446,7 +532,7 @@ typedef ConvCfg<kConvS2, 32, 64, 2, 7, 7, 8> L5;
 typedef ConvCfg<kConvS1, 64, 64, 4, 7, 7, 16> L6;
 typedef ConvCfg<kDeconvS2, 64, 32, 4, 14, 14, 16> L7;
 typedef ConvCfg<kDeconvS2, 32, 16, 4, 14, 28, 8> L8;
-typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 56, 8> L9;
+typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 28, 8, 3> L9;
 
 struct LayerDesc { int mode, cin, cout, ck; };
 const LayerDesc kLayers[10] = {
