@@ -107,7 +107,94 @@ def golden_costvolume():
          reg_sub=reg[:, ::5, ::7, ::7], depth=d)
 
 
+def tiny_scene(n_ref=4, seed=31, two_batches=False):
+    """Small sliding-window scene in the synthetic room with analytic wall depth + noise."""
+    img_size, feat_size, plane_size = (64, 80), (16, 20), (12, 14)
+    edges, n_img = syn.make_edges(n_ref, 1, 1)
+    rot, tv, K = syn.make_cameras(n_img, img_size, seed=seed)
+    feat = syn.make_features(n_img, 32, *feat_size, seed=seed)
+    depth = syn.ray_box_depth(rot[1:1 + n_ref], tv[1:1 + n_ref], K[1:1 + n_ref], img_size, plane_size)
+    g = torch.Generator().manual_seed(seed)
+    depth = depth + 0.02 * torch.randn(depth.shape, generator=g)
+    depth_batch = torch.zeros(n_ref, dtype=torch.long)
+    if two_batches:
+        depth_batch[n_ref // 2:] = 1
+    return dict(img_size=img_size, plane_size=plane_size, edges=edges, rotmats=rot, tvecs=tv, K=K,
+                feat=feat, depth=depth, depth_batch=depth_batch)
+
+
+def golden_scene():
+    from oracle import scene as osc
+    sc = tiny_scene(two_batches=True)
+    fake = NS(hparams=NS(img_size=sc['img_size'], feat_dim=32))
+    with torch.no_grad():
+        # ---- B1-B2 ------------------------------------------------------------------------------
+        pts, pts_feat, pts_batch = ref.lm.PL3DVNet.construct_feature_rich_pointcloud(
+            fake, sc['depth'], sc['depth_batch'], sc['feat'], sc['rotmats'], sc['tvecs'], sc['K'], sc['edges'])
+        save('B_pointcloud', **{k: sc[k] for k in ('img_size', 'edges', 'rotmats', 'tvecs', 'K', 'feat',
+                                                   'depth', 'depth_batch')},
+             pts=pts, pts_feat=pts_feat, pts_batch=pts_batch)
+        # ---- B3 ---------------------------------------------------------------------------------
+        a_pts, a_idx, a_batch, a_edges = ref.utils.voxelize(pts, pts_batch, 0.16)
+        save('B_voxelize', pts=pts, pts_batch=pts_batch, edge_len=0.16, anchor_pts=a_pts,
+             anchor_idx3d=a_idx, anchor_batch=a_batch, anchor_pts_edges=a_edges)
+        # ---- B4 ---------------------------------------------------------------------------------
+        sd_pn = syn.pointnet_weights(seed=1)
+        pn = ref.scene.PointNet(128, 64, 35).eval()
+        pn.load_state_dict(sd_pn)
+        x_in = torch.cat((pts[a_edges[1]] - a_pts[a_edges[0]], pts_feat[a_edges[1]]), dim=1)
+        x_out = pn(x_in, a_edges[0], a_pts.shape[0])
+        save('B_pointnet', x_in=x_in, idx=a_edges[0], n_idx=a_pts.shape[0], weights_seed=1,
+             weights_checksum=checksum(sd_pn), out=x_out)
+        # ---- C1 + C3 (decoder replaced by a capture that returns a deterministic softmax) ---------
+        cap = {}
+
+        def fake_decoder(xs, pts_hyp, pts_feat_h, pts_batch_h):
+            cap.update(pts_hyp=pts_hyp.clone(), pts_feat=pts_feat_h.clone(), pts_batch=pts_batch_h.clone())
+            return torch.softmax(pts_feat_h.sum(-1) * 20.0, dim=1)
+
+        fake2 = NS(hparams=NS(img_size=sc['img_size'], feat_dim=32), decoder=fake_decoder)
+        off = ref.lm.PL3DVNet.run_pointflow(fake2, None, sc['depth'], sc['depth_batch'], sc['feat'],
+                                            sc['rotmats'], sc['tvecs'], sc['K'], sc['edges'], 0.05, 3)
+        save('C_pointflow', offset=0.05, n=3, pts_hyp=cap['pts_hyp'], pts_feat=cap['pts_feat'],
+             pts_batch=cap['pts_batch'], offset_pred=off)
+        # ---- C2b: the conv1d decoder stack ----------------------------------------------------------
+        sd_dec = syn.decoder_weights(in_dim=352, h_dim=128, seed=3, sharpen=50.0)
+        dec = ref.refine.HypothesisDecoder(352, 128, 3, 1).eval()
+        r = dec.load_state_dict(sd_dec, strict=False)
+        assert not r.unexpected_keys and all('num_batches' in k for k in r.missing_keys), r
+        g = torch.Generator().manual_seed(5)
+        feats = torch.randn((64, 7, 352), generator=g)
+        preds = torch.softmax(dec.net(feats.transpose(2, 1)).squeeze(1), dim=1)
+        save('C_decoder_net', features=feats, weights_seed=3, sharpen=50.0,
+             weights_checksum=checksum(sd_dec), preds=preds)
+        # ---- C2a pinned against the reference's own dense formulation forward_forloop ----------------
+        sd_pn2 = syn.pointnet_weights(seed=1)
+        sd_un = syn.sparse_unet_weights(seed=2)
+        xs = osc.sparse_unet(x_out, a_pts, a_idx, a_batch, 0.16, sd_un)     # level dicts (oracle B6)
+        sd_dec320 = syn.decoder_weights(in_dim=320, h_dim=128, seed=4, sharpen=50.0)
+        dec320 = ref.refine.HypothesisDecoder(320, 128, 3, 1).eval()
+        dec320.load_state_dict(sd_dec320, strict=False)
+        n_ref, P = sc['depth'].shape[0], sc['depth'].shape[1] * sc['depth'].shape[2]
+        pts_h = cap['pts_hyp'].view(n_ref, P, 7, 3)
+        xs_ref = [dict(feats=x['feats'].clone(), idx=x['idx'].clone(), pts=x['pts'].clone(), res=x['res'],
+                       stride=x['stride'], batch=x['batch'].clone()) for x in xs]
+        preds_loop = dec320.forward_forloop(xs_ref, pts_h.clone(), sc['depth_batch'])
+        save('C_forloop', x_pointnet=x_out, anchor_pts=a_pts, anchor_idx3d=a_idx, anchor_batch=a_batch,
+             edge_len=0.16, unet_seed=2, unet_checksum=checksum(sd_un), dec_seed=4, sharpen=50.0,
+             dec_checksum=checksum(sd_dec320), pts_hyp=cap['pts_hyp'], pts_batch=cap['pts_batch'],
+             depth_batch=sc['depth_batch'], preds=preds_loop.reshape(n_ref * P, 7))
+        # ---- H1, H4 -----------------------------------------------------------------------------------
+        e = torch.tensor([[2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5], [1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6]])
+        gt = sc['depth'] + 0.1
+        gt[0, :2] = 0.2
+        save('H_misc', edges=e, sliced=ref.utils.slice_edges(e.clone(), 3, 5, 0), depth_pred=sc['depth'],
+             depth_gt=gt, abs_rel=ref.metrics.calc_2d_depth_metrics(sc['depth'], gt)['abs_rel'])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['A']
+    which = sys.argv[1:] or ['A', 'B']
     if 'A' in which:
         golden_costvolume()
+    if 'B' in which:
+        golden_scene()
