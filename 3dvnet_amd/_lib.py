@@ -38,6 +38,24 @@ SIGNATURES = {
                                                                     c_size_t, c_void_p]),
     'v3d_costreg_layer_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
                               [c_void_p, c_void_p]),
+    'v3d_backproject_workspace_bytes': (c_size_t, [c_int] * 4),
+    'v3d_backproject_variance_f32': (c_int, [c_void_p] * 8 + [c_int] * 10 + [c_double, c_int] +
+                                     [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_gemm_pack': (c_int, [c_float_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
+                              c_int, c_int, c_int, c_float_p, c_float_p, c_float_p, c_float_p,
+                              ctypes.POINTER(c_void_p)]),
+    'v3d_gemm_free': (None, [c_void_p]),
+    'v3d_gemm_gather_f32': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                    ctypes.POINTER(c_int), c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'v3d_fill_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
+    'v3d_hash_bytes': (c_size_t, [c_int]),
+    'v3d_hash_build': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'v3d_sparse_neighbors': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'v3d_sparse_interp_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                      c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
 }
 
 

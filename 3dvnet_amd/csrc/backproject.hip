@@ -1,0 +1,169 @@
+// Rows B1-B2 and C1 of SURVEY.md §8a: back-project depth pixels (or 2n+1 depth hypotheses per pixel) to
+// world points, re-project them into every source view of the reference, bilinearly sample the
+// quarter-resolution features and reduce to the cross-view variance.  Reference semantics:
+// mv3d/lightningmodel.py:132-174 (construct_feature_rich_pointcloud) and :187-235 (run_pointflow),
+// mv3d/utils.py:67-83 (build_img_pts).
+//
+// One kernel, n_hyp = 1 (scene point cloud) or 2n+1 (point-flow hypotheses).  8 (C=32) lanes per
+// sample, each owning 4 channels of the channel-last feature tensor; sums over edges in edge order.
+// The problem is small (3 136 x n_hyp samples per view): latency-bound, so views are batched per launch.
+#include "v3d_common.h"
+
+namespace {
+
+constexpr int kMaxE = 8;
+
+struct BpParams {
+  const float* depth;    // [n_ref, h*w]
+  const float* featT;    // [n_img, Hf, Wf, C]
+  const float* K; const float* R; const float* t;
+  const int* ref_img; const int* edge_ofs; const int* edge_src;
+  float* pts;            // [n_ref*P, n_hyp, 3]
+  float* var;            // [n_ref*P, n_hyp, C]
+  int n_ref, Hf, Wf, H, W, h, w, n_hyp, n_half;
+  double x_step, y_step, offset;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
+  constexpr int LP = C / 4;
+  __shared__ float s_ref[24];
+  __shared__ float s_P[kMaxE][12];
+  __shared__ int s_base[kMaxE];
+  const int tid = threadIdx.x;
+  const int r = blockIdx.y;
+  const int P = p.h * p.w;
+  const int ref = p.ref_img[r];
+  const int e_begin = p.edge_ofs[r], ne = p.edge_ofs[r + 1] - e_begin;
+
+  if (tid == 0) {   // K^-1 (fp64 adjugate, rounded to f32; lightningmodel.py:138,191)
+    const float* Kp = p.K + ref * 9;
+    double a = Kp[0], bb = Kp[1], c = Kp[2], d = Kp[3], e = Kp[4], f = Kp[5], g = Kp[6], hh = Kp[7], i = Kp[8];
+    double det = a * (e * i - f * hh) - bb * (d * i - f * g) + c * (d * hh - e * g), id = 1.0 / det;
+    s_ref[0] = (float)((e * i - f * hh) * id); s_ref[1] = (float)((c * hh - bb * i) * id); s_ref[2] = (float)((bb * f - c * e) * id);
+    s_ref[3] = (float)((f * g - d * i) * id);  s_ref[4] = (float)((a * i - c * g) * id);   s_ref[5] = (float)((c * d - a * f) * id);
+    s_ref[6] = (float)((d * hh - e * g) * id); s_ref[7] = (float)((bb * g - a * hh) * id); s_ref[8] = (float)((a * e - bb * d) * id);
+  }
+  if (tid >= 64 && tid < 73) s_ref[9 + tid - 64] = p.R[ref * 9 + tid - 64];
+  if (tid >= 128 && tid < 131) s_ref[18 + tid - 128] = p.t[ref * 3 + tid - 128];
+
+  const int sample = (blockIdx.x * 256 + tid) / LP;       // (pixel, hypothesis) of this lane group
+  const int cg = tid % LP;
+  const bool active = sample < P * p.n_hyp;
+  const int pix = active ? sample / p.n_hyp : 0, hyp = active ? sample % p.n_hyp : 0;
+  const int gy = pix / p.w, gx = pix % p.w;
+  const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
+  const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
+  // hypothesis depth: depth + i * offset with i * offset evaluated in double then rounded (python float)
+  const float dep = p.depth[(size_t)r * P + pix] + (float)((double)(hyp - p.n_half) * p.offset);
+  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1), Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+  float X = 0.f, Y = 0.f, Z = 0.f;
+  float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_q = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int ec = 0; ec < ne; ec += kMaxE) {
+    const int nec = min(kMaxE, ne - ec);
+    __syncthreads();
+    if (tid < nec * 12) {      // P = K [R|t] of the chunk's source views (lightningmodel.py:152-154)
+      int e = tid / 12, ij = tid % 12, i = ij / 4, j = ij % 4;
+      int src = p.edge_src[e_begin + ec + e];
+      const float* Kp = p.K + src * 9; const float* Rp = p.R + src * 9; const float* tp = p.t + src * 3;
+      float v;
+      if (j < 3) v = Kp[i * 3 + 0] * Rp[0 * 3 + j] + Kp[i * 3 + 1] * Rp[1 * 3 + j] + Kp[i * 3 + 2] * Rp[2 * 3 + j];
+      else v = Kp[i * 3 + 0] * tp[0] + Kp[i * 3 + 1] * tp[1] + Kp[i * 3 + 2] * tp[2];
+      s_P[e][ij] = v;
+      if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
+    }
+    __syncthreads();
+    if (ec == 0) {   // world point X = R^T (K^-1 (pix * depth) - t)   (lightningmodel.py:142-144,202-204)
+      float p0 = xf * dep, p1 = yf * dep, p2 = dep;
+      float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
+      float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
+      float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
+      X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
+      Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
+      Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+    }
+    if (!active) continue;
+    for (int e = 0; e < nec; ++e) {
+      const float* Pm = s_P[e];
+      float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
+      float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
+      float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+      float zb = fabsf(qz) + 1e-8f;
+      float u = qx / zb, v = qy / zb;
+      float gxn = (u / Wm1) * 2.f - 1.f, gyn = (v / Hm1) * 2.f - 1.f;
+      float ix = ((gxn + 1.f) / 2.f) * Wfm1, iy = ((gyn + 1.f) / 2.f) * Hfm1;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ix > -1.f && ix < Wfm1 + 1.f && iy > -1.f && iy < Hfm1 + 1.f) {
+        const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
+        const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
+        const float w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f, w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
+        const float w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f, w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
+        const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+        const float* fb = p.featT + (size_t)s_base[e] * C + cg * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(fb + (yi0 * p.Wf + xi0) * C);
+        const float4 v01 = *reinterpret_cast<const float4*>(fb + (yi0 * p.Wf + xi1) * C);
+        const float4 v10 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi0) * C);
+        const float4 v11 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi1) * C);
+        s.x = v00.x * w00; s.y = v00.y * w00; s.z = v00.z * w00; s.w = v00.w * w00;
+        s.x += v01.x * w01; s.y += v01.y * w01; s.z += v01.z * w01; s.w += v01.w * w01;
+        s.x += v10.x * w10; s.y += v10.y * w10; s.z += v10.z * w10; s.w += v10.w * w10;
+        s.x += v11.x * w11; s.y += v11.y * w11; s.z += v11.z * w11; s.w += v11.w * w11;
+      }
+      acc_s.x += s.x; acc_s.y += s.y; acc_s.z += s.z; acc_s.w += s.w;
+      acc_q.x += s.x * s.x; acc_q.y += s.y * s.y; acc_q.z += s.z * s.z; acc_q.w += s.w * s.w;
+    }
+  }
+  if (!active) return;
+  const size_t row = ((size_t)r * P + pix) * p.n_hyp + hyp;
+  if (cg == 0) { p.pts[row * 3] = X; p.pts[row * 3 + 1] = Y; p.pts[row * 3 + 2] = Z; }
+  const float cnt = (float)max(ne, 1);
+  float4 o;
+  { float a = acc_s.x / cnt, q = acc_q.x / cnt; o.x = __fsub_rn(q, __fmul_rn(a, a)); }
+  { float a = acc_s.y / cnt, q = acc_q.y / cnt; o.y = __fsub_rn(q, __fmul_rn(a, a)); }
+  { float a = acc_s.z / cnt, q = acc_q.z / cnt; o.z = __fsub_rn(q, __fmul_rn(a, a)); }
+  { float a = acc_s.w / cnt, q = acc_q.w / cnt; o.w = __fsub_rn(q, __fmul_rn(a, a)); }
+  *reinterpret_cast<float4*>(p.var + row * C + cg * 4) = o;
+}
+
+}  // namespace
+
+extern "C" size_t v3d_backproject_workspace_bytes(int n_img, int C, int Hf, int Wf) {
+  return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256);
+}
+
+extern "C" int v3d_backproject_variance_f32(const float* depth, const float* feat, const float* K,
+                                            const float* R, const float* t, const int32_t* ref_img,
+                                            const int32_t* edge_ofs, const int32_t* edge_src, int n_img,
+                                            int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                                            int h, int w, double offset, int n_half, float* pts,
+                                            float* var, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  V3D_REQUIRE(depth && feat && K && R && t && ref_img && edge_ofs && edge_src && pts && var && workspace,
+              V3D_ERR_BAD_ARG, "v3d_backproject_variance_f32: null pointer argument");
+  V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED, "v3d_backproject_variance_f32: C=%d unsupported", C);
+  V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && H > 1 && W > 1 && h > 0 && w > 0 && n_half >= 0,
+              V3D_ERR_BAD_SHAPE, "v3d_backproject_variance_f32: bad shape");
+  V3D_REQUIRE(workspace_bytes >= v3d_backproject_workspace_bytes(n_img, C, Hf, Wf),
+              V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_backproject_variance_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* featT = (float*)workspace;
+  v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
+  V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
+  BpParams p;
+  p.depth = depth; p.featT = featT; p.K = K; p.R = R; p.t = t;
+  p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.pts = pts; p.var = var;
+  p.n_ref = n_ref; p.Hf = Hf; p.Wf = Wf; p.H = H; p.W = W; p.h = h; p.w = w;
+  p.n_hyp = 2 * n_half + 1; p.n_half = n_half; p.offset = offset;
+  p.x_step = w > 1 ? (double)(W - 1) / (double)(w - 1) : 0.0;
+  p.y_step = h > 1 ? (double)(H - 1) / (double)(h - 1) : 0.0;
+  const long long lanes = (long long)h * w * p.n_hyp * (C / 4);
+  dim3 grid((unsigned)((lanes + 255) / 256), n_ref);
+  {
+    v3d::TimedScope ts("backproject_variance", s);
+    if (C == 32) backproject_variance_kernel<32><<<grid, 256, 0, s>>>(p);
+    else backproject_variance_kernel<16><<<grid, 256, 0, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH("backproject_variance_kernel");
+  return V3D_OK;
+}

@@ -1,0 +1,321 @@
+// Gather-GEMM on the exact-fp32 matrix cores: the dense-arithmetic workhorse of rows B4 (PointNet),
+// B6 (sparse 3D U-Net) and C2b (hypothesis decoder conv1d) of SURVEY.md §8a.
+//
+//   Y[m, :] = epilogue( sum_{s < n_seg}  act(X_s[row_s(m), 0:K]) @ W_s  + bias )
+//
+// A "segment" is (source matrix, row map, weight slab):
+//   * PointNet fcK(relu(cat(x, pool[idx])))  -> 2 segments: (x, identity), (pool, idx)
+//                                                (scenemodeling.py:129-141)
+//   * sparse conv, 27 kernel offsets           -> 27 segments over one source, row map = column k of
+//                                                the neighbour table, -1 = absent voxel = zero row
+//                                                (MinkowskiConvolution, scenemodeling.py:36-38,160,181)
+//   * conv1d(k3, pad 1) along the 7 hypotheses -> 3 segments, row map m + (s - 1) inside each group
+//                                                of `group_len` rows (refinement.py:8-25)
+// Tile: 128 rows x N (<= 128) outputs per 256-thread workgroup.  D[co, row] orientation: the A operand
+// is the weight fragment (pre-packed, staged per 32-wide K chunk into LDS), the B operand the
+// gathered activations (LDS, row stride 34 floats = conflict-free for the 4 k-lanes x 16 row-lanes).
+// Each wave owns all 8 row blocks x N/64 channel blocks, so the per-row GroupNorm (16-channel groups
+// == one MFMA channel block, scenemodeling.py:98-104) needs only two cross-lane shuffles.
+// Segments whose row map is empty for the whole tile are skipped (structured sparsity).
+// Epilogue (all optional): + bias, GroupNorm(rows), + residual, ReLU, scatter-max into pool[idx[m]]
+// (order-independent => deterministic), row-major store.
+#include <vector>
+
+#include "v3d_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxSeg = 27;
+constexpr int kTM = 128;     // rows per workgroup
+constexpr int kKC = 32;      // K chunk
+constexpr int kXS = kKC + 2; // LDS row stride of the activation tile
+
+struct Seg {
+  const float* src;
+  const int* idx;   // row map or null (identity)
+  int ld;           // row stride of src in floats
+};
+
+struct GemmParams {
+  Seg seg[kMaxSeg];
+  int n_seg, M, N, K, KP;        // K real columns per segment, KP = K rounded up to kKC
+  int group_len;                 // > 0: conv1d row map (segment s reads row m + s - n_seg/2 of its group)
+  int relu_in;
+  const float* wp;               // packed [seg][KP/32][8][MB][64]
+  const float* bias;             // [N] or null
+  const float* gn_w; const float* gn_b; float gn_eps;   // row GroupNorm over 16-channel groups (null = off)
+  const float* residual; int ld_res;
+  int relu_out;
+  float* pool; const int* pool_idx; int ld_pool;        // scatter-max target (null = off)
+  float* out; int ld_out;                               // null = do not store
+};
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // order-independent max for mixed-sign floats; target initialised to -inf
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+template <int MBW>   // channel blocks (16 outputs) per wave: N = 64 * MBW (or N <= 16 * 4 * MBW)
+__global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
+  __shared__ float xs[kTM * kXS];
+  __shared__ float ws[4 * MBW * 16 * kKC];
+  __shared__ int s_any;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  const int m0 = blockIdx.x * kTM;
+  const int MB = 4 * MBW;
+
+  f32x4 acc[8][MBW];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging role: 8 lanes x float4 cover the 32 columns of one row; 32 rows per pass, 4 passes
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  const int nkc = p.KP / kKC;
+  const int wslab = MB * 16 * kKC;                 // packed floats per (segment, K chunk)
+
+  for (int s = 0; s < p.n_seg; ++s) {
+    const Seg sg = p.seg[s];
+    // source row of each of this thread's 4 staging rows (-1 = zero row)
+    int rsrc[4];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + srow + 32 * i;
+      int r = -1;
+      if (m < p.M) {
+        if (p.group_len > 0) {
+          const int h = m % p.group_len + s - p.n_seg / 2;
+          r = (h >= 0 && h < p.group_len) ? m + s - p.n_seg / 2 : -1;
+        } else {
+          r = sg.idx ? sg.idx[m] : m;
+        }
+      }
+      rsrc[i] = r;
+      any |= r >= 0;
+    }
+    if (sg.idx) {   // structured sparsity: skip a segment nobody in the tile needs
+      if (tid == 0) s_any = 0;
+      __syncthreads();
+      if (any) s_any = 1;
+      __syncthreads();
+      if (!s_any) continue;
+    }
+    const bool vec_ok = (sg.ld % 4 == 0) && (p.K % 4 == 0) && ((reinterpret_cast<size_t>(sg.src) & 15) == 0);
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();
+      // ---- stage activations (gathered rows, optional ReLU) --------------------------------------
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int col = kc * kKC + sc4;
+        if (rsrc[i] >= 0 && col < p.K) {
+          const float* rowp = sg.src + (size_t)rsrc[i] * sg.ld + col;
+          if (vec_ok) {
+            v = *reinterpret_cast<const float4*>(rowp);
+          } else {
+            v.x = rowp[0];
+            if (col + 1 < p.K) v.y = rowp[1];
+            if (col + 2 < p.K) v.z = rowp[2];
+            if (col + 3 < p.K) v.w = rowp[3];
+          }
+          if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        float* d = xs + (srow + 32 * i) * kXS + sc4;
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      }
+      // ---- stage the weight slab of this (segment, chunk) ------------------------------------------
+      const float4* wsrc = reinterpret_cast<const float4*>(p.wp + (size_t)(s * nkc + kc) * wslab);
+      for (int i = tid; i < wslab / 4; i += 256) reinterpret_cast<float4*>(ws)[i] = wsrc[i];
+      __syncthreads();
+      // ---- MFMA ------------------------------------------------------------------------------------
+#pragma unroll
+      for (int k4 = 0; k4 < kKC / 4; ++k4) {
+        float a[MBW];
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) a[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          const float bv = xs[(nb * 16 + jn) * kXS + k4 * 4 + kq];
+#pragma unroll
+          for (int m = 0; m < MBW; ++m)
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[nb][m], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    const int m = m0 + nb * 16 + jn;
+#pragma unroll
+    for (int mw = 0; mw < MBW; ++mw) {
+      const int co0 = (wave * MBW + mw) * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[nb][mw][r] + ((p.bias && co0 + r < p.N) ? p.bias[co0 + r] : 0.f);
+      if (p.gn_w) {
+        // GroupNorm over the 16 channels of this block for row m: 4 registers x 4 lane quarters
+        float sum = v[0] + v[1] + v[2] + v[3];
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.f / 16.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq += (v[r] - mean) * (v[r] - mean);
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        const float rstd = 1.f / sqrtf(sq * (1.f / 16.f) + p.gn_eps);      // biased variance (torch GN)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co0 + r < p.N) v[r] = (v[r] - mean) * rstd * p.gn_w[co0 + r] + p.gn_b[co0 + r];
+      }
+      if (m < p.M && co0 < p.N) {
+        if (p.residual) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < p.N) v[r] += p.residual[(size_t)m * p.ld_res + co0 + r];
+        }
+        if (p.relu_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.pool) {
+          float* pr = p.pool + (size_t)p.pool_idx[m] * p.ld_pool + co0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < p.N) atomic_max_float(pr + r, v[r]);
+        }
+        if (p.out) {
+          float* o = p.out + (size_t)m * p.ld_out + co0;
+          if (co0 + 3 < p.N && (p.ld_out % 4 == 0)) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co0 + r < p.N) o[r] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// ---- packed weights -------------------------------------------------------------------------------
+struct v3d_gemm_weights {
+  int N, K, KP, n_seg, MBW;
+  float* dev;       // packed fragments followed by bias[N] (0 if none), gn_w[N], gn_b[N]
+  size_t bias_ofs, gnw_ofs, gnb_ofs;
+  int has_bias, has_gn;
+};
+
+extern "C" int v3d_gemm_pack(const float* w_host, long long stride_seg, long long stride_co,
+                             long long stride_k, int n_seg, int N, int K, const float* scale_host,
+                             const float* bias_host, const float* gn_w_host, const float* gn_b_host,
+                             v3d_gemm_weights** out_handle) {
+  V3D_REQUIRE(w_host && out_handle, V3D_ERR_BAD_ARG, "v3d_gemm_pack: null argument");
+  V3D_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg && N >= 1 && N <= 128 && K >= 1, V3D_ERR_BAD_SHAPE,
+              "v3d_gemm_pack: unsupported shape (n_seg=%d N=%d K=%d)", n_seg, N, K);
+  v3d_gemm_weights* h = new v3d_gemm_weights();
+  h->N = N; h->K = K; h->n_seg = n_seg;
+  h->KP = (K + kKC - 1) / kKC * kKC;
+  h->MBW = N > 64 ? 2 : 1;
+  const int MB = 4 * h->MBW, nkc = h->KP / kKC;
+  const size_t wslab = (size_t)MB * 16 * kKC;
+  std::vector<float> host((size_t)n_seg * nkc * wslab + 3 * 128, 0.f);
+  for (int s = 0; s < n_seg; ++s)
+    for (int kc = 0; kc < nkc; ++kc)
+      for (int k4 = 0; k4 < kKC / 4; ++k4)
+        for (int mb = 0; mb < MB; ++mb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = mb * 16 + (lane & 15), k = kc * kKC + k4 * 4 + (lane >> 4);
+            float v = 0.f;
+            if (co < N && k < K) {
+              v = w_host[s * stride_seg + co * stride_co + k * stride_k];
+              if (scale_host) v *= scale_host[co];
+            }
+            host[((size_t)(s * nkc + kc) * wslab) + ((size_t)(k4 * MB + mb) * 64) + lane] = v;
+          }
+  h->bias_ofs = (size_t)n_seg * nkc * wslab;
+  h->gnw_ofs = h->bias_ofs + 128;
+  h->gnb_ofs = h->gnw_ofs + 128;
+  h->has_bias = bias_host != nullptr;
+  h->has_gn = gn_w_host != nullptr && gn_b_host != nullptr;
+  for (int i = 0; i < N; ++i) {
+    if (bias_host) host[h->bias_ofs + i] = bias_host[i];
+    if (h->has_gn) { host[h->gnw_ofs + i] = gn_w_host[i]; host[h->gnb_ofs + i] = gn_b_host[i]; }
+  }
+  hipError_t e = hipMalloc((void**)&h->dev, host.size() * sizeof(float));
+  if (e != hipSuccess) { delete h; return v3d::fail(V3D_ERR_HIP, "hipMalloc(gemm weights): %s", hipGetErrorString(e)); }
+  e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return v3d::fail(V3D_ERR_HIP, "hipMemcpy(gemm weights): %s", hipGetErrorString(e)); }
+  *out_handle = h;
+  return V3D_OK;
+}
+
+extern "C" void v3d_gemm_free(v3d_gemm_weights* h) {
+  if (!h) return;
+  if (h->dev) (void)hipFree(h->dev);
+  delete h;
+}
+
+extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float* const* seg_src_host,
+                                   const int32_t* const* seg_idx_host, const int* seg_ld_host,
+                                   int group_len, int relu_in, int use_gn, float gn_eps,
+                                   const float* residual, int ld_res, int relu_out, float* pool,
+                                   const int32_t* pool_idx, int ld_pool, float* out, int ld_out,
+                                   void* stream) {
+  V3D_REQUIRE(h && seg_src_host && seg_ld_host, V3D_ERR_BAD_ARG, "v3d_gemm_gather_f32: null argument");
+  V3D_REQUIRE(M >= 0, V3D_ERR_BAD_SHAPE, "v3d_gemm_gather_f32: M < 0");
+  V3D_REQUIRE(!use_gn || (h->has_gn && h->N % 16 == 0), V3D_ERR_BAD_ARG,
+              "v3d_gemm_gather_f32: GroupNorm requested but weights carry no affine / N %% 16 != 0");
+  V3D_REQUIRE(!pool || pool_idx, V3D_ERR_BAD_ARG, "v3d_gemm_gather_f32: pool without pool_idx");
+  if (M == 0) return V3D_OK;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  for (int s = 0; s < h->n_seg; ++s) {
+    V3D_REQUIRE(seg_src_host[s], V3D_ERR_BAD_ARG, "v3d_gemm_gather_f32: segment %d has no source", s);
+    p.seg[s].src = seg_src_host[s];
+    p.seg[s].idx = seg_idx_host ? seg_idx_host[s] : nullptr;
+    p.seg[s].ld = seg_ld_host[s];
+  }
+  p.n_seg = h->n_seg; p.M = M; p.N = h->N; p.K = h->K; p.KP = h->KP;
+  p.group_len = group_len; p.relu_in = relu_in;
+  p.wp = h->dev; p.bias = h->has_bias ? h->dev + h->bias_ofs : nullptr;
+  p.gn_w = use_gn ? h->dev + h->gnw_ofs : nullptr; p.gn_b = use_gn ? h->dev + h->gnb_ofs : nullptr;
+  p.gn_eps = gn_eps;
+  p.residual = residual; p.ld_res = ld_res; p.relu_out = relu_out;
+  p.pool = pool; p.pool_idx = pool_idx; p.ld_pool = ld_pool;
+  p.out = out; p.ld_out = ld_out;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((M + kTM - 1) / kTM);
+  {
+    v3d::TimedScope ts(h->n_seg == 27 ? "sparse_conv_gemm" : h->n_seg == 3 ? "conv1d_gemm" : "linear_gemm", s);
+    if (h->MBW == 2) gemm_gather_kernel<2><<<blocks, 256, 0, s>>>(p);
+    else gemm_gather_kernel<1><<<blocks, 256, 0, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH("gemm_gather_kernel");
+  return V3D_OK;
+}
+
+extern "C" int v3d_fill_f32(float* ptr, size_t n, float value, void* stream) {
+  V3D_REQUIRE(ptr || n == 0, V3D_ERR_BAD_ARG, "v3d_fill_f32: null pointer");
+  if (n == 0) return V3D_OK;
+  fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(ptr, n, value);
+  V3D_CHECK_LAUNCH("fill_kernel");
+  return V3D_OK;
+}

@@ -243,6 +243,16 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
 
 }  // namespace
 
+// shared with backproject.hip
+int v3d::transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s) {
+  dim3 tg((HW + kPix - 1) / kPix, n_img);
+  v3d::TimedScope ts("transpose_channel_last", s);
+  if (C == 32) transpose_channel_last_kernel<32><<<tg, 256, 0, s>>>(feat, featT, HW);
+  else if (C == 16) transpose_channel_last_kernel<16><<<tg, 256, 0, s>>>(feat, featT, HW);
+  else return -1;
+  return 0;
+}
+
 extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
   return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256);
 }
@@ -268,13 +278,7 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
               workspace_bytes, v3d_psv_workspace_bytes(n_img, C, Hf, Wf));
   hipStream_t s = (hipStream_t)stream;
   float* featT = (float*)workspace;
-  const int HW = Hf * Wf;
-  dim3 tg((HW + kPix - 1) / kPix, n_img);
-  {
-    v3d::TimedScope ts("transpose_channel_last", s);
-    if (C == 32) transpose_channel_last_kernel<32><<<tg, 256, 0, s>>>(feat, featT, HW);
-    else transpose_channel_last_kernel<16><<<tg, 256, 0, s>>>(feat, featT, HW);
-  }
+  v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
   V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
 
   PsvParams p;

@@ -1,0 +1,174 @@
+// Hash-indexed sparse-tensor structure kernels replacing MinkowskiEngine's coordinate manager on the
+// refinement path (semantics restated in SURVEY Appendix A):
+//   * open-addressing hash table over packed (batch, x, y, z) coordinates,
+//   * 27-offset neighbour ("kernel map") tables for stride-1 / stride-2 convs and stride-2 transposed
+//     convs -- consumed as row maps by the gather-GEMM (gemm_gather.hip),
+//   * sparse trilinear interpolation at arbitrary query points (MinkowskiInterpolation,
+//     mv3d/subnetworks/refinement.py:26,39), written straight into the decoder's wide feature row.
+#include "v3d_common.h"
+
+namespace {
+
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr int kGuard = 8;   // coordinates may be probed a few voxels below zero
+
+__device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int z) {
+  return ((unsigned long long)(unsigned)(b & 0xffff) << 48) | ((unsigned long long)(unsigned)((x + kGuard) & 0xffff) << 32) |
+         ((unsigned long long)(unsigned)((y + kGuard) & 0xffff) << 16) | (unsigned long long)(unsigned)((z + kGuard) & 0xffff);
+}
+
+__device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (unsigned)k;
+}
+
+struct HashTable {          // device layout inside the caller-provided buffer
+  unsigned long long* keys; // [cap]
+  int* vals;                // [cap]
+  unsigned mask;            // cap - 1 (cap = power of two)
+};
+
+__device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
+  unsigned slot = hash_u64(key) & t.mask;
+  for (unsigned probe = 0; probe <= t.mask; ++probe) {
+    const unsigned long long k = t.keys[slot];
+    if (k == key) return t.vals[slot];
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & t.mask;
+  }
+  return -1;
+}
+
+__global__ void hash_clear_kernel(unsigned long long* keys, unsigned cap) {
+  unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < cap) keys[i] = kEmpty;
+}
+
+__global__ void hash_insert_kernel(HashTable t, const int* __restrict__ coords, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = pack_key(coords[i * 4], coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3]);
+  unsigned slot = hash_u64(key) & t.mask;
+  for (unsigned probe = 0; probe <= t.mask; ++probe) {
+    const unsigned long long prev = atomicCAS(&t.keys[slot], kEmpty, key);
+    if (prev == kEmpty || prev == key) { t.vals[slot] = i; return; }   // coordinates are unique rows
+    slot = (slot + 1) & t.mask;
+  }
+}
+
+// nbr[k][p] = row of (out_coords[p] + step * o_k) in the hashed map, o_k in {-1,0,1}^3 with
+// k = (ox+1) + 3 (oy+1) + 9 (oz+1);  conv: step = +ts_in, transposed conv: step = -ts_out.
+__global__ void neighbors_kernel(HashTable t, const int* __restrict__ out_coords, int n_out, int step,
+                                 int* __restrict__ nbr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const int b = out_coords[i * 4], x = out_coords[i * 4 + 1], y = out_coords[i * 4 + 2], z = out_coords[i * 4 + 3];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+    nbr[(size_t)k * n_out + i] = hash_find(t, pack_key(b, x + step * ox, y + step * oy, z + step * oz));
+  }
+}
+
+// Sparse trilinear interpolation.  C/4 threads per query, float4 channels each.
+__global__ __launch_bounds__(256) void sparse_interp_kernel(HashTable t, const float* __restrict__ feats,
+                                                            int C, int ts, const float* __restrict__ pts,
+                                                            const long long* __restrict__ pts_batch,
+                                                            int n_hyp, const float* __restrict__ min_pts,
+                                                            float res, int n_query, float* __restrict__ out,
+                                                            int ld_out, int col0) {
+  const int tpq = C / 4;                       // threads per query
+  const int q = (blockIdx.x * 256 + threadIdx.x) / tpq;
+  const int c4 = ((blockIdx.x * 256 + threadIdx.x) % tpq) * 4;
+  if (q >= n_query) return;
+  const int b = (int)pts_batch[q / n_hyp];
+  // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
+  float qc[3], lo[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    qc[d] = ((pts[(size_t)q * 3 + d] - min_pts[b * 3 + d]) / res) * (float)ts;
+    lo[d] = floorf(qc[d] / (float)ts) * (float)ts;
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const float cx = lo[0] + ((corner & 1) ? ts : 0), cy = lo[1] + ((corner & 2) ? ts : 0),
+                cz = lo[2] + ((corner & 4) ? ts : 0);
+    const float w = (1.f - fabsf(qc[0] - cx) / ts) * (1.f - fabsf(qc[1] - cy) / ts) * (1.f - fabsf(qc[2] - cz) / ts);
+    // coordinates far outside the packed range cannot be present
+    if (cx < -kGuard || cy < -kGuard || cz < -kGuard || cx > 60000.f || cy > 60000.f || cz > 60000.f) continue;
+    const int row = hash_find(t, pack_key(b, (int)cx, (int)cy, (int)cz));
+    if (row >= 0) {
+      const float4 f = *reinterpret_cast<const float4*>(feats + (size_t)row * C + c4);
+      acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
+    }
+  }
+  float* o = out + (size_t)q * ld_out + col0 + c4;
+  o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+}
+
+unsigned table_capacity(int n) {
+  unsigned cap = 64;
+  while (cap < 2u * (unsigned)(n > 0 ? n : 1)) cap <<= 1;
+  return cap;
+}
+
+HashTable table_view(void* buf, int n) {
+  HashTable t;
+  const unsigned cap = table_capacity(n);
+  t.keys = (unsigned long long*)buf;
+  t.vals = (int*)((char*)buf + (size_t)cap * 8);
+  t.mask = cap - 1;
+  return t;
+}
+
+}  // namespace
+
+extern "C" size_t v3d_hash_bytes(int n) { return (size_t)table_capacity(n) * 12; }
+
+extern "C" int v3d_hash_build(const int32_t* coords, int n, void* table, size_t table_bytes, void* stream) {
+  V3D_REQUIRE(coords && table, V3D_ERR_BAD_ARG, "v3d_hash_build: null argument");
+  V3D_REQUIRE(n > 0, V3D_ERR_BAD_SHAPE, "v3d_hash_build: empty coordinate map");
+  V3D_REQUIRE(table_bytes >= v3d_hash_bytes(n), V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_hash_build: table buffer too small");
+  hipStream_t s = (hipStream_t)stream;
+  HashTable t = table_view(table, n);
+  v3d::TimedScope ts("hash_build", s);
+  hash_clear_kernel<<<(t.mask + 256) / 256, 256, 0, s>>>(t.keys, t.mask + 1);
+  hash_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(t, coords, n);
+  V3D_CHECK_LAUNCH("hash_insert_kernel");
+  return V3D_OK;
+}
+
+extern "C" int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* out_coords, int n_out,
+                                    int step, int32_t* nbr, void* stream) {
+  V3D_REQUIRE(table && out_coords && nbr, V3D_ERR_BAD_ARG, "v3d_sparse_neighbors: null argument");
+  V3D_REQUIRE(n_in > 0 && n_out > 0 && step != 0, V3D_ERR_BAD_SHAPE, "v3d_sparse_neighbors: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  HashTable t = table_view(const_cast<void*>(table), n_in);
+  v3d::TimedScope ts("sparse_neighbors", s);
+  neighbors_kernel<<<(n_out + 255) / 256, 256, 0, s>>>(t, out_coords, n_out, step, nbr);
+  V3D_CHECK_LAUNCH("neighbors_kernel");
+  return V3D_OK;
+}
+
+extern "C" int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C,
+                                     int tensor_stride, const float* pts, const int64_t* pts_batch,
+                                     int n_pts, int n_hyp, const float* min_pts, float res, float* out,
+                                     int ld_out, int col0, void* stream) {
+  V3D_REQUIRE(table && feats && pts && pts_batch && min_pts && out, V3D_ERR_BAD_ARG,
+              "v3d_sparse_interp_f32: null argument");
+  V3D_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0, V3D_ERR_UNSUPPORTED,
+              "v3d_sparse_interp_f32: C=%d unsupported", C);
+  V3D_REQUIRE(n_in > 0 && n_pts >= 0 && n_hyp > 0 && tensor_stride > 0 && res > 0.f, V3D_ERR_BAD_SHAPE,
+              "v3d_sparse_interp_f32: bad shape");
+  const long long nq = (long long)n_pts * n_hyp;
+  if (nq == 0) return V3D_OK;
+  hipStream_t s = (hipStream_t)stream;
+  HashTable t = table_view(const_cast<void*>(table), n_in);
+  const long long threads = nq * (C / 4);
+  v3d::TimedScope ts("sparse_interp", s);
+  sparse_interp_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(
+      t, feats, C, tensor_stride, pts, (const long long*)pts_batch, n_hyp, min_pts, res, (int)nq, out, ld_out, col0);
+  V3D_CHECK_LAUNCH("sparse_interp_kernel");
+  return V3D_OK;
+}

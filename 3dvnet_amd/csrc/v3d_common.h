@@ -62,4 +62,7 @@ struct TimedScope {
   }
 };
 
+// [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
+int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
+
 }  // namespace v3d

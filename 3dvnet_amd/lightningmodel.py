@@ -1,0 +1,111 @@
+"""Host-side mirror of the inference methods of ``mv3d/lightningmodel.py`` (SURVEY.md §8a rows A7, B2,
+B5, C1-C3; §8b): ``PL3DVNet`` with the reference's constructor arguments, sub-module names and method
+signatures / return tuples.  Training-only members (losses, Lightning hooks, optimiser) are out of
+scope -- the benchmark path runs under ``torch.no_grad()`` (mv3d/eval-3dvnet.py:27).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib, utils
+from .mvsnet import MVSNet, _Workspace, edges_to_csr
+from .refinement import HypothesisDecoder
+from .scenemodeling import PointNet, SparseUNet
+
+
+def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges, img_size, offset=0.0,
+                         n=0, workspace=None):
+    """Rows B1-B2 / C1: -> (pts [n_ref*P, 2n+1, 3], var [n_ref*P, 2n+1, C])."""
+    if not depth_pred.is_cuda:
+        raise _lib.V3DLibraryError('backproject_variance: tensors must live on a HIP device (no CPU fallback)')
+    lib = _lib.load()
+    dev = depth_pred.device
+    feat = img_feats.contiguous().float()
+    n_img, C, Hf, Wf = feat.shape
+    _, ref_img, edge_ofs, edge_src = edges_to_csr(ref_src_edges.to(dev))
+    n_ref, h, w = depth_pred.shape
+    assert n_ref == ref_img.shape[0], 'one depth map per reference view'
+    n_hyp = 2 * n + 1
+    pts = torch.empty((n_ref * h * w, n_hyp, 3), dtype=torch.float32, device=dev)
+    var = torch.empty((n_ref * h * w, n_hyp, C), dtype=torch.float32, device=dev)
+    nbytes = lib.v3d_backproject_workspace_bytes(n_img, C, Hf, Wf)
+    ws = (workspace or _Workspace()).get('bp', nbytes, dev)
+    Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
+    d = depth_pred.contiguous().float()
+    rc = lib.v3d_backproject_variance_f32(d.data_ptr(), feat.data_ptr(), Kc.data_ptr(), Rc.data_ptr(),
+                                          tc.data_ptr(), ref_img.data_ptr(), edge_ofs.data_ptr(),
+                                          edge_src.data_ptr(), n_img, n_ref, edge_src.shape[0], C, Hf, Wf,
+                                          int(img_size[0]), int(img_size[1]), h, w, float(offset), int(n),
+                                          pts.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr(dev))
+    _lib.check(rc, 'v3d_backproject_variance_f32')
+    return pts, var
+
+
+class PL3DVNet(nn.Module):
+    """Reference ``PL3DVNet`` (lightningmodel.py:14-43), inference surface only."""
+
+    def __init__(self, depth_train, depth_test, edge_len, feat_dim=16, img_size=(256, 320), hyp_ksize=3,
+                 hyp_pad=1, lr=1e-3, lr_step=100, lr_gamma=0.1, finetune=False, feat_extractor=None,
+                 feat_shrinker=None):
+        super().__init__()
+        self.depth_train, self.depth_test, self.edge_len = depth_train, depth_test, edge_len
+        self.feat_dim, self.img_size = feat_dim, img_size
+        self.hparams = SimpleNamespace(depth_train=depth_train, depth_test=depth_test, edge_len=edge_len,
+                                       feat_dim=feat_dim, img_size=img_size, hyp_ksize=hyp_ksize,
+                                       hyp_pad=hyp_pad, lr=lr, lr_step=lr_step, lr_gamma=lr_gamma,
+                                       finetune=finetune)
+        self.mvsnet = MVSNet(feat_dim, img_size, feat_extractor, feat_shrinker)
+        self.pointnet = PointNet(4 * feat_dim, 2 * feat_dim, feat_dim + 3)
+        self.sparse_conv = SparseUNet(dims=(2 * feat_dim, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3))
+        self.decoder = HypothesisDecoder(128 + 128 + 3 * feat_dim, 128, hyp_ksize, hyp_pad)
+        self._ws = _Workspace()
+
+    def make_initial_depth_predictions(self, batch, depth_config):
+        """lightningmodel.py:124-130."""
+        depth_pred, feats_half, feats_quarter, features_eighth = self.mvsnet(
+            batch, depth_config['depth_start'], depth_config['depth_interval'], depth_config['n_intervals'],
+            depth_config['size'])
+        ref_idx = torch.unique(batch.ref_src_edges[0])
+        depth_batch = batch.images_batch[ref_idx]
+        return depth_pred, depth_batch, feats_half, feats_quarter, features_eighth, ref_idx
+
+    def construct_feature_rich_pointcloud(self, depth_pred, depth_batch, img_feats, rotmats, tvecs, K,
+                                          ref_src_edges):
+        """lightningmodel.py:132-174 -> (pts [Np,3], pts_feat [Np,C], pts_batch [Np])."""
+        n_imgs = depth_pred.shape[0]
+        pts, var = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
+                                        self.hparams.img_size, workspace=self._ws)
+        pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, depth_pred.shape[1] * depth_pred.shape[2]).reshape(-1)
+        return pts.view(-1, 3), var.view(-1, var.shape[-1]), pts_batch
+
+    def model_scene(self, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
+                    return_pts=False, gather_fn=None):
+        """lightningmodel.py:176-185.  ``gather_fn`` (multi-GPU): all-gathers the local
+        feature-rich point cloud in view order before the replicated voxelise / PointNet / U-Net."""
+        pts, pts_feat, pts_batch = self.construct_feature_rich_pointcloud(depth_pred, depth_batch, img_feats,
+                                                                          rotmats, tvecs, K, ref_src_edges)
+        if gather_fn is not None:
+            pts, pts_feat, pts_batch = gather_fn(pts, pts_feat, pts_batch)
+        anchor_pts, anchor_idx3d, anchor_batch, anchor_pts_edges = utils.voxelize(pts, pts_batch, self.edge_len)
+        n_anchors = anchor_pts.shape[0]
+        x = torch.cat((pts[anchor_pts_edges[1]] - anchor_pts[anchor_pts_edges[0]],
+                       pts_feat[anchor_pts_edges[1]]), dim=1)
+        x = self.pointnet(x, anchor_pts_edges[0], n_anchors)
+        xs = self.sparse_conv(x, anchor_pts, anchor_idx3d, anchor_batch, self.edge_len)
+        return (xs, pts) if return_pts else xs
+
+    def run_pointflow(self, xs, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
+                      offset, n):
+        """lightningmodel.py:187-242 -> offset prediction [n_ref, h, w]."""
+        n_imgs = depth_pred.shape[0]
+        n_pts = depth_pred.shape[1] * depth_pred.shape[2]
+        pts_hyp, pts_feat = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
+                                                 self.hparams.img_size, offset=offset, n=n,
+                                                 workspace=self._ws)
+        pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
+        offset_vals = torch.linspace(-n * offset, n * offset, 2 * n + 1)
+        feats = self.decoder.features(xs, pts_hyp, pts_feat, pts_batch)
+        _, expect = self.decoder.decode(feats, offset_vals)
+        return expect.view(n_imgs, *depth_pred.shape[1:])

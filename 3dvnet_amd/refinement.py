@@ -1,0 +1,97 @@
+"""Host-side mirror of ``mv3d/subnetworks/refinement.py``:
+``HypothesisDecoder`` with the reference's constructor, ``forward`` signature and ``state_dict`` keys
+(``net.{0,1,2}.{0.weight,1.*}``, ``net.3.{weight,bias}``).  ``MinkowskiInterpolation`` becomes the
+hash-indexed trilinear kernel, the Conv1d+BN+ReLU stack a 3-segment gather-GEMM on fp32 MFMA, the last
+conv + softmax a per-point wave kernel.  No CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .scenemodeling import PackedGemm, _PackCache
+
+
+def conv1d_bn_relu(in_channels, out_channels, kernel_size=3, stride=1, padding=1):
+    """Parameter container with the reference's layout (refinement.py:8-13)."""
+    return nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding, bias=False),
+                         nn.BatchNorm1d(out_channels), nn.ReLU(inplace=True))
+
+
+class HypothesisDecoder(nn.Module):
+    """``forward(xs, pts[Nq,n_hyp,3], pts_feat[Nq,n_hyp,C]|None, pts_batch[Nq]) -> preds[Nq,n_hyp]``
+    (refinement.py:28-44)."""
+
+    def __init__(self, in_dim=128 + 128 + 64, h_dim=256, kernel_size=3, padding=1):
+        super().__init__()
+        assert kernel_size == 3 and padding == 1, 'the reference instantiates k=3, pad=1 (lightningmodel.py:39-40)'
+        self.in_dim, self.h_dim = in_dim, h_dim
+        self.net = nn.Sequential(conv1d_bn_relu(in_dim, h_dim), conv1d_bn_relu(h_dim, h_dim),
+                                 conv1d_bn_relu(h_dim, h_dim), nn.Conv1d(h_dim, 1, kernel_size, 1, padding))
+        self._cache = _PackCache(self)
+
+    def _build(self):
+        packs = []
+        for i in range(3):
+            conv, bn = self.net[i][0], self.net[i][1]
+            co, ci, _ = conv.weight.shape
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)          # eval-mode BatchNorm1d folded
+            bias = bn.bias - bn.running_mean * scale
+            packs.append(PackedGemm(conv.weight, 1, 3 * ci, 3, 3, co, ci, scale=scale, bias=bias))
+        dev = self.net[3].weight.device
+        return packs, self.net[3].weight.detach().float().contiguous().to(dev), \
+            self.net[3].bias.detach().float().contiguous().to(dev)
+
+    def features(self, xs, pts, pts_feat, pts_batch):
+        """Row C2a: [Nq, n_hyp, in_dim] = [finest level | ... | coarsest level | pts_feat]."""
+        lib = _lib.load()
+        dev = pts.device
+        n_pts, n_hyp = pts.shape[:2]
+        pts = pts.contiguous().float()
+        pts_batch = pts_batch.contiguous().long()
+        widths = [x['feats'].shape[1] for x in xs]
+        cf = 0 if pts_feat is None else pts_feat.shape[2]
+        total = sum(widths) + cf
+        assert total == self.in_dim, (total, self.in_dim)
+        feats = torch.empty((n_pts, n_hyp, total), dtype=torch.float32, device=dev)
+        if pts_feat is not None:
+            feats[:, :, total - cf:] = pts_feat
+        col = total - cf
+        for x in xs:                                   # coarse -> fine, each level prepended (:41)
+            lv = x['sparse']
+            col -= x['feats'].shape[1]
+            nb = int(x['batch'].max().item()) + 1
+            min_pts = torch.zeros((nb, 3), dtype=torch.float32, device=dev).scatter_reduce_(
+                0, x['batch'].view(-1, 1).expand(-1, 3), x['pts'], 'amin', include_self=False)   # :33
+            f = x['feats'].contiguous()
+            rc = lib.v3d_sparse_interp_f32(lv.table.data_ptr(), lv.n, f.data_ptr(), f.shape[1],
+                                           int(x['stride']), pts.data_ptr(), pts_batch.data_ptr(), n_pts,
+                                           n_hyp, min_pts.data_ptr(), float(x['res']), feats.data_ptr(),
+                                           total, col, _lib.stream_ptr(dev))
+            _lib.check(rc, 'v3d_sparse_interp_f32')
+        return feats
+
+    def decode(self, feats, offset_vals=None):
+        """Row C2b (+C3 when offset_vals is given): feats [Nq, n_hyp, in_dim] -> preds [Nq, n_hyp]
+        (and the expected offset [Nq])."""
+        assert not self.training, 'inference only: BatchNorm is folded with running statistics'
+        lib = _lib.load()
+        packs, w_last, b_last = self._cache.get(self._build)
+        n_pts, n_hyp, _ = feats.shape
+        x = feats.view(n_pts * n_hyp, -1)
+        for pk in packs:
+            x = pk(n_pts * n_hyp, [x, x, x], group_len=n_hyp, relu_out=True)
+        preds = torch.empty((n_pts, n_hyp), dtype=torch.float32, device=feats.device)
+        expect = None
+        if offset_vals is not None:
+            offset_vals = offset_vals.to(feats.device).float().contiguous()
+            expect = torch.empty(n_pts, dtype=torch.float32, device=feats.device)
+        rc = lib.v3d_decoder_head_f32(x.data_ptr(), n_pts, n_hyp, x.shape[1], w_last.data_ptr(),
+                                      b_last.data_ptr(), _lib.ptr(offset_vals), preds.data_ptr(),
+                                      _lib.ptr(expect), _lib.stream_ptr(feats.device))
+        _lib.check(rc, 'v3d_decoder_head_f32')
+        return preds if expect is None else (preds, expect)
+
+    def forward(self, xs, pts, pts_feat, pts_batch):
+        if not pts.is_cuda:
+            raise _lib.V3DLibraryError('HypothesisDecoder: tensors must live on a HIP device (no CPU fallback)')
+        return self.decode(self.features(xs, pts, pts_feat, pts_batch))

@@ -1,0 +1,303 @@
+"""Host-side mirror of ``mv3d/subnetworks/scenemodeling.py``: ``PointNet``
+and ``SparseUNet`` with the reference's constructor arguments, ``forward`` signatures, return
+structures and ``state_dict`` keys (MinkowskiEngine parameter naming: ``.kernel``, ``.gn.weight``).
+MinkowskiEngine is replaced by hash-indexed neighbour tables + the fp32-MFMA gather-GEMM of
+``lib3dvnet_hip.so`` (csrc/sparse.hip, csrc/gemm_gather.hip); torch_scatter's max is fused into the
+GEMM epilogue.  No CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_NEG_INF = float('-inf')
+
+
+def _host_f32(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+class PackedGemm:
+    """Device-resident packed weights of one gather-GEMM layer (v3d_gemm_pack)."""
+
+    def __init__(self, w, stride_seg, stride_co, stride_k, n_seg, N, K, scale=None, bias=None,
+                 gn_w=None, gn_b=None):
+        lib = _lib.load()
+        keep = [_host_f32(w)] + [None if x is None else _host_f32(x) for x in (scale, bias, gn_w, gn_b)]
+        ptrs = [None if a is None else a.ctypes.data_as(_lib.c_float_p) for a in keep]
+        self.handle = ctypes.c_void_p()
+        rc = lib.v3d_gemm_pack(ptrs[0], stride_seg, stride_co, stride_k, n_seg, N, K, ptrs[1], ptrs[2],
+                               ptrs[3], ptrs[4], ctypes.byref(self.handle))
+        _lib.check(rc, 'v3d_gemm_pack')
+        self.n_seg, self.N, self.K = n_seg, N, K
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().v3d_gemm_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def __call__(self, M, srcs, idxs=None, lds=None, group_len=0, relu_in=False, use_gn=False,
+                 gn_eps=1e-5, residual=None, relu_out=False, pool=None, pool_idx=None, out=True,
+                 device=None):
+        """srcs: list of n_seg source matrices [rows, ld] (float32, contiguous);
+        idxs: list of int32 row maps (or None = identity) per segment."""
+        lib = _lib.load()
+        n = self.n_seg
+        dev = srcs[0].device
+        if not srcs[0].is_cuda:
+            raise _lib.V3DLibraryError('gather-GEMM: tensors must live on a HIP device (no CPU fallback)')
+        assert len(srcs) == n
+        src_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        idx_arr = (ctypes.c_void_p * n)(*[(None if (idxs is None or idxs[i] is None) else
+                                          (idxs[i] if isinstance(idxs[i], int) else idxs[i].data_ptr()))
+                                         for i in range(n)])
+        ld_arr = (ctypes.c_int * n)(*[(lds[i] if lds is not None else srcs[i].shape[-1]) for i in range(n)])
+        y = None
+        if out is True:
+            y = torch.empty((M, self.N), dtype=torch.float32, device=dev)
+        elif out is not None and out is not False:
+            y = out
+        rc = lib.v3d_gemm_gather_f32(
+            self.handle, M, src_arr, idx_arr, ld_arr, group_len, int(relu_in), int(use_gn), gn_eps,
+            _lib.ptr(residual), residual.shape[-1] if residual is not None else 0, int(relu_out),
+            _lib.ptr(pool), _lib.ptr(pool_idx), pool.shape[-1] if pool is not None else 0,
+            _lib.ptr(y), y.stride(0) if y is not None else 0, _lib.stream_ptr(dev))
+        _lib.check(rc, 'v3d_gemm_gather_f32')
+        return y
+
+
+class _PackCache:
+    """Re-packs when any parameter of the owning module changed (version counters)."""
+
+    def __init__(self, module):
+        self._module = module
+        self._key = None
+        self._packs = None
+
+    def get(self, builder):
+        key = tuple(int(p._version) for p in list(self._module.parameters()) + list(self._module.buffers()))
+        if self._packs is None or key != self._key:
+            self._packs, self._key = builder(), key
+        return self._packs
+
+
+class PointNet(nn.Module):
+    """Reference ``PointNet(hidden_dim, out_dim, in_dim=3)`` (scenemodeling.py:116-144):
+    ``forward(pts[Np,in_dim], idx[Np], n_idx) -> [n_idx, out_dim]``."""
+
+    def __init__(self, hidden_dim, out_dim, in_dim=3):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.fc_pos = nn.Linear(in_dim, hidden_dim)
+        self.fc1 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc2 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.fc3 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.fc4 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.fc_out = nn.Linear(hidden_dim, out_dim)
+        self._cache = _PackCache(self)
+
+    def _build(self):
+        def lin(m, n_seg):
+            N, Kt = m.weight.shape
+            return PackedGemm(m.weight, Kt // n_seg, Kt, 1, n_seg, N, Kt // n_seg, bias=m.bias)
+        return dict(fc_pos=lin(self.fc_pos, 1), fc1=lin(self.fc1, 1), fc2=lin(self.fc2, 2),
+                    fc3=lin(self.fc3, 2), fc4=lin(self.fc4, 2), fc_out=lin(self.fc_out, 1))
+
+    def forward(self, pts, idx, n_idx):
+        if not pts.is_cuda:
+            raise _lib.V3DLibraryError('PointNet: tensors must live on a HIP device (no CPU fallback)')
+        g = self._cache.get(self._build)
+        lib = _lib.load()
+        dev = pts.device
+        pts = pts.contiguous().float()
+        Np, H = pts.shape[0], self.hidden_dim
+        idx32 = idx.to(torch.int32).contiguous()
+        stream = _lib.stream_ptr(dev)
+
+        def new_pool():
+            pool = torch.empty((n_idx, H), dtype=torch.float32, device=dev)
+            _lib.check(lib.v3d_fill_f32(pool.data_ptr(), pool.numel(), _NEG_INF, stream), 'v3d_fill_f32')
+            return pool
+
+        h = g['fc_pos'](Np, [pts])                                            # fc_pos(pts)
+        pool = new_pool()
+        x = g['fc1'](Np, [h], relu_in=True, pool=pool, pool_idx=idx32)        # fc1(relu(.)) + max-pool
+        for name in ('fc2', 'fc3', 'fc4'):
+            nxt = new_pool()
+            last = name == 'fc4'
+            x = g[name](Np, [x, pool], idxs=[None, idx32], relu_in=True, pool=nxt, pool_idx=idx32,
+                        out=None if last else True)                           # fcK(relu(cat(x, pool[idx])))
+            pool = nxt
+        return g['fc_out'](n_idx, [pool], relu_in=True)
+
+
+class _SparseConv(nn.Module):
+    """Parameter container for a MinkowskiConvolution(-Transpose): ``kernel`` [27, Ci, Co] or [Ci, Co]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3):
+        super().__init__()
+        shape = (27, in_channels, out_channels) if kernel_size == 3 else (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        nn.init.kaiming_uniform_(self.kernel.view(-1, out_channels).t(), a=5 ** 0.5)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+
+
+class MinkowskiGroupNorm(nn.Module):
+    """Reference-defined wrapper (scenemodeling.py:78-113): ``gn = torch.nn.GroupNorm(G, C)`` applied to
+    the [N, C] feature matrix => every voxel row is normalised on its own."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True):
+        super().__init__()
+        self.gn = nn.GroupNorm(num_groups, num_channels, eps=eps, affine=affine)
+
+
+class SparseResidual3d(nn.Module):
+    def __init__(self, feat_dim, norm="gn", num_groups=None):
+        super().__init__()
+        assert norm == "gn", 'only the GroupNorm variant is instantiated by the reference (scenemodeling.py:154,174)'
+        self.n1 = MinkowskiGroupNorm(num_groups, feat_dim)
+        self.n2 = MinkowskiGroupNorm(num_groups, feat_dim)
+        nn.init.constant_(self.n2.gn.weight, 0)
+        self.conv1 = _SparseConv(feat_dim, feat_dim)
+        self.conv2 = _SparseConv(feat_dim, feat_dim)
+
+
+class SparseLevel:
+    """Stand-in for the ``ME.SparseTensor`` stored under ``'sparse'`` in each level dict
+    (scenemodeling.py:234): int32 coordinates + hash table + features + tensor stride."""
+
+    def __init__(self, coords, stride):
+        lib = _lib.load()
+        self.coords = coords.contiguous()
+        self.n = coords.shape[0]
+        self.stride = stride
+        nbytes = lib.v3d_hash_bytes(self.n)
+        self.table = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+        _lib.check(lib.v3d_hash_build(self.coords.data_ptr(), self.n, self.table.data_ptr(), nbytes,
+                                      _lib.stream_ptr(coords.device)), 'v3d_hash_build')
+        self.feats = None
+
+    def neighbors(self, out_coords, step):
+        """[27, n_out] int32 row map: row of out_coords[p] + step * o_k in this level (or -1)."""
+        lib = _lib.load()
+        n_out = out_coords.shape[0]
+        nbr = torch.empty((27, n_out), dtype=torch.int32, device=out_coords.device)
+        _lib.check(lib.v3d_sparse_neighbors(self.table.data_ptr(), self.n, out_coords.data_ptr(), n_out,
+                                            step, nbr.data_ptr(), _lib.stream_ptr(out_coords.device)),
+                   'v3d_sparse_neighbors')
+        return nbr
+
+
+class SparseUNet(nn.Module):
+    """Reference ``SparseUNet(dims, n_groups, n_res)`` (scenemodeling.py:147-237):
+    ``forward(F, pts, idx, batch, res) -> list[dict(feats, pts, res, batch, idx, stride, sparse)]``,
+    coarse -> fine."""
+
+    def __init__(self, dims=(64, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3)):
+        super().__init__()
+        assert all(d // g == 16 for d, g in zip(dims, n_groups)), \
+            'the fused GroupNorm epilogue handles 16-channel groups (reference: 64/4, 128/8)'
+        self.dims, self.n_groups, self.n_res = tuple(dims), tuple(n_groups), tuple(n_res)
+        self.res_down = nn.ModuleList([nn.Sequential(*[SparseResidual3d(dims[i], "gn", n_groups[i])
+                                                       for _ in range(n)]) for i, n in enumerate(n_res)])
+        self.down = nn.ModuleList([nn.Sequential(_SparseConv(dims[i - 1], dims[i]),
+                                                 MinkowskiGroupNorm(n_groups[i], dims[i]))
+                                   for i in range(1, len(dims))])
+        rn, rd, rg = n_res[::-1], dims[::-1], n_groups[::-1]
+        self.res_up = nn.ModuleList([nn.Sequential(*[SparseResidual3d(rd[i + 1], "gn", rg[i + 1])
+                                                     for _ in range(n)]) for i, n in enumerate(rn[1:])])
+        self.up = nn.ModuleList([nn.Sequential(_SparseConv(rd[i - 1], rd[i]), MinkowskiGroupNorm(rg[i], rd[i]))
+                                 for i in range(1, len(rd))])
+        self.feat_adj = nn.ModuleList([nn.Sequential(_SparseConv(2 * rd[i], rd[i], kernel_size=1),
+                                                     MinkowskiGroupNorm(rg[i], rd[i]))
+                                       for i in range(1, len(rd))])
+        self._cache = _PackCache(self)
+
+    # -- weight packing ---------------------------------------------------------------------------
+    @staticmethod
+    def _pack3(conv, norm):
+        _, ci, co = conv.kernel.shape
+        return PackedGemm(conv.kernel, ci * co, 1, co, 27, co, ci, gn_w=norm.gn.weight, gn_b=norm.gn.bias)
+
+    def _build(self):
+        g = {}
+        for name, lst in (('res_down', self.res_down), ('res_up', self.res_up)):
+            for i, seq in enumerate(lst):
+                for l, blk in enumerate(seq):
+                    g[(name, i, l)] = (self._pack3(blk.conv1, blk.n1), self._pack3(blk.conv2, blk.n2))
+        for i, seq in enumerate(self.down):
+            g[('down', i)] = self._pack3(seq[0], seq[1])
+        for i, seq in enumerate(self.up):
+            g[('up', i)] = self._pack3(seq[0], seq[1])
+        for i, seq in enumerate(self.feat_adj):
+            c2, co = seq[0].kernel.shape
+            g[('feat_adj', i)] = PackedGemm(seq[0].kernel, (c2 // 2) * co, 1, co, 2, co, c2 // 2,
+                                            gn_w=seq[1].gn.weight, gn_b=seq[1].gn.bias)
+        return g
+
+    # -- execution ----------------------------------------------------------------------------------
+    @staticmethod
+    def _conv(pack, x, nbr, n_out, eps, residual=None):
+        idxs = [nbr.data_ptr() + 4 * k * n_out for k in range(27)]      # column k of the neighbour table
+        return pack(n_out, [x] * 27, idxs=idxs, use_gn=True, gn_eps=eps, residual=residual, relu_out=True)
+
+    def _residual(self, packs, blk, x, nbr):
+        n = x.shape[0]
+        y = self._conv(packs[0], x, nbr, n, blk.n1.gn.eps)
+        return self._conv(packs[1], y, nbr, n, blk.n2.gn.eps, residual=x)
+
+    def forward(self, F, pts, idx, batch, res):
+        if not F.is_cuda:
+            raise _lib.V3DLibraryError('SparseUNet: tensors must live on a HIP device (no CPU fallback)')
+        g = self._cache.get(self._build)
+        coords = torch.cat((batch.unsqueeze(1), idx), dim=1).int().contiguous()       # [N,4] (b,x,y,z)
+        # coordinate maps: stride-2 conv output = unique(floor(c / 2ts) * 2ts), lexicographic order
+        levels = [SparseLevel(coords, 1)]
+        for i in range(1, len(self.dims)):
+            ts = levels[-1].stride
+            c = levels[-1].coords.clone()
+            c[:, 1:] = torch.div(c[:, 1:], 2 * ts, rounding_mode='floor') * (2 * ts)
+            levels.append(SparseLevel(torch.unique(c, dim=0).int(), 2 * ts))
+        same = [lv.neighbors(lv.coords, lv.stride) for lv in levels]                    # stride-1 maps
+        x = F.contiguous().float()
+        xs = []
+        for i in range(len(self.dims)):
+            if i > 0:
+                nbr = levels[i - 1].neighbors(levels[i].coords, levels[i - 1].stride)   # stride-2 conv
+                x = self._conv(g[('down', i - 1)], x, nbr, levels[i].n, self.down[i - 1][1].gn.eps)
+            for l, blk in enumerate(self.res_down[i]):
+                x = self._residual(g[('res_down', i, l)], blk, x, same[i])
+            xs.append(x)
+        lv_rev, xs_rev, same_rev = levels[::-1], xs[::-1], same[::-1]
+        out = [(lv_rev[0], xs_rev[0])]
+        x = xs_rev[0]
+        for i in range(len(self.dims) - 1):
+            tgt = lv_rev[i + 1]
+            nbr = lv_rev[i].neighbors(tgt.coords, -tgt.stride)                          # transposed conv
+            u = self._conv(g[('up', i)], x, nbr, tgt.n, self.up[i][1].gn.eps)
+            x = g[('feat_adj', i)](tgt.n, [u, xs_rev[i + 1]], use_gn=True,
+                                   gn_eps=self.feat_adj[i][1].gn.eps, relu_out=True)   # 1x1 on ME.cat
+            for l, blk in enumerate(self.res_up[i]):
+                x = self._residual(g[('res_up', i, l)], blk, x, same_rev[i + 1])
+            out.append((tgt, x))
+
+        out_info = []
+        n_batches = int(torch.max(batch).item()) + 1                                   # scenemodeling.py:221
+        for lv, xf in out:
+            x_idx = lv.coords[:, 1:].type_as(batch)
+            x_batch = lv.coords[:, 0].type_as(batch)
+            x_pts = torch.empty((lv.n, 3), dtype=torch.float, device=pts.device)
+            for b in range(n_batches):
+                bin_, bout = batch == b, x_batch == b
+                pts_min = pts[bin_][0] - (idx[bin_][0] * res)
+                x_pts[bout] = x_idx[bout] * res + pts_min
+            lv.feats = xf
+            out_info.append({'feats': xf, 'pts': x_pts, 'res': lv.stride * res, 'batch': x_batch,
+                             'idx': x_idx, 'stride': lv.stride, 'sparse': lv})
+        return out_info

@@ -107,6 +107,78 @@ int v3d_costreg_depth_f32(const v3d_costreg_weights* handle, const float* var,
 int v3d_costreg_layer_f32(const v3d_costreg_weights* handle, int layer, const float* in,
                           const float* skip, int n, int Di, int Hi, int Wi, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Rows B1-B2 and C1: back-project depth pixels / depth hypotheses to world points and compute their
+ * multi-view variance feature.  Replaces mv3d/utils.py:67-83 (build_img_pts),
+ * mv3d/lightningmodel.py:138-169 (construct_feature_rich_pointcloud) and :191-229 (run_pointflow).
+ *   depth [n_ref, h, w]; feat [n_img, C, Hf, Wf]; cameras / edge CSR as in v3d_psv_variance_f32;
+ *   hypotheses depth + i*offset, i in [-n_half, n_half] (n_half = 0: the depth itself);
+ *   pts [n_ref*h*w, 2*n_half+1, 3] out, var [n_ref*h*w, 2*n_half+1, C] out (= pts_hyp / pts_feat of
+ *   lightningmodel.py:231-235; for n_half = 0: pts / pts_feat of :171-172).
+ * ------------------------------------------------------------------------------------------ */
+size_t v3d_backproject_workspace_bytes(int n_img, int C, int Hf, int Wf);
+int v3d_backproject_variance_f32(const float* depth, const float* feat, const float* K, const float* R,
+                                 const float* t, const int32_t* ref_img, const int32_t* edge_ofs,
+                                 const int32_t* edge_src, int n_img, int n_ref, int n_edges, int C,
+                                 int Hf, int Wf, int H, int W, int h, int w, double offset, int n_half,
+                                 float* pts, float* var, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather-GEMM on fp32 MFMA: Y[m,:] = epilogue(sum_s act(X_s[row_s(m), 0:K]) @ W_s + bias).
+ * Replaces the dense arithmetic of: PointNet's Linear layers incl. the concat with the pooled voxel
+ * feature and torch_scatter max (mv3d/subnetworks/scenemodeling.py:127-144); MinkowskiConvolution /
+ * ConvolutionTranspose / 1x1 + MinkowskiGroupNorm + ReLU + residual (scenemodeling.py:16-44,160,181,
+ * 186); Conv1d+BN+ReLU of the hypothesis decoder (mv3d/subnetworks/refinement.py:8-13,20-23).
+ *
+ * v3d_gemm_pack: HOST weight tensor addressed as w[seg*stride_seg + co*stride_co + k*stride_k]
+ *   (Linear [N, n_seg*K]: K, n_seg*K, 1;  ME kernel [27, Ci, Co]: Ci*Co, 1, Co;  Conv1d [Co, Ci, 3]:
+ *   1, 3*Ci, 3), optional per-output scale (folded BatchNorm), bias, GroupNorm affine.  N <= 128.
+ * v3d_gemm_gather_f32: seg_src/seg_idx/seg_ld are HOST arrays of n_seg device pointers / strides;
+ *   seg_idx[s] NULL = identity row map, entry -1 = zero row; group_len > 0 selects the conv1d row map
+ *   (segment s reads row m + s - n_seg/2 inside each group of group_len rows; seg_idx ignored);
+ *   relu_in: ReLU applied to gathered inputs; use_gn: per-row GroupNorm over 16-channel groups
+ *   (eps gn_eps) before the optional residual add and ReLU; pool/pool_idx: scatter-max of the result
+ *   into pool[pool_idx[m], :] (pre-filled with -inf); out may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct v3d_gemm_weights v3d_gemm_weights;
+int v3d_gemm_pack(const float* w_host, long long stride_seg, long long stride_co, long long stride_k,
+                  int n_seg, int N, int K, const float* scale_host, const float* bias_host,
+                  const float* gn_w_host, const float* gn_b_host, v3d_gemm_weights** out_handle);
+void v3d_gemm_free(v3d_gemm_weights* handle);
+int v3d_gemm_gather_f32(const v3d_gemm_weights* handle, int M, const float* const* seg_src_host,
+                        const int32_t* const* seg_idx_host, const int* seg_ld_host, int group_len,
+                        int relu_in, int use_gn, float gn_eps, const float* residual, int ld_res,
+                        int relu_out, float* pool, const int32_t* pool_idx, int ld_pool, float* out,
+                        int ld_out, void* stream);
+int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse-tensor structure (replaces MinkowskiEngine's coordinate manager; semantics: SURVEY.md
+ * Appendix A).  coords are int32 [N,4] = (batch, x, y, z), unique rows.
+ *   v3d_hash_build        open-addressing table over the coordinate map (buffer >= v3d_hash_bytes(n))
+ *   v3d_sparse_neighbors  nbr[k][p] = row of out_coords[p] + step*o_k (or -1), k = (ox+1)+3(oy+1)+9(oz+1);
+ *                         conv: step = +tensor_stride_in, transposed conv: step = -tensor_stride_out
+ *   v3d_sparse_interp_f32 MinkowskiInterpolation (refinement.py:26,39): trilinear interpolation of
+ *                         feats [N,C] at pts [n_pts, n_hyp, 3] (world), query coordinate
+ *                         ((p - min_pts[batch]) / res) * tensor_stride, missing corners add 0; result
+ *                         written to out[q*ld_out + col0 .. +C).
+ * ------------------------------------------------------------------------------------------ */
+size_t v3d_hash_bytes(int n);
+int v3d_hash_build(const int32_t* coords, int n, void* table, size_t table_bytes, void* stream);
+int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* out_coords, int n_out, int step,
+                         int32_t* nbr, void* stream);
+int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C, int tensor_stride,
+                          const float* pts, const int64_t* pts_batch, int n_pts, int n_hyp,
+                          const float* min_pts, float res, float* out, int ld_out, int col0, void* stream);
+
+/* Row C2b tail + C3: last Conv1d(C -> 1, k3, pad 1, bias) over the hypothesis axis, softmax
+ * (refinement.py:24,43) and optional expectation sum_i p_i*offset_vals_i (lightningmodel.py:238-241).
+ * act [n_pts, n_hyp, C]; weight [1, C, 3]; preds [n_pts, n_hyp]; expect [n_pts] or NULL. */
+int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int C, const float* weight,
+                         const float* bias, const float* offset_vals, float* preds, float* expect,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

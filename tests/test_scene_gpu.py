@@ -1,0 +1,213 @@
+"""GPU parity tests, rows B1-B6 and C1-C3: the HIP path (through the C ABI) against golden vectors
+captured from the reference and against the oracle on the same seeded inputs.
+
+Tolerances (fp32 path): world points 2e-5 m; per-point variance 5e-5 abs (same argument as the cost
+volume); integer outputs of voxelisation exact; PointNet / sparse U-Net features 2e-4 * max|ref|
+(22 stacked fp32 GEMM + GroupNorm layers); decoder probabilities 2e-4 abs; depth offsets 2e-5 m
+(=> final depth well inside the 1e-4 relative gate of BASELINE.json).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import v3d
+from helpers import load_golden, t, weights_checksum
+from oracle import scene as osc
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, atol=None, rel=None):
+    a, b = np.asarray(a), np.asarray(b)
+    if rel is not None:
+        atol = rel * max(float(np.abs(b).max()), 1e-12)
+    np.testing.assert_allclose(a, b, rtol=0, atol=atol)
+
+
+def _scene(cuda):
+    g = load_golden('B_pointcloud')
+    img_size = tuple(int(v) for v in g['img_size'])
+    d = {k: t(g[k]).to(cuda) for k in ('depth', 'depth_batch', 'feat', 'rotmats', 'tvecs', 'K', 'edges')}
+    return g, img_size, d
+
+
+def _net(cuda, img_size, dec_in=352, dec_seed=3, sharpen=50.0):
+    syn, lm = v3d('synthetic'), v3d('lightningmodel')
+    net = lm.PL3DVNet(None, {'size': (12, 14)}, 0.16, feat_dim=32, img_size=img_size).eval()
+    sd = dict(pn=syn.pointnet_weights(seed=1), un=syn.sparse_unet_weights(seed=2),
+              dec=syn.decoder_weights(in_dim=dec_in, h_dim=128, seed=dec_seed, sharpen=sharpen))
+    if dec_in != 352:
+        net.decoder = v3d('refinement').HypothesisDecoder(dec_in, 128, 3, 1).eval()
+    net.pointnet.load_state_dict(sd['pn'])
+    net.sparse_conv.load_state_dict(sd['un'])
+    net.decoder.load_state_dict(sd['dec'], strict=False)
+    return net.to(cuda), sd
+
+
+def test_backproject_pointcloud_B2(cuda):
+    g, img_size, d = _scene(cuda)
+    net, _ = _net(cuda, img_size)
+    pts, feat, batch = net.construct_feature_rich_pointcloud(d['depth'], d['depth_batch'], d['feat'],
+                                                              d['rotmats'], d['tvecs'], d['K'], d['edges'])
+    _close(pts.cpu(), g['pts'], atol=2e-5)
+    _close(feat.cpu(), g['pts_feat'], atol=5e-5)
+    assert np.array_equal(batch.cpu().numpy(), g['pts_batch'])
+
+
+def test_backproject_hypotheses_C1(cuda):
+    g, img_size, d = _scene(cuda)
+    c = load_golden('C_pointflow')
+    lm = v3d('lightningmodel')
+    pts, var = lm.backproject_variance(d['depth'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'],
+                                       img_size, offset=float(c['offset']), n=int(c['n']))
+    _close(pts.cpu(), c['pts_hyp'], atol=2e-5)
+    _close(var.cpu(), c['pts_feat'], atol=5e-5)
+
+
+def test_voxelize_B3_on_device(cuda):
+    g = load_golden('B_voxelize')
+    a_pts, a_idx, a_batch, a_edges = v3d('utils').voxelize(t(g['pts']).to(cuda), t(g['pts_batch']).to(cuda),
+                                                           float(g['edge_len']))
+    assert np.array_equal(a_idx.cpu().numpy(), g['anchor_idx3d'])
+    assert np.array_equal(a_batch.cpu().numpy(), g['anchor_batch'])
+    assert np.array_equal(a_edges.cpu().numpy(), g['anchor_pts_edges'])
+    _close(a_pts.cpu(), g['anchor_pts'], atol=1e-6)
+
+
+def test_pointnet_B4(cuda):
+    g = load_golden('B_pointnet')
+    syn, sm = v3d('synthetic'), v3d('scenemodeling')
+    sd = syn.pointnet_weights(seed=int(g['weights_seed']))
+    assert abs(weights_checksum(sd) - float(g['weights_checksum'])) < 1e-6
+    pn = sm.PointNet(128, 64, 35).eval()
+    pn.load_state_dict(sd)
+    out = pn.to(cuda)(t(g['x_in']).to(cuda), t(g['idx']).to(cuda), int(g['n_idx']))
+    _close(out.cpu(), g['out'], rel=2e-4)
+
+
+def test_gather_gemm_unit(cuda):
+    """Segments with -1 rows, identity + gathered sources, ReLU-in, GroupNorm, residual, scatter-max."""
+    sm, libm = v3d('scenemodeling'), v3d('_lib')
+    gen = torch.Generator().manual_seed(0)
+    M, K, N, R = 333, 48, 64, 200
+    x0 = torch.randn((M, K), generator=gen)
+    x1 = torch.randn((R, K), generator=gen)
+    idx = torch.randint(-1, R, (M,), generator=gen).int()
+    W = torch.randn((N, 2 * K), generator=gen) * 0.2
+    bias, gw, gb = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    res = torch.randn((M, N), generator=gen)
+    pidx = torch.randint(0, 17, (M,), generator=gen).int()
+    gathered = torch.where((idx >= 0).unsqueeze(1), x1[idx.clamp(min=0).long()], torch.zeros(M, K))
+    y = torch.relu(torch.cat((x0, gathered), 1)) @ W.t() + bias
+    y = torch.nn.functional.group_norm(y, N // 16, gw, gb, 1e-5) + res
+    y = torch.relu(y)
+    pool_ref = torch.full((17, N), float('-inf')).scatter_reduce_(0, pidx.long().view(-1, 1).expand(-1, N), y, 'amax')
+    pk = sm.PackedGemm(W, K, 2 * K, 1, 2, N, K, bias=bias, gn_w=gw, gn_b=gb)
+    pool = torch.full((17, N), float('-inf'), device=cuda)
+    out = pk(M, [x0.to(cuda), x1.to(cuda)], idxs=[None, idx.to(cuda)], relu_in=True, use_gn=True,
+             residual=res.to(cuda), relu_out=True, pool=pool, pool_idx=pidx.to(cuda))
+    _close(out.cpu(), y, rel=1e-5)
+    _close(pool.cpu(), pool_ref, rel=1e-5)
+    # conv1d row map (groups of 7) with an output width that is not a multiple of 16
+    Wc = torch.randn((20, K, 3), generator=gen) * 0.2
+    xin = torch.randn((35, K), generator=gen)
+    yref = torch.nn.functional.conv1d(xin.view(5, 7, K).transpose(2, 1), Wc, None, 1, 1).transpose(2, 1).reshape(35, 20)
+    pk2 = sm.PackedGemm(Wc, 1, 3 * K, 3, 3, 20, K)
+    xg = xin.to(cuda)
+    _close(pk2(35, [xg, xg, xg], group_len=7).cpu(), yref, rel=1e-5)
+    with pytest.raises(libm.V3DLibraryError):
+        pk(M, [x0, x1])                      # CPU tensors: no fallback
+
+
+def _unet_inputs(cuda):
+    g = load_golden('C_forloop')
+    return g, dict(F=t(g['x_pointnet']).to(cuda), pts=t(g['anchor_pts']).to(cuda),
+                   idx=t(g['anchor_idx3d']).to(cuda), batch=t(g['anchor_batch']).to(cuda))
+
+
+def test_neighbor_tables_match_oracle_lookup(cuda):
+    g, u = _unet_inputs(cuda)
+    sm = v3d('scenemodeling')
+    coords = torch.cat((u['batch'].unsqueeze(1), u['idx']), 1).int()
+    lv = sm.SparseLevel(coords, 1)
+    nbr = lv.neighbors(coords, 1).cpu()
+    cc = coords.cpu().long()
+    for k, o in enumerate(osc.kernel_offsets()):
+        q = cc.clone()
+        q[:, 1:] += o
+        assert torch.equal(nbr[k].long(), osc._lookup(cc, q)), 'offset %d' % k
+    assert (nbr[13] == torch.arange(coords.shape[0])).all()       # centre offset maps to itself
+
+
+def test_sparse_unet_B6_matches_oracle(cuda):
+    g, u = _unet_inputs(cuda)
+    syn, sm = v3d('synthetic'), v3d('scenemodeling')
+    sd = syn.sparse_unet_weights(seed=int(g['unet_seed']))
+    net = sm.SparseUNet().eval()
+    net.load_state_dict(sd)
+    xs = net.to(cuda)(u['F'], u['pts'], u['idx'], u['batch'], float(g['edge_len']))
+    ref = osc.sparse_unet(t(g['x_pointnet']), t(g['anchor_pts']), t(g['anchor_idx3d']), t(g['anchor_batch']),
+                          float(g['edge_len']), sd)
+    assert [x['stride'] for x in xs] == [4, 2, 1]
+    for x, r in zip(xs, ref):
+        assert torch.equal(x['sparse'].coords.cpu().long(), r['coords'])     # same coordinate order
+        assert torch.equal(x['idx'].cpu(), r['idx']) and torch.equal(x['batch'].cpu(), r['batch'])
+        _close(x['pts'].cpu(), r['pts'], atol=1e-5)
+        assert x['res'] == pytest.approx(r['res'])
+        _close(x['feats'].cpu(), r['feats'], rel=2e-4)
+
+
+def test_decoder_net_C2b(cuda):
+    g = load_golden('C_decoder_net')
+    syn, rf = v3d('synthetic'), v3d('refinement')
+    dec = rf.HypothesisDecoder(352, 128, 3, 1).eval()
+    dec.load_state_dict(syn.decoder_weights(in_dim=352, h_dim=128, seed=int(g['weights_seed']),
+                                            sharpen=float(g['sharpen'])), strict=False)
+    preds = dec.to(cuda).decode(t(g['features']).to(cuda))
+    _close(preds.cpu(), g['preds'], atol=2e-4)
+    assert g['preds'].max() > 0.5
+
+
+def test_interpolation_and_decoder_against_reference_forloop(cuda):
+    """Sparse U-Net -> trilinear interpolation -> decoder, against the reference's dense formulation."""
+    g, u = _unet_inputs(cuda)
+    syn, sm, rf = v3d('synthetic'), v3d('scenemodeling'), v3d('refinement')
+    net = sm.SparseUNet().eval()
+    net.load_state_dict(syn.sparse_unet_weights(seed=int(g['unet_seed'])))
+    xs = net.to(cuda)(u['F'], u['pts'], u['idx'], u['batch'], float(g['edge_len']))
+    dec = rf.HypothesisDecoder(320, 128, 3, 1).eval()
+    dec.load_state_dict(syn.decoder_weights(in_dim=320, h_dim=128, seed=int(g['dec_seed']),
+                                            sharpen=float(g['sharpen'])), strict=False)
+    preds = dec.to(cuda)(xs, t(g['pts_hyp']).to(cuda), None, t(g['pts_batch']).to(cuda))
+    _close(preds.cpu(), g['preds'], atol=2e-4)
+
+
+def test_model_scene_and_pointflow_end_to_end(cuda):
+    """Rows B5 + C1-C3 chained exactly like mv3d/eval-3dvnet.py:73-99 on the tiny two-batch scene, vs the
+    oracle; also chunk invariance (two chunks of reference views == one call)."""
+    g, img_size, d = _scene(cuda)
+    net, sd = _net(cuda, img_size)
+    cpu = {k: v.cpu() for k, v in d.items()}
+    xs_o, pts_o = osc.model_scene(cpu['depth'], cpu['depth_batch'], cpu['feat'], cpu['rotmats'], cpu['tvecs'],
+                                  cpu['K'], cpu['edges'], 0.16, sd['pn'], sd['un'], img_size)
+    off_o = osc.run_pointflow(xs_o, cpu['depth'], cpu['depth_batch'], cpu['feat'], cpu['rotmats'], cpu['tvecs'],
+                              cpu['K'], cpu['edges'], 0.05, 3, sd['dec'], img_size)
+    with torch.no_grad():
+        xs, pts = net.model_scene(d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'],
+                                  d['edges'], return_pts=True)
+        off = net.run_pointflow(xs, d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'],
+                                d['edges'], 0.05, 3)
+        _close(pts.cpu(), pts_o, atol=2e-5)
+        for x, r in zip(xs, xs_o):
+            _close(x['feats'].cpu(), r['feats'], rel=2e-4)
+        _close(off.cpu(), off_o, atol=2e-5)
+        assert float(off_o.abs().max()) > 0.01           # peaked decoder => non-trivial offsets
+        # chunked like the reference driver: refs [0,2) and [2,4) with their +-1 image halo
+        ut = v3d('utils')
+        parts = []
+        for r0, r1 in ((0, 2), (2, 4)):
+            e = ut.slice_edges(d['edges'], r0 + 1, r1 + 1, 0) - r0
+            parts.append(net.run_pointflow(xs, d['depth'][r0:r1], d['depth_batch'][r0:r1], d['feat'][r0:r1 + 2],
+                                           d['rotmats'][r0:r1 + 2], d['tvecs'][r0:r1 + 2], d['K'][r0:r1 + 2],
+                                           e, 0.05, 3))
+        assert torch.equal(torch.cat(parts), off)
