@@ -28,7 +28,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxSeg = 27;
-constexpr int kTM = 128;     // rows per workgroup
 constexpr int kKC = 32;      // K chunk
 constexpr int kXS = kKC + 2; // LDS row stride of the activation tile
 
@@ -58,8 +57,13 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-template <int MBW>   // channel blocks (16 outputs) per wave: N = 64 * MBW (or N <= 16 * 4 * MBW)
+// MBW: channel blocks (16 outputs) per wave (N <= 64 * MBW); NB: 16-row blocks per workgroup tile
+// (tile = 16 * NB rows: 128 for large problems, 32 when M is small so that more workgroups than CUs
+// exist and gather latency is hidden by occupancy).
+template <int MBW, int NB>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
+  constexpr int kTM = 16 * NB;
+  constexpr int NPASS = (kTM + 31) / 32;      // staging passes of 32 rows
   __shared__ float xs[kTM * kXS];
   __shared__ float ws[4 * MBW * 16 * kKC];
   __shared__ int s_any;
@@ -70,13 +74,13 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   const int m0 = blockIdx.x * kTM;
   const int MB = 4 * MBW;
 
-  f32x4 acc[8][MBW];
+  f32x4 acc[NB][MBW];
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int m = 0; m < MBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // staging role: 8 lanes x float4 cover the 32 columns of one row; 32 rows per pass, 4 passes
+  // staging role: 8 lanes x float4 cover the 32 columns of one row; 32 rows per pass
   const int srow = tid >> 3, sc4 = (tid & 7) * 4;
   const int nkc = p.KP / kKC;
   const int wslab = MB * 16 * kKC;                 // packed floats per (segment, K chunk)
@@ -84,13 +88,13 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   for (int s = 0; s < p.n_seg; ++s) {
     const Seg sg = p.seg[s];
     // source row of each of this thread's 4 staging rows (-1 = zero row)
-    int rsrc[4];
+    int rsrc[NPASS];
     bool any = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPASS; ++i) {
       const int m = m0 + srow + 32 * i;
       int r = -1;
-      if (m < p.M) {
+      if (m < p.M && srow + 32 * i < kTM) {
         if (p.group_len > 0) {
           const int h = m % p.group_len + s - p.n_seg / 2;
           r = (h >= 0 && h < p.group_len) ? m + s - p.n_seg / 2 : -1;
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
       __syncthreads();
       // ---- stage activations (gathered rows, optional ReLU) --------------------------------------
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NPASS; ++i) {
+        if (srow + 32 * i >= kTM) break;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int col = kc * kKC + sc4;
         if (rsrc[i] >= 0 && col < p.K) {
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
 #pragma unroll
         for (int m = 0; m < MBW; ++m) a[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           const float bv = xs[(nb * 16 + jn) * kXS + k4 * 4 + kq];
 #pragma unroll
           for (int m = 0; m < MBW; ++m)
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
 
   // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     const int m = m0 + nb * 16 + jn;
 #pragma unroll
     for (int mw = 0; mw < MBW; ++mw) {
@@ -302,11 +307,18 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   p.pool = pool; p.pool_idx = pool_idx; p.ld_pool = ld_pool;
   p.out = out; p.ld_out = ld_out;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned blocks = (unsigned)((M + kTM - 1) / kTM);
+  const bool small = M < 128 * 1024;           // fewer than ~4 tiles of 128 rows per CU: use 32-row tiles
+  const int tm = small ? 32 : 128;
+  const unsigned blocks = (unsigned)((M + tm - 1) / tm);
   {
     v3d::TimedScope ts(h->n_seg == 27 ? "sparse_conv_gemm" : h->n_seg == 3 ? "conv1d_gemm" : "linear_gemm", s);
-    if (h->MBW == 2) gemm_gather_kernel<2><<<blocks, 256, 0, s>>>(p);
-    else gemm_gather_kernel<1><<<blocks, 256, 0, s>>>(p);
+    if (h->MBW == 2) {
+      if (small) gemm_gather_kernel<2, 2><<<blocks, 256, 0, s>>>(p);
+      else gemm_gather_kernel<2, 8><<<blocks, 256, 0, s>>>(p);
+    } else {
+      if (small) gemm_gather_kernel<1, 2><<<blocks, 256, 0, s>>>(p);
+      else gemm_gather_kernel<1, 8><<<blocks, 256, 0, s>>>(p);
+    }
   }
   V3D_CHECK_LAUNCH("gemm_gather_kernel");
   return V3D_OK;

@@ -1,0 +1,113 @@
+"""Per-scene inference driver: counterpart of ``mv3d/eval-3dvnet.py::process_scene`` (:26-129), SURVEY.md
+§8a row H2, with the multi-GPU partitioning of §8e added.
+
+Single process: identical control flow to the reference -- chunked initial depth with a +-k image
+halo (:41-63), ``len(offsets_list)`` outer iterations of ``model_scene`` followed by chunked
+``run_pointflow`` sweeps with in-place ``+=`` (:73-99).  (Stage 3, the PropagationNet upsampling
+:101-125, is a "next" row -- stock 2D convolutions -- and is not part of this driver yet.)
+
+Multi-GPU (one process per GPU, ``torch.distributed``): reference views are independent units for
+the cost volume and the point-flow sweeps, so rank g owns a contiguous block of reference views and
+the images within its halo; no data-path collective there.  The scene model needs every view's
+points: each rank back-projects its own views and the feature-rich point cloud is all-gathered in
+view order (bit-identical to the single-process tensor), after which voxelise / PointNet / sparse
+U-Net run replicated on every rank.
+"""
+import torch
+
+from .batch import Batch
+from . import utils
+
+INIT_DEPTH_BATCH = 18      # eval-3dvnet.py:12-14
+OFFSET_BATCH = 16
+DEPTH_CONFIG = {'depth_start': 0.5, 'depth_interval': 0.05, 'n_intervals': 96, 'size': (56, 56)}
+OFFSETS_LIST = [[0.05, 0.05, 0.025], [0.05, 0.05, 0.025]]
+
+
+def shard_range(n, rank, world):
+    """Contiguous block partition of n reference views: [start, end) of `rank`."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(x, group=None):
+    """All-gather tensors that differ in dim 0, concatenated in rank order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([x.shape[0]], dtype=torch.long, device=x.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    pad = torch.zeros((max(sizes),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[:x.shape[0]] = x
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def gather_pointcloud(pts, pts_feat, pts_batch, group=None):
+    """The one exchange step of the path: [pts | feat] in one message + batch ids."""
+    packed = all_gather_rows(torch.cat((pts, pts_feat), dim=1), group)
+    return packed[:, :3].contiguous(), packed[:, 3:].contiguous(), all_gather_rows(pts_batch, group)
+
+
+def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, offsets_list=None,
+                  init_depth_batch=INIT_DEPTH_BATCH, offset_batch=OFFSET_BATCH, rank=0, world=1,
+                  group=None, gather_depth=True):
+    """Returns the refined depth maps [n_ref, h, w] (all views when gather_depth, else this rank's).
+
+    ``batch``: images (or precomputed ``features_quarter``), rotmats, tvecs, K, ref_src_edges for the
+    whole scene with the reference's edge convention (dsets/dataset.py:133-137)."""
+    depth_config = depth_config or DEPTH_CONFIG
+    offsets_list = offsets_list or OFFSETS_LIST
+    k = n_src_on_either_side
+    with torch.no_grad():
+        ref_idx = torch.unique(batch.ref_src_edges[0])
+        n_ref_imgs = len(ref_idx)
+        r0, r1 = shard_range(n_ref_imgs, rank, world)
+        n_local = r1 - r0
+        has_feats = getattr(batch, 'features_quarter', None) is not None
+        all_depth = torch.empty((n_local, *depth_config['size']), dtype=torch.float32, device=device)
+        feats_local = None          # quarter features of images [r0, r1 + 2k)
+
+        # ---- stage 1: initial depth, chunks of init_depth_batch reference views (:41-63) ----------
+        for c0 in range(r0, r1, init_depth_batch):
+            c1 = min(c0 + init_depth_batch, r1)
+            ref_idx_start, ref_idx_end = c0 + k, c1 + k
+            idx_start, idx_end = c0, c1 + 2 * k
+            edges = utils.slice_edges(batch.ref_src_edges, ref_idx_start, ref_idx_end, 0) - idx_start
+            sl = Batch(None if batch.images is None else batch.images[idx_start:idx_end],
+                       batch.rotmats[idx_start:idx_end], batch.tvecs[idx_start:idx_end],
+                       batch.K[idx_start:idx_end], None, edges)
+            sl.images_batch = torch.zeros(idx_end - idx_start, dtype=torch.long)
+            if has_feats:
+                sl.features_quarter = batch.features_quarter[idx_start:idx_end]
+            sl.to(device)
+            pred, _, _, feats_quarter, _, _ = net.make_initial_depth_predictions(sl, depth_config)
+            all_depth[c0 - r0:c1 - r0] = pred
+            if feats_local is None:
+                feats_local = torch.empty((n_local + 2 * k,) + tuple(feats_quarter.shape[1:]),
+                                          dtype=torch.float32, device=device)
+            feats_local[idx_start - r0:idx_end - r0] = feats_quarter
+
+        # ---- stage 2: volumetric refinement (:65-99) ------------------------------------------------
+        rot = batch.rotmats[r0:r1 + 2 * k].to(device)
+        tv = batch.tvecs[r0:r1 + 2 * k].to(device)
+        K = batch.K[r0:r1 + 2 * k].to(device)
+        edges_local = (utils.slice_edges(batch.ref_src_edges, r0 + k, r1 + k, 0) - r0).to(device)
+        depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
+        gather_fn = (lambda p, f, b: gather_pointcloud(p, f, b, group)) if world > 1 else None
+        for offsets in offsets_list:
+            xs = net.model_scene(all_depth, depth_batch, feats_local, rot, tv, K, edges_local,
+                                 gather_fn=gather_fn)
+            for offset in offsets:
+                for b0 in range(0, n_local, offset_batch):
+                    b1 = min(b0 + offset_batch, n_local)
+                    e = utils.slice_edges(edges_local, b0 + k, b1 + k, 0) - b0
+                    all_depth[b0:b1] += net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
+                                                          feats_local[b0:b1 + 2 * k], rot[b0:b1 + 2 * k],
+                                                          tv[b0:b1 + 2 * k], K[b0:b1 + 2 * k], e, offset, 3)
+        if world > 1 and gather_depth:
+            all_depth = all_gather_rows(all_depth, group)
+        return all_depth

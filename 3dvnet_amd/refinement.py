@@ -59,9 +59,13 @@ class HypothesisDecoder(nn.Module):
         for x in xs:                                   # coarse -> fine, each level prepended (:41)
             lv = x['sparse']
             col -= x['feats'].shape[1]
-            nb = int(x['batch'].max().item()) + 1
-            min_pts = torch.zeros((nb, 3), dtype=torch.float32, device=dev).scatter_reduce_(
-                0, x['batch'].view(-1, 1).expand(-1, 3), x['pts'], 'amin', include_self=False)   # :33
+            if '_min_pts' not in x:
+                # scatter(x.pts, x.batch, reduce='min') (:33) as one reduction per batch element; cached
+                # on the level dict (the levels are reused by every point-flow sweep of the scene)
+                nb = int(x['batch'].max().item()) + 1
+                x['_min_pts'] = torch.stack([x['pts'][x['batch'] == b].amin(dim=0) for b in range(nb)]) \
+                    if nb > 1 else x['pts'].amin(dim=0, keepdim=True)
+            min_pts = x['_min_pts'].contiguous()
             f = x['feats'].contiguous()
             rc = lib.v3d_sparse_interp_f32(lv.table.data_ptr(), lv.n, f.data_ptr(), f.shape[1],
                                            int(x['stride']), pts.data_ptr(), pts_batch.data_ptr(), n_pts,

@@ -44,13 +44,18 @@ def voxelize(pts, pts_batch, edge_len):
     voxel_idx = _voxel_grid(pts, pts_batch, edge_len, bbox_min, bbox_max)
     anchor_idx, inv_idx = torch.unique(voxel_idx, return_inverse=True)
     anchor_pts_edges = torch.stack((inv_idx, torch.arange(pts.shape[0], dtype=torch.long, device=pts.device)), dim=0)
-    anchor_batch = _scatter_min(pts_batch, anchor_pts_edges[0], anchor_idx.shape[0])
+    # scatter(pts_batch, inv, reduce='min') (:50): the voxel id encodes the batch, so every point of a
+    # voxel carries the same batch id and a plain (non-atomic) scatter gives the same result
+    anchor_batch = torch.empty(anchor_idx.shape[0], dtype=pts_batch.dtype, device=pts.device)
+    anchor_batch.scatter_(0, inv_idx, pts_batch)
     anchor_idx = anchor_idx - anchor_batch * max_grid_idx
     anchor_idx3d = torch.zeros((anchor_idx.shape[0], 3), dtype=torch.int, device=pts.device)
     anchor_idx3d[:, 2] = anchor_idx // (grid_size[0] * grid_size[1])
     anchor_idx3d[:, 1] = (anchor_idx - anchor_idx3d[:, 2] * (grid_size[0] * grid_size[1])) // (grid_size[0])
     anchor_idx3d[:, 0] = (anchor_idx - anchor_idx3d[:, 2] * (grid_size[0] * grid_size[1])) % (grid_size[0])
     anchor_pts = anchor_idx3d * edge_len + bbox_min + edge_len / 2.
-    min_idx3d = _scatter_min(anchor_idx3d, anchor_batch, int(anchor_batch.max().item()) + 1)
+    n_batches = int(anchor_batch.max().item()) + 1
+    min_idx3d = torch.stack([anchor_idx3d[anchor_batch == b].amin(dim=0) for b in range(n_batches)]) \
+        if n_batches > 1 else anchor_idx3d.amin(dim=0, keepdim=True)              # scatter-min (:61)
     anchor_idx3d = anchor_idx3d - min_idx3d[anchor_batch]
     return anchor_pts, anchor_idx3d, anchor_batch, anchor_pts_edges
