@@ -528,9 +528,9 @@ typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
 typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
 typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
 typedef ConvCfg<kConvS1, 32, 32, 4, 7, 14, 8> L4;
-typedef ConvCfg<kConvS2, 32, 64, 2, 7, 7, 8> L5;
-typedef ConvCfg<kConvS1, 64, 64, 4, 7, 7, 16> L6;
-typedef ConvCfg<kDeconvS2, 64, 32, 4, 14, 14, 16> L7;
+typedef ConvCfg<kConvS2, 32, 64, 2, 4, 7, 8> L5;
+typedef ConvCfg<kConvS1, 64, 64, 2, 4, 7, 16> L6;
+typedef ConvCfg<kDeconvS2, 64, 32, 4, 8, 14, 16> L7;
 typedef ConvCfg<kDeconvS2, 32, 16, 4, 14, 28, 8> L8;
 typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 28, 8, 3> L9;
 

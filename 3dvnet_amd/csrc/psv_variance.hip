@@ -17,6 +17,8 @@
 //            edge -> the C/4 lanes of a pixel read one full contiguous run per tap -- and
 //            accumulates sum / sum of squares in registers in edge order (deterministic);
 //   phase 3  the [C][64] tile is transposed through LDS and written as 256-B rows of `var`.
+#include <cstdlib>
+
 #include "v3d_common.h"
 
 namespace {
@@ -241,6 +243,266 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-window variant (C == 32): one 512-thread workgroup per (reference view, 8x8 plane-grid pixels,
+// 8 depth planes).  Thread t owns sample (plane t/64, pixel t%64) in the projection phase and
+// (pixel t/8, channel group t%8) in the sampling phase.  Per source edge:
+//   A  project the 512 samples, store (ix, iy) in LDS, reduce their cell bounding box;
+//   B  if the window (<= kWinCells feature cells) fits, copy it featT -> LDS with coalesced float4 loads
+//      (each 128-B cell is read ONCE for all the taps that touch it: ~8x less L1 traffic than gathering
+//      4 x 128 B per sample); otherwise this edge falls back to global gathers;
+//   C  every (pixel, channel group) lane walks its 8 planes: 4 ds_read_b128 taps, bilinear weights with
+//      padding-zero semantics, sum / sum-of-squares in registers (edge order => deterministic).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kWT = 8;            // pixel tile is kWT x kWT
+constexpr int kWDB = 4;           // depth planes per workgroup
+constexpr int kWinCells = 192;    // LDS window budget in feature cells (x 128 B)
+constexpr int kWinFloats = 4 * 32 * 65;   // window buffer, also reused as [4 planes][32 ch][64+1 px] out tile
+constexpr int kWinMaxE = 16;      // edges per pipelined chunk
+
+struct PsvWinParams {
+  PsvParams b;
+  int ntx, nty;
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(512, 4) void psv_variance_win_kernel(PsvWinParams pp) {
+  constexpr int C = 32;
+  const PsvParams& p = pp.b;
+  // double-buffered feature window (buffer 0 is reused as the [4 planes][32 ch][64+1 px] output tile),
+  // triple-buffered sample positions / bounding boxes: edge e+1 is projected and its window prefetched
+  // into registers while edge e is being sampled -> ONE barrier per edge, global latency hidden.
+  __shared__ __attribute__((aligned(16))) float s_win[2][kWinFloats];
+  __shared__ float2 s_ixy[3][kWDB][64];
+  __shared__ int s_bbox[3][4];     // xmin, ymin, xmax, ymax of floor(ix), floor(iy) over valid samples
+  __shared__ float s_ref[24];
+  __shared__ float s_P[kWinMaxE][12];
+  __shared__ int s_base[kWinMaxE];
+
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % pp.ntx; b /= pp.ntx;
+  const int ty = b % pp.nty; b /= pp.nty;
+  const int n_dchunk = (p.D + kWDB - 1) / kWDB;
+  const int dchunk = b % n_dchunk;
+  const int r = b / n_dchunk;
+  const int P = p.h * p.w;
+  const int e_begin = p.edge_ofs[r], ne = p.edge_ofs[r + 1] - e_begin;
+  const int ref = p.ref_img[r];
+  const int d_first = dchunk * kWDB;
+  const int nd = min(kWDB, p.D - d_first);
+
+  if (tid == 0) {
+    const float* Kp = p.K + ref * 9;
+    double a = Kp[0], bb = Kp[1], c = Kp[2], d = Kp[3], e = Kp[4], f = Kp[5], g = Kp[6], hh = Kp[7], i = Kp[8];
+    double det = a * (e * i - f * hh) - bb * (d * i - f * g) + c * (d * hh - e * g), id = 1.0 / det;
+    s_ref[0] = (float)((e * i - f * hh) * id); s_ref[1] = (float)((c * hh - bb * i) * id); s_ref[2] = (float)((bb * f - c * e) * id);
+    s_ref[3] = (float)((f * g - d * i) * id);  s_ref[4] = (float)((a * i - c * g) * id);   s_ref[5] = (float)((c * d - a * f) * id);
+    s_ref[6] = (float)((d * hh - e * g) * id); s_ref[7] = (float)((bb * g - a * hh) * id); s_ref[8] = (float)((a * e - bb * d) * id);
+  }
+  if (tid >= 64 && tid < 73) s_ref[9 + tid - 64] = p.R[ref * 9 + tid - 64];
+  if (tid >= 128 && tid < 131) s_ref[18 + tid - 128] = p.t[ref * 3 + tid - 128];
+  __syncthreads();
+
+  // ---- projection role: sample (plane sd, pixel sp) -------------------------------------------------
+  const int sd = tid >> 6, sp = tid & 63;
+  const int sgx = tx * kWT + (sp & 7), sgy = ty * kWT + (sp >> 3);
+  const bool projector = sd < kWDB;            // waves beyond kWDB*64 samples only stage and sample
+  const bool s_ok = projector && sd < nd && sgx < p.w && sgy < p.h;
+  float X, Y, Z;
+  {
+    const float xf = (p.w > 1 && sgx == p.w - 1) ? (float)(p.W - 1) : (float)((double)sgx * p.x_step);
+    const float yf = (p.h > 1 && sgy == p.h - 1) ? (float)(p.H - 1) : (float)((double)sgy * p.y_step);
+    const int d = d_first + sd;
+    const float z = (d == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d * p.z_step);
+    const float p0 = xf * z, p1 = yf * z, p2 = z;
+    const float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
+    const float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
+    const float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
+    X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
+    Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
+    Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+  }
+  // ---- sampling role: pixel cp, channel group cg ------------------------------------------------------
+  const int cp = tid >> 3, cg = tid & 7;
+  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+  const float kNaN = __int_as_float(0x7fc00000);
+
+  float acc_s[kWDB][4], acc_q[kWDB][4];
+#pragma unroll
+  for (int d = 0; d < kWDB; ++d)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc_s[d][k] = acc_q[d][k] = 0.f;
+
+  struct Win { int x0, y0, w, h; bool nonempty, lds; };
+
+  // A: project this thread's sample for edge e (chunk-local), reduce the cell bounding box
+  auto project = [&](int e, int buf) {
+    if (!projector) return;                      // wave-uniform
+    const float* Pm = s_P[e];
+    const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
+    const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
+    const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+    const float zb = fabsf(qz) + 1e-8f;
+    const float u = qx / zb, v = qy / zb;
+    const float gx = (u / Wm1) * 2.f - 1.f, gy = (v / Hm1) * 2.f - 1.f;
+    const float ix = ((gx + 1.f) / 2.f) * Wfm1, iy = ((gy + 1.f) / 2.f) * Hfm1;
+    const bool any = s_ok && (ix > -1.f) && (ix < Wfm1 + 1.f) && (iy > -1.f) && (iy < Hfm1 + 1.f);
+    s_ixy[buf][sd][sp] = any ? make_float2(ix, iy) : make_float2(kNaN, kNaN);
+    const int fx = (int)floorf(any ? ix : 0.f), fy = (int)floorf(any ? iy : 0.f);
+    const int x0 = wave_min_i(any ? fx : 0x7fffffff), y0 = wave_min_i(any ? fy : 0x7fffffff);
+    const int x1 = wave_max_i(any ? fx : -0x7fffffff), y1 = wave_max_i(any ? fy : -0x7fffffff);
+    if ((tid & 63) == 0 && x1 >= x0) {
+      atomicMin(&s_bbox[buf][0], x0); atomicMin(&s_bbox[buf][1], y0);
+      atomicMax(&s_bbox[buf][2], x1); atomicMax(&s_bbox[buf][3], y1);
+    }
+  };
+  auto window = [&](int buf) {
+    Win wn;
+    wn.nonempty = s_bbox[buf][2] >= s_bbox[buf][0];
+    wn.x0 = wn.nonempty ? max(s_bbox[buf][0], 0) : 0;
+    wn.y0 = wn.nonempty ? max(s_bbox[buf][1], 0) : 0;
+    const int x1 = wn.nonempty ? min(s_bbox[buf][2] + 1, p.Wf - 1) : 0, y1 = wn.nonempty ? min(s_bbox[buf][3] + 1, p.Hf - 1) : 0;
+    wn.w = x1 - wn.x0 + 1; wn.h = y1 - wn.y0 + 1;
+    wn.lds = wn.nonempty && wn.w * wn.h <= kWinCells;
+    return wn;
+  };
+  constexpr int kStg = kWinCells * 8 / 512;      // float4 per thread for a full window
+  static_assert(kWinCells * 8 % 512 == 0 && kWDB % 4 == 0 && kWDB * 64 <= 512, "window kernel geometry");
+  float4 stg[kStg];
+  auto prefetch = [&](int e, const Win& wn) {    // B, first half: window cells -> registers
+    if (!wn.lds) return;
+    const float* fimg = p.featT + (size_t)s_base[e] * C;
+    const int nf4 = wn.w * wn.h * 8;
+#pragma unroll
+    for (int k = 0; k < kStg; ++k) {
+      const int i = tid + k * 512;
+      if (i < nf4) {
+        const int cell = i >> 3, c4 = (i & 7) * 4;
+        const int cy = cell / wn.w, cx = cell - cy * wn.w;
+        stg[k] = *reinterpret_cast<const float4*>(fimg + ((wn.y0 + cy) * p.Wf + wn.x0 + cx) * C + c4);
+      }
+    }
+  };
+  auto commit = [&](int wbuf, const Win& wn) {   // B, second half: registers -> LDS window
+    if (!wn.lds) return;
+    const int nf4 = wn.w * wn.h * 8;
+#pragma unroll
+    for (int k = 0; k < kStg; ++k) {
+      const int i = tid + k * 512;
+      if (i < nf4) *reinterpret_cast<float4*>(&s_win[wbuf][(i >> 3) * C + (i & 7) * 4]) = stg[k];
+    }
+  };
+
+  for (int ec = 0; ec < ne; ec += kWinMaxE) {
+    const int nec = min(kWinMaxE, ne - ec);
+    __syncthreads();
+    if (tid < nec * 12) {
+      int e = tid / 12, ij = tid % 12, i = ij / 4, j = ij % 4;
+      int src = p.edge_src[e_begin + ec + e];
+      const float* Kp = p.K + src * 9; const float* Rp = p.R + src * 9; const float* tp = p.t + src * 3;
+      float v;
+      if (j < 3) v = Kp[i * 3 + 0] * Rp[0 * 3 + j] + Kp[i * 3 + 1] * Rp[1 * 3 + j] + Kp[i * 3 + 2] * Rp[2 * 3 + j];
+      else v = Kp[i * 3 + 0] * tp[0] + Kp[i * 3 + 1] * tp[1] + Kp[i * 3 + 2] * tp[2];
+      s_P[e][ij] = v;
+      if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
+    }
+    if (tid >= 256 && tid < 256 + 12) s_bbox[(tid - 256) >> 2][(tid - 256) & 3] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
+    __syncthreads();
+    project(0, 0);
+    __syncthreads();
+    Win cur = window(0);
+    prefetch(0, cur);
+    for (int e = 0; e < nec; ++e) {
+      const int ib = e % 3, wb = e & 1;
+      commit(wb, cur);
+      if (tid < 4) s_bbox[(e + 2) % 3][tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;   // free since edge e-1
+      const bool more = e + 1 < nec;
+      if (more) project(e + 1, (e + 1) % 3);
+      __syncthreads();
+      Win nxt = cur;
+      if (more) { nxt = window((e + 1) % 3); prefetch(e + 1, nxt); }
+      // ---- C: sample edge e ---------------------------------------------------------------------------
+      if (cur.nonempty) {
+        const float* fimg = p.featT + (size_t)s_base[e] * C + cg * 4;
+        const float* wbase = &s_win[wb][cg * 4];
+#pragma unroll
+        for (int dd = 0; dd < kWDB; ++dd) {
+          const float2 q = s_ixy[ib][dd][cp];
+          const float ix = q.x, iy = q.y;
+          if (ix == ix) {
+            const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
+            const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
+            const float w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f, w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
+            const float w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f, w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
+            const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+            float4 v00, v01, v10, v11;
+            if (cur.lds) {
+              // clamped coordinates lie inside the window by construction of the bounding box
+              const int ax0 = max(xi0 - cur.x0, 0), ax1 = max(xi1 - cur.x0, 0);
+              const int ay0 = max(yi0 - cur.y0, 0), ay1 = max(yi1 - cur.y0, 0);
+              v00 = *reinterpret_cast<const float4*>(wbase + (ay0 * cur.w + ax0) * C);
+              v01 = *reinterpret_cast<const float4*>(wbase + (ay0 * cur.w + ax1) * C);
+              v10 = *reinterpret_cast<const float4*>(wbase + (ay1 * cur.w + ax0) * C);
+              v11 = *reinterpret_cast<const float4*>(wbase + (ay1 * cur.w + ax1) * C);
+            } else {
+              v00 = *reinterpret_cast<const float4*>(fimg + (yi0 * p.Wf + xi0) * C);
+              v01 = *reinterpret_cast<const float4*>(fimg + (yi0 * p.Wf + xi1) * C);
+              v10 = *reinterpret_cast<const float4*>(fimg + (yi1 * p.Wf + xi0) * C);
+              v11 = *reinterpret_cast<const float4*>(fimg + (yi1 * p.Wf + xi1) * C);
+            }
+            float4 s;
+            s.x = v00.x * w00; s.y = v00.y * w00; s.z = v00.z * w00; s.w = v00.w * w00;
+            s.x += v01.x * w01; s.y += v01.y * w01; s.z += v01.z * w01; s.w += v01.w * w01;
+            s.x += v10.x * w10; s.y += v10.y * w10; s.z += v10.z * w10; s.w += v10.w * w10;
+            s.x += v11.x * w11; s.y += v11.y * w11; s.z += v11.z * w11; s.w += v11.w * w11;
+            acc_s[dd][0] += s.x; acc_s[dd][1] += s.y; acc_s[dd][2] += s.z; acc_s[dd][3] += s.w;
+            acc_q[dd][0] += s.x * s.x; acc_q[dd][1] += s.y * s.y; acc_q[dd][2] += s.z * s.z; acc_q[dd][3] += s.w * s.w;
+          }
+        }
+      }
+      cur = nxt;
+    }
+  }
+  // ---- variance -> LDS transpose -> store, 4 planes at a time ---------------------------------------------
+  const float cnt = (float)max(ne, 1);
+  float (*s_out)[C][65] = reinterpret_cast<float (*)[C][65]>(&s_win[0][0]);
+#pragma unroll
+  for (int half = 0; half < kWDB / 4; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int d4 = 0; d4 < 4; ++d4) {
+      const int dd = half * 4 + d4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float avg = acc_s[dd][k] / cnt, avg_sq = acc_q[dd][k] / cnt;
+        s_out[d4][cg * 4 + k][cp] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));
+      }
+    }
+    __syncthreads();
+    const int px = tid & 63;
+    const int gx = tx * kWT + (px & 7), gy = ty * kWT + (px >> 3);
+    if (gx < p.w && gy < p.h) {
+      for (int dc = tid >> 6; dc < 4 * C; dc += 8) {
+        const int d4 = dc / C, c = dc % C, d = d_first + half * 4 + d4;
+        if (d < p.D) p.var[(((size_t)r * C + c) * p.D + d) * P + gy * p.w + gx] = s_out[d4][c][px];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // shared with backproject.hip
@@ -296,7 +558,18 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
   const int n_dchunk = (D + kDB - 1) / kDB;
   const long long blocks = (long long)n_ref * n_dchunk * p.n_ptile;
   V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
-  {
+  // The LDS-window kernel is correct (same parity tests) but currently slower than the gather kernel
+  // (2.1-2.9 ms vs 1.3 ms per 32-view launch); it stays opt-in for further work.
+  static const bool use_win = getenv("V3D_PSV_WINDOW") != nullptr;
+  if (C == 32 && use_win) {
+    PsvWinParams pw;
+    pw.b = p;
+    pw.ntx = (w + kWT - 1) / kWT; pw.nty = (h + kWT - 1) / kWT;
+    const long long wblocks = (long long)n_ref * ((D + kWDB - 1) / kWDB) * pw.ntx * pw.nty;
+    V3D_REQUIRE(wblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
+    v3d::TimedScope ts("psv_variance", s);
+    psv_variance_win_kernel<<<(unsigned)wblocks, 512, 0, s>>>(pw);
+  } else {
     v3d::TimedScope ts("psv_variance", s);
     if (C == 32) psv_variance_kernel<32><<<(unsigned)blocks, kThreads, 0, s>>>(p);
     else psv_variance_kernel<16><<<(unsigned)blocks, kThreads, 0, s>>>(p);

@@ -150,8 +150,6 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import costvolume as ocv   # checker / reported baseline only
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         per = inp['edges'].shape[1] // args.refs
 
         def cpu_run(n):
@@ -159,6 +157,19 @@ def main():
                 return ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
                                         inp['edges'][:, :n * per], sd, d0, dd, D, inp['img_size'],
                                         inp['plane_size'])[0]
+        # PyTorch's CPU kernels do not scale to every hardware thread of a big host: probe a few
+        # thread counts on one view each and report the fastest (its thread count is `cores`)
+        ncpu = os.cpu_count() or 1
+        best = None
+        for nt in sorted({min(ncpu, c) for c in (16, 32, 64, ncpu)}):
+            torch.set_num_threads(nt)
+            cpu_run(1)
+            t0 = time.perf_counter()
+            cpu_run(1)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, nt)
+        torch.set_num_threads(best[1])
         cpu_run(1)
         t0 = time.perf_counter()
         d_cpu = cpu_run(args.cpu_refs)
