@@ -144,7 +144,17 @@ def main():
                                     for k, v in r.items() if k in ('bound', 'achieved', 'frac', 'unit')})
         dom = max(stats, key=lambda k: stats[k][0])
         roofline = kernel_roofline(dom, stats[dom][0] / stats[dom][1], shape)
-        roofline.update(kernel=dom, avg_ms=stats[dom][0] / stats[dom][1], traffic=None)
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/r01_traffic.json; FETCH_SIZE + WRITE_SIZE, KB -> bytes per launch), if they were taken
+        # at the same batch size
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+            if tj.get('refs_per_step_per_gpu') == args.refs and dom in tj['kernels']:
+                traffic = (tj['kernels'][dom]['fetch_kb'] + tj['kernels'][dom]['write_kb']) * 1024.0
+        except (OSError, ValueError, KeyError):
+            pass
+        roofline.update(kernel=dom, avg_ms=stats[dom][0] / stats[dom][1], traffic=traffic)
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N=1 only) --------------------------
     cpu_baseline = None
