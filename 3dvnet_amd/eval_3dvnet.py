@@ -3,8 +3,8 @@
 
 Single process: identical control flow to the reference -- chunked initial depth with a +-k image
 halo (:41-63), ``len(offsets_list)`` outer iterations of ``model_scene`` followed by chunked
-``run_pointflow`` sweeps with in-place ``+=`` (:73-99).  (Stage 3, the PropagationNet upsampling
-:101-125, is a "next" row -- stock 2D convolutions -- and is not part of this driver yet.)
+``run_pointflow`` sweeps with in-place ``+=`` (:73-99), and optionally stage 3, the three nearest +
+PropagationNet upsampling steps to full resolution (:101-125; a "next" row, stock 2D convolutions).
 
 Multi-GPU (one process per GPU, ``torch.distributed``): reference views are independent units for
 the cost volume and the point-flow sweeps, so rank g owns a contiguous block of reference views and
@@ -54,7 +54,7 @@ def gather_pointcloud(pts, pts_feat, pts_batch, group=None):
 
 def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, offsets_list=None,
                   init_depth_batch=INIT_DEPTH_BATCH, offset_batch=OFFSET_BATCH, rank=0, world=1,
-                  group=None, gather_depth=True):
+                  group=None, gather_depth=True, upsample=False):
     """Returns the refined depth maps [n_ref, h, w] (all views when gather_depth, else this rank's).
 
     ``batch``: images (or precomputed ``features_quarter``), rotmats, tvecs, K, ref_src_edges for the
@@ -108,6 +108,14 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                     all_depth[b0:b1] += net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
                                                           feats_local[b0:b1 + 2 * k], rot[b0:b1 + 2 * k],
                                                           tv[b0:b1 + 2 * k], K[b0:b1 + 2 * k], e, offset, 3)
+        if upsample:
+            # ---- stage 3 (:101-125): plane grid -> 1/4 -> 1/2 -> full resolution, guided by the quarter /
+            # half features and the image of each reference view (images k .. k + n_local of the halo'd slice)
+            from .upsampling import upsample_depth
+            half = batch.features_half[r0 + k:r1 + k].to(device)
+            imgs = batch.images[r0 + k:r1 + k].to(device)
+            all_depth = upsample_depth(all_depth, [(net.refine_quarter, feats_local[k:k + n_local]),
+                                                   (net.refine_half, half), (net.refine_full, imgs)])
         if world > 1 and gather_depth:
             all_depth = all_gather_rows(all_depth, group)
         return all_depth

@@ -12,6 +12,7 @@ from . import _lib, utils
 from .mvsnet import MVSNet, _Workspace, edges_to_csr
 from .refinement import HypothesisDecoder
 from .scenemodeling import PointNet, SparseUNet
+from .upsampling import PropagationNet
 
 
 def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges, img_size, offset=0.0,
@@ -60,6 +61,10 @@ class PL3DVNet(nn.Module):
         self.pointnet = PointNet(4 * feat_dim, 2 * feat_dim, feat_dim + 3)
         self.sparse_conv = SparseUNet(dims=(2 * feat_dim, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3))
         self.decoder = HypothesisDecoder(128 + 128 + 3 * feat_dim, 128, hyp_ksize, hyp_pad)
+        # stage-3 upsamplers (lightningmodel.py:41-43): stock 2D convolutions, SURVEY.md 8f "next" row
+        self.refine_quarter = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
+        self.refine_half = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
+        self.refine_full = PropagationNet(in_dim=3 + 1, h_dim=32)
         self._ws = _Workspace()
 
     def make_initial_depth_predictions(self, batch, depth_config):

@@ -198,6 +198,17 @@ def decoder_weights(in_dim=352, h_dim=128, ksize=3, seed=3, sharpen=1.0):
     return sd
 
 
+def propagation_weights(in_dim=33, h_dim=32, seed=5):
+    """state_dict for PropagationNet(in_dim, h_dim) (mv3d/subnetworks/upsampling.py:14-21)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    widths = [in_dim, h_dim, h_dim, h_dim, 9]
+    for i in range(4):
+        sd['conv%d.0.weight' % (i + 1)] = _conv_weight(g, (widths[i + 1], widths[i], 3, 3), widths[i] * 9)
+        _norm_stats(g, sd, 'conv%d.1' % (i + 1), widths[i + 1])
+    return sd
+
+
 # ----------------------------------------------------------------------------------------------
 # benchmark configurations (BASELINE.json configs, SURVEY.md §8d)
 # ----------------------------------------------------------------------------------------------

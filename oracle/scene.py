@@ -373,3 +373,19 @@ def model_scene(depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_e
     x = pointnet(x, edges[0], anchor_pts.shape[0], sd_pointnet)
     xs = sparse_unet(x, anchor_pts, anchor_idx3d, anchor_batch, edge_len, sd_unet)
     return xs, pts
+
+
+# ----------------------------------------------------------------------------------------------
+# "next" row: PropagationNet (mv3d/subnetworks/upsampling.py:14-36)
+# ----------------------------------------------------------------------------------------------
+
+def propagation_net(features, depth, sd, eps=1e-5):
+    x = torch.cat((features, depth), dim=1)
+    for i in range(1, 5):
+        x = F.conv2d(x, sd['conv%d.0.weight' % i], None, 1, 1)
+        x = F.relu(F.batch_norm(x, sd['conv%d.1.running_mean' % i], sd['conv%d.1.running_var' % i],
+                                sd['conv%d.1.weight' % i], sd['conv%d.1.bias' % i], False, 0., eps))
+    p = F.softmax(x, dim=1)
+    unf = F.unfold(F.pad(depth, (1, 1, 1, 1), mode='replicate'), kernel_size=3)     # [B, 9, H*W]
+    b, c, h, w = p.shape
+    return torch.sum(p.view(b, c, h * w) * unf, dim=1).view(b, h, w)

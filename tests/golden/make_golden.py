@@ -184,6 +184,16 @@ def golden_scene():
              edge_len=0.16, unet_seed=2, unet_checksum=checksum(sd_un), dec_seed=4, sharpen=50.0,
              dec_checksum=checksum(sd_dec320), pts_hyp=cap['pts_hyp'], pts_batch=cap['pts_batch'],
              depth_batch=sc['depth_batch'], preds=preds_loop.reshape(n_ref * P, 7))
+        # ---- 8f rank 2: PropagationNet (pure torch in the reference) ----------------------------------
+        sd_pr = syn.propagation_weights(in_dim=33, h_dim=32, seed=5)
+        pr = ref.up.PropagationNet(33, 32).eval()
+        rr = pr.load_state_dict(sd_pr, strict=False)
+        assert not rr.unexpected_keys and all('num_batches' in k for k in rr.missing_keys), rr
+        gg = torch.Generator().manual_seed(9)
+        pf = torch.rand((2, 32, 10, 12), generator=gg)
+        pd = 1.0 + 2.0 * torch.rand((2, 1, 10, 12), generator=gg)
+        save('N_propagation', features=pf, depth=pd, weights_seed=5, weights_checksum=checksum(sd_pr),
+             out=pr(pf, pd))
         # ---- H1, H4 -----------------------------------------------------------------------------------
         e = torch.tensor([[2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5], [1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6]])
         gt = sc['depth'] + 0.1

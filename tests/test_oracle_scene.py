@@ -159,3 +159,40 @@ def test_sparse_interpolate_equals_dense_grid_sample():
     samp = F.grid_sample(vol, grid[None, None, None][..., [2, 1, 0]], mode='bilinear',
                          padding_mode='zeros', align_corners=True)
     np.testing.assert_allclose(out.numpy(), samp[0, :, 0, 0].T.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_propagation_net_next_row():
+    """oracle and the product's stock-PyTorch module against the reference golden."""
+    g = load_golden('N_propagation')
+    syn = v3d('synthetic')
+    sd = _sd(syn.propagation_weights, g, 'weights_seed', 'weights_checksum', in_dim=33, h_dim=32)
+    out = osc.propagation_net(t(g['features']), t(g['depth']), sd)
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-5, atol=1e-6)
+    net = v3d('upsampling').PropagationNet(33, 32).eval()
+    r = net.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all('num_batches' in k for k in r.missing_keys)
+    with torch.no_grad():
+        np.testing.assert_allclose(net(t(g['features']), t(g['depth'])).numpy(), g['out'], rtol=1e-5, atol=1e-6)
+
+
+def test_upsample_chain_stage3():
+    """eval-3dvnet.py:101-125: nearest resize + PropagationNet at 1/4, 1/2 and full resolution."""
+    syn, up = v3d('synthetic'), v3d('upsampling')
+    g = torch.Generator().manual_seed(3)
+    depth = 1 + torch.rand((3, 7, 7), generator=g)
+    guides = [torch.rand((3, 32, 8, 10), generator=g), torch.rand((3, 32, 16, 20), generator=g),
+              torch.rand((3, 3, 32, 40), generator=g)]
+    sds = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
+    nets = []
+    for sd, cin in zip(sds, (33, 33, 4)):
+        n = up.PropagationNet(cin, 32).eval()
+        n.load_state_dict(sd, strict=False)
+        nets.append(n)
+    with torch.no_grad():
+        out = up.upsample_depth(depth.clone(), list(zip(nets, guides)), chunk=2)
+    ref = depth
+    for sd, gd in zip(sds, guides):
+        ref = F.interpolate(ref.unsqueeze(1), gd.shape[-2:], mode='nearest')
+        ref = osc.propagation_net(gd, ref, sd)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    assert out.shape == (3, 32, 40)
