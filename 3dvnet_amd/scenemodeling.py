@@ -243,6 +243,21 @@ class SparseUNet(nn.Module):
 
     # -- execution ----------------------------------------------------------------------------------
     @staticmethod
+    def _strided_coords(level):
+        """unique(floor(c / 2ts) * 2ts) in lexicographic (batch, x, y, z) order: packed 64-bit keys,
+        radix sort + unique in the library, unpack."""
+        from .utils import sort_unique_u64
+        lib = _lib.load()
+        dev, stream = level.coords.device, _lib.stream_ptr(level.coords.device)
+        keys = torch.empty(level.n, dtype=torch.int64, device=dev)
+        _lib.check(lib.v3d_strided_keys(level.coords.data_ptr(), level.n, level.stride, keys.data_ptr(), stream),
+                   'v3d_strided_keys')
+        uniq = sort_unique_u64(keys)
+        out = torch.empty((uniq.shape[0], 4), dtype=torch.int32, device=dev)
+        _lib.check(lib.v3d_unpack_coords(uniq.data_ptr(), uniq.shape[0], out.data_ptr(), stream), 'v3d_unpack_coords')
+        return out
+
+    @staticmethod
     def _conv(pack, x, nbr, n_out, eps, residual=None):
         idxs = [nbr.data_ptr() + 4 * k * n_out for k in range(27)]      # column k of the neighbour table
         return pack(n_out, [x] * 27, idxs=idxs, use_gn=True, gn_eps=eps, residual=residual, relu_out=True)
@@ -260,10 +275,7 @@ class SparseUNet(nn.Module):
         # coordinate maps: stride-2 conv output = unique(floor(c / 2ts) * 2ts), lexicographic order
         levels = [SparseLevel(coords, 1)]
         for i in range(1, len(self.dims)):
-            ts = levels[-1].stride
-            c = levels[-1].coords.clone()
-            c[:, 1:] = torch.div(c[:, 1:], 2 * ts, rounding_mode='floor') * (2 * ts)
-            levels.append(SparseLevel(torch.unique(c, dim=0).int(), 2 * ts))
+            levels.append(SparseLevel(self._strided_coords(levels[-1]), 2 * levels[-1].stride))
         same = [lv.neighbors(lv.coords, lv.stride) for lv in levels]                    # stride-1 maps
         x = F.contiguous().float()
         xs = []

@@ -172,6 +172,33 @@ int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C
                           const float* pts, const int64_t* pts_batch, int n_pts, int n_hyp,
                           const float* min_pts, float res, float* out, int ld_out, int col0, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row B3 (mv3d/utils.py:38-64 incl. the un-vendored torch_geometric voxel_grid / torch_cluster grid,
+ * restated) and the stride-2 coordinate maps of row B6.  Output sizes are data dependent, so
+ * v3d_sort_unique_u64 returns the count to the HOST and synchronises the stream (as torch.unique does
+ * in the reference, utils.py:48); everything else is asynchronous.
+ *   v3d_voxel_keys       bounding box of pts [n,3] -> ceil-based grid size + trunc+1 cell counts -> 1-D
+ *                        voxel id per point (utils.py:39-45); metadata stays in `workspace`
+ *   v3d_sort_unique_u64  ascending unique keys (torch.unique, :48)
+ *   v3d_lower_bound_u64  position of each point's key in the unique list = inverse index (:48-49)
+ *   v3d_voxel_decode     anchor batch, 3-D voxel index, voxel centre, per-batch shift to min 0 (:50-62);
+ *                        `workspace` must be the buffer v3d_voxel_keys filled; half_edge = edge_len / 2
+ *   v3d_strided_keys / v3d_unpack_coords   packed keys of floor(c / 2ts) * 2ts and back to int32 [n,4]
+ * ------------------------------------------------------------------------------------------ */
+size_t v3d_sort_unique_workspace_bytes(int n);
+int v3d_sort_unique_u64(const uint64_t* keys_in, int n, uint64_t* keys_out, int* n_unique_host,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int v3d_strided_keys(const int32_t* coords, int n, int tensor_stride, uint64_t* keys_out, void* stream);
+int v3d_unpack_coords(const uint64_t* keys, int n, int32_t* coords_out, void* stream);
+size_t v3d_voxelize_workspace_bytes(void);
+int v3d_voxel_keys(const float* pts, const int64_t* pts_batch, int n, float edge_len, uint64_t* keys_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int v3d_lower_bound_u64(const uint64_t* sorted_unique, int n_unique, const uint64_t* queries, int n,
+                        int64_t* index_out, void* stream);
+int v3d_voxel_decode(const uint64_t* unique_keys, int n_unique, float edge_len, float half_edge,
+                     float* anchor_pts, int32_t* anchor_idx3d, int64_t* anchor_batch, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Row C2b tail + C3: last Conv1d(C -> 1, k3, pad 1, bias) over the hypothesis axis, softmax
  * (refinement.py:24,43) and optional expectation sum_i p_i*offset_vals_i (lightningmodel.py:238-241).
  * act [n_pts, n_hyp, C]; weight [1, C, 3]; preds [n_pts, n_hyp]; expect [n_pts] or NULL. */
