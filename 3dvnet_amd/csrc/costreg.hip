@@ -441,35 +441,43 @@ __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict_
 
   constexpr int ROWS = PT_CK * PT_ID * PT_IH;          // one 64-lane group per row
   constexpr int NIT = (ROWS + 3) / 4;
-  constexpr int SU = 10;
+  // staging: lane = x position of the row; the next chunk's rows are loaded into registers right after the
+  // barrier and stay in flight while the current chunk is being consumed
+  const int sgx = ox0 - 1 + lane;
+  const bool xok = lane < PT_IW;
+  const bool xin = xok && sgx >= 0 && sgx < W;
+  float pre[NIT];
+  auto issue = [&](int c0) {
+    int gx_o = sgx;                           // opaque copies keep the per-row address arithmetic from
+    asm volatile("" : "+v"(gx_o));            // being hoisted out of the chunk loop into VGPRs
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * 4 + wave;
+      const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
+      const int gz = oz0 - 1 + rz, gy = oy0 - 1 + ry;
+      float v = 0.f;
+      if (row < ROWS && xin && gz >= 0 && gz < D && gy >= 0 && gy < H)
+        v = inb[(size_t)(c0 + ck) * plane + ((size_t)gz * H + gy) * W + gx_o];
+      pre[it] = v;
+    }
+  };
+  auto commit = [&]() {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * 4 + wave;
+      const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
+      if (row < ROWS && xok) xs[ck * PT_PLANE + (rz * PT_IH + ry) * PT_RS + lane_o] = pre[it];
+    }
+  };
+  issue(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < CIN; c0 += PT_CK) {
     __syncthreads();
-    {
-      const int gx = ox0 - 1 + lane;
-      const bool xok = lane < PT_IW;
-      const bool xin = xok && gx >= 0 && gx < W;
-#pragma unroll 1
-      for (int it0 = 0; it0 < NIT; it0 += SU) {
-        float v[SU];
-        int dst[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int row = (it0 + u) * 4 + wave;
-          const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
-          const int gz = oz0 - 1 + rz, gy = oy0 - 1 + ry;
-          const bool rok = (it0 + u) < NIT && row < ROWS;
-          v[u] = 0.f;
-          if (rok && xin && gz >= 0 && gz < D && gy >= 0 && gy < H)
-            v[u] = inb[(size_t)(c0 + ck) * plane + ((size_t)gz * H + gy) * W + gx];
-          dst[u] = (rok && xok) ? ck * PT_PLANE + (rz * PT_IH + ry) * PT_RS + lane : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < SU; ++u)
-          if (dst[u] >= 0) xs[dst[u]] = v[u];
-      }
-    }
+    commit();
     __syncthreads();
+    if (c0 + PT_CK < CIN) issue(c0 + PT_CK);
 #pragma unroll
     for (int ck = 0; ck < PT_CK; ++ck) {
 #pragma unroll
@@ -509,12 +517,19 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
   if (gid >= (size_t)n * HW) return;
   const int b = gid / HW, pix = gid % HW;
   const float* col = reg + (size_t)b * D * HW + pix;
-  float m = -INFINITY;
-  for (int d = 0; d < D; ++d) m = fmaxf(m, -col[(size_t)d * HW]);
-  float s = 0.f;
-  for (int d = 0; d < D; ++d) s += expf(-col[(size_t)d * HW] - m);
-  float e = 0.f;
-  for (int d = 0; d < D; ++d) e += vals[d] * (expf(-col[(size_t)d * HW] - m) / s);
+  // one pass over D with a running maximum: num = sum vals_d e^{-x_d - m}, den = sum e^{-x_d - m}
+  float m = -INFINITY, num = 0.f, den = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float x = -col[(size_t)d * HW];
+    if (x > m) {
+      const float sc = expf(m - x);          // exp(-inf) = 0 on the first plane
+      num *= sc; den *= sc; m = x;
+    }
+    const float ex = expf(x - m);
+    num += vals[d] * ex;
+    den += ex;
+  }
+  const float e = num / den;
   depth[gid] = e;
 }
 
@@ -524,19 +539,31 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
 #define V3D_L0_CFG kConvS1Pair, 32, 8, 4, 8, 28, 4, 3
 #endif
 typedef ConvCfg<V3D_L0_CFG> L0;
-typedef ConvCfg<kConvS2, 8, 16, 2, 4, 28, 4> L1;
-typedef ConvCfg<kConvS1, 16, 16, 4, 4, 28, 8> L2;
+#ifndef V3D_L1_CFG
+#define V3D_L1_CFG kConvS2, 8, 16, 2, 4, 28, 4
+#endif
+typedef ConvCfg<V3D_L1_CFG> L1;
+#ifndef V3D_L2_CFG
+#define V3D_L2_CFG kConvS1, 16, 16, 4, 4, 28, 8
+#endif
+typedef ConvCfg<V3D_L2_CFG> L2;
 typedef ConvCfg<kConvS2, 16, 32, 2, 7, 14, 4> L3;
 typedef ConvCfg<kConvS1, 32, 32, 4, 7, 14, 8> L4;
 typedef ConvCfg<kConvS2, 32, 64, 2, 4, 7, 8> L5;
 typedef ConvCfg<kConvS1, 64, 64, 2, 4, 7, 16> L6;
 typedef ConvCfg<kDeconvS2, 64, 32, 4, 8, 14, 16> L7;
-typedef ConvCfg<kDeconvS2, 32, 16, 4, 14, 28, 8> L8;
-typedef ConvCfg<kDeconvS2, 16, 8, 4, 8, 28, 8, 3> L9;
+#ifndef V3D_L8_CFG
+#define V3D_L8_CFG kDeconvS2, 32, 16, 4, 8, 28, 8
+#endif
+typedef ConvCfg<V3D_L8_CFG> L8;
+#ifndef V3D_L9_CFG
+#define V3D_L9_CFG kDeconvS2, 16, 8, 4, 8, 28, 16, 3
+#endif
+typedef ConvCfg<V3D_L9_CFG> L9;
 
 struct LayerDesc { int mode, cin, cout, ck; };
 const LayerDesc kLayers[10] = {
-    {L0::MODE, 32, 8, L0::CK},   {kConvS2, 8, 16, L1::CK},   {kConvS1, 16, 16, L2::CK},
+    {L0::MODE, 32, 8, L0::CK},   {L1::MODE, 8, 16, L1::CK},   {L2::MODE, 16, 16, L2::CK},
     {kConvS2, 16, 32, L3::CK},  {kConvS1, 32, 32, L4::CK},  {kConvS2, 32, 64, L5::CK},
     {kConvS1, 64, 64, L6::CK},  {kDeconvS2, 64, 32, L7::CK}, {kDeconvS2, 32, 16, L8::CK},
     {kDeconvS2, 16, 8, L9::CK}};

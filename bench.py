@@ -67,7 +67,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--refs', type=int, default=32, help='reference views per step per GPU')
+    ap.add_argument('--refs', type=int, default=64, help='reference views per step per GPU')
     ap.add_argument('--cpu-refs', type=int, default=4, help='reference views in the CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
