@@ -211,3 +211,65 @@ def test_model_scene_and_pointflow_end_to_end(cuda):
                                            d['rotmats'][r0:r1 + 2], d['tvecs'][r0:r1 + 2], d['K'][r0:r1 + 2],
                                            e, 0.05, 3))
         assert torch.equal(torch.cat(parts), off)
+
+
+def test_voxelize_exact_multiple_quirk_and_multibatch(cuda):
+    """utils.py:41 decodes with ceil((max-min)/edge) while torch_cluster encodes with trunc+1; they differ when
+    an extent is an exact multiple of the edge length.  The reference behaviour is restated literally, so the
+    native kernels must reproduce the oracle (= reference + restated voxel_grid) in that case too.  Three
+    batch elements, voxels holding a single point, points exactly on cell borders."""
+    g = torch.Generator().manual_seed(11)
+    lattice = torch.stack(torch.meshgrid(torch.arange(5), torch.arange(4), torch.arange(3), indexing='ij'), -1)
+    pts = lattice.reshape(-1, 3).float() * 0.25                       # extents 1.0, 0.75, 0.5 = 4, 3, 2 cells exactly
+    pts = torch.cat((pts, torch.rand((200, 3), generator=g) * torch.tensor([1.0, 0.75, 0.5])))
+    batch = torch.randint(0, 3, (pts.shape[0],), generator=g)
+    ref = osc.voxelize(pts, batch, 0.25)
+    out = v3d('utils').voxelize(pts.to(cuda), batch.to(cuda), 0.25)
+    for a, b in zip(out, ref):
+        if a.dtype.is_floating_point:
+            _close(a.cpu(), b, atol=1e-6)
+        else:
+            assert torch.equal(a.cpu().to(b.dtype), b)
+    grid = torch.ceil((pts.max(0)[0] - pts.min(0)[0]) / 0.25)
+    assert (grid == torch.tensor([4., 3., 2.])).all()                 # the quirk case is really exercised
+
+
+def test_full_size_scene_properties_cfg3(cuda):
+    """BASELINE config-3 shapes (56x56 maps, 32-ch 64x80 features, 4 cm voxels), 12 views, two batch elements:
+    size-independent properties at full size -- finite outputs, offsets inside the hypothesis range, probabilities
+    sum to one, chunked point-flow bit-identical to one call, queries far outside the scene interpolate to zero."""
+    syn, lm, ut = v3d('synthetic'), v3d('lightningmodel'), v3d('utils')
+    cfg = syn.CONFIGS['cfg3']
+    n_ref, k = 12, 2
+    edges, n_img = syn.make_edges(n_ref, k, k)
+    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=5)
+    feat = syn.make_features(n_img, 32, *cfg['feat_size'], seed=5).to(cuda)
+    depth = syn.ray_box_depth(rot[k:k + n_ref], tv[k:k + n_ref], K[k:k + n_ref], cfg['img_size'], (56, 56))
+    depth = (depth + 0.02 * torch.randn(depth.shape, generator=torch.Generator().manual_seed(1))).to(cuda)
+    rot, tv, K, edges = rot.to(cuda), tv.to(cuda), K.to(cuda), edges.to(cuda)
+    dbatch = torch.zeros(n_ref, dtype=torch.long, device=cuda)
+    dbatch[n_ref // 2:] = 1
+    net = lm.PL3DVNet(None, {'size': (56, 56)}, 0.04, feat_dim=32, img_size=cfg['img_size']).eval()
+    net.pointnet.load_state_dict(syn.pointnet_weights())
+    net.sparse_conv.load_state_dict(syn.sparse_unet_weights())
+    net.decoder.load_state_dict(syn.decoder_weights(sharpen=50.0), strict=False)
+    net = net.to(cuda)
+    with torch.no_grad():
+        xs, pts = net.model_scene(depth, dbatch, feat, rot, tv, K, edges, return_pts=True)
+        assert pts.shape == (n_ref * 3136, 3) and [x['stride'] for x in xs] == [4, 2, 1]
+        assert all(torch.isfinite(x['feats']).all() for x in xs)
+        assert xs[2]['feats'].shape[0] > 5000 and set(xs[2]['batch'].unique().tolist()) == {0, 1}
+        off = net.run_pointflow(xs, depth, dbatch, feat, rot, tv, K, edges, 0.05, 3)
+        assert torch.isfinite(off).all() and float(off.abs().max()) <= 0.15 + 1e-6
+        parts = []
+        for r0 in range(0, n_ref, 5):
+            r1 = min(r0 + 5, n_ref)
+            e = ut.slice_edges(edges, r0 + k, r1 + k, 0) - r0
+            parts.append(net.run_pointflow(xs, depth[r0:r1], dbatch[r0:r1], feat[r0:r1 + 2 * k], rot[r0:r1 + 2 * k],
+                                           tv[r0:r1 + 2 * k], K[r0:r1 + 2 * k], e, 0.05, 3))
+        assert torch.equal(torch.cat(parts), off)
+        far = torch.full((4, 7, 3), 500.0, device=cuda)
+        f = net.decoder.features(xs, far, torch.zeros((4, 7, 32), device=cuda), torch.zeros(4, dtype=torch.long, device=cuda))
+        assert float(f.abs().max()) == 0.0
+        preds = net.decoder.decode(f)
+        assert torch.allclose(preds.sum(1), torch.ones(4, device=cuda), atol=1e-6)
