@@ -64,9 +64,9 @@ template <int MBW, int NB>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   constexpr int kTM = 16 * NB;
   constexpr int NPASS = (kTM + 31) / 32;      // staging passes of 32 rows
-  __shared__ float xs[kTM * kXS];
-  __shared__ float ws[4 * MBW * 16 * kKC];
-  __shared__ int s_any;
+  __shared__ __attribute__((aligned(16))) float xs[kTM * kXS];
+  __shared__ __attribute__((aligned(16))) float ws[4 * MBW * 16 * kKC];
+  __shared__ int s_act[kMaxSeg], s_list[kMaxSeg], s_nact;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,76 +83,124 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   // staging role: 8 lanes x float4 cover the 32 columns of one row; 32 rows per pass
   const int srow = tid >> 3, sc4 = (tid & 7) * 4;
   const int nkc = p.KP / kKC;
-  const int wslab = MB * 16 * kKC;                 // packed floats per (segment, K chunk)
+  constexpr int kWslab = 4 * MBW * 16 * kKC;       // packed floats per (segment, K chunk)
+  constexpr int WPT = kWslab / 4 / 256;            // float4 of the weight slab per thread
+  static_assert(kWslab % 1024 == 0, "weight slab must split evenly over the workgroup");
 
-  for (int s = 0; s < p.n_seg; ++s) {
-    const Seg sg = p.seg[s];
-    // source row of each of this thread's 4 staging rows (-1 = zero row)
-    int rsrc[NPASS];
-    bool any = false;
+  // row source of this thread's staging rows for segment s (-1 = zero row)
+  auto rows_of = [&](int s, int (&r)[NPASS]) __attribute__((always_inline)) {
+    const int* idx = p.seg[s].idx;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int m = m0 + srow + 32 * i;
-      int r = -1;
+      int v = -1;
       if (m < p.M && srow + 32 * i < kTM) {
         if (p.group_len > 0) {
           const int h = m % p.group_len + s - p.n_seg / 2;
-          r = (h >= 0 && h < p.group_len) ? m + s - p.n_seg / 2 : -1;
+          v = (h >= 0 && h < p.group_len) ? m + s - p.n_seg / 2 : -1;
         } else {
-          r = sg.idx ? sg.idx[m] : m;
+          v = idx ? idx[m] : m;
         }
       }
-      rsrc[i] = r;
-      any |= r >= 0;
+      r[i] = v;
     }
-    if (sg.idx) {   // structured sparsity: skip a segment nobody in the tile needs
-      if (tid == 0) s_any = 0;
-      __syncthreads();
-      if (any) s_any = 1;
-      __syncthreads();
-      if (!s_any) continue;
-    }
-    const bool vec_ok = (sg.ld % 4 == 0) && (p.K % 4 == 0) && ((reinterpret_cast<size_t>(sg.src) & 15) == 0);
-    for (int kc = 0; kc < nkc; ++kc) {
-      __syncthreads();
-      // ---- stage activations (gathered rows, optional ReLU) --------------------------------------
+  };
+
+  // ---- which segments does this tile need at all? (structured sparsity of the neighbour tables) ---------
+  if (tid < kMaxSeg) s_act[tid] = 0;
+  __syncthreads();
+  for (int s = 0; s < p.n_seg; ++s) {
+    bool any = p.seg[s].idx == nullptr;            // identity / conv1d maps are always needed
+    if (!any) {
+      int r[NPASS];
+      rows_of(s, r);
 #pragma unroll
-      for (int i = 0; i < NPASS; ++i) {
-        if (srow + 32 * i >= kTM) break;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int col = kc * kKC + sc4;
-        if (rsrc[i] >= 0 && col < p.K) {
-          const float* rowp = sg.src + (size_t)rsrc[i] * sg.ld + col;
-          if (vec_ok) {
-            v = *reinterpret_cast<const float4*>(rowp);
-          } else {
-            v.x = rowp[0];
-            if (col + 1 < p.K) v.y = rowp[1];
-            if (col + 2 < p.K) v.z = rowp[2];
-            if (col + 3 < p.K) v.w = rowp[3];
-          }
-          if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      for (int i = 0; i < NPASS; ++i) any |= r[i] >= 0;
+    }
+    if (any) s_act[s] = 1;                         // benign race: everybody writes the same value
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int s = 0; s < p.n_seg; ++s) if (s_act[s]) s_list[n++] = s;
+    s_nact = n;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+
+  // ---- software pipeline over the flat (active segment, K chunk) sequence: the next chunk's gathered rows
+  // and weight slab are loaded into registers right after the barrier and land during the MFMA loop -------
+  f32x4 xr[NPASS], wr[WPT];     // native vector type: keeps the staging registers out of scratch
+  auto issue = [&](int s, int kc, const int (&r)[NPASS]) __attribute__((always_inline)) {
+    const Seg sg = p.seg[s];
+    const bool vec_ok = (sg.ld % 4 == 0) && (p.K % 4 == 0) && ((reinterpret_cast<size_t>(sg.src) & 15) == 0);
+    const int col = kc * kKC + sc4;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (r[i] >= 0 && col < p.K) {
+        const float* rowp = sg.src + (size_t)r[i] * sg.ld + col;
+        if (vec_ok) {
+          v = *reinterpret_cast<const f32x4*>(rowp);
+        } else {
+          v.x = rowp[0];
+          if (col + 1 < p.K) v.y = rowp[1];
+          if (col + 2 < p.K) v.z = rowp[2];
+          if (col + 3 < p.K) v.w = rowp[3];
         }
+      }
+      xr[i] = v;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp + (size_t)(s * nkc + kc) * kWslab) + tid;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) wr[i] = wsrc[i * 256];
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      if (srow + 32 * i < kTM) {
+        f32x4 v = xr[i];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         float* d = xs + (srow + 32 * i) * kXS + sc4;
         *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
         *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
       }
-      // ---- stage the weight slab of this (segment, chunk) ------------------------------------------
-      const float4* wsrc = reinterpret_cast<const float4*>(p.wp + (size_t)(s * nkc + kc) * wslab);
-      for (int i = tid; i < wslab / 4; i += 256) reinterpret_cast<float4*>(ws)[i] = wsrc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) reinterpret_cast<f32x4*>(ws)[tid + i * 256] = wr[i];
+  };
+
+  int rcur[NPASS], rnxt[NPASS];
+  if (nact > 0) {
+    rows_of(s_list[0], rcur);
+    issue(s_list[0], 0, rcur);
+    if (nact > 1) rows_of(s_list[1], rnxt);
+  }
+  for (int a = 0; a < nact; ++a) {
+    for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();
-      // ---- MFMA ------------------------------------------------------------------------------------
+      commit();
+      __syncthreads();
+      if (kc + 1 < nkc) {
+        issue(s_list[a], kc + 1, rcur);
+      } else if (a + 1 < nact) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) rcur[i] = rnxt[i];
+        issue(s_list[a + 1], 0, rcur);
+        if (a + 2 < nact) rows_of(s_list[a + 2], rnxt);       // one whole segment ahead of its first use
+      }
+      // ---- MFMA ------------------------------------------------------------------------------------------
 #pragma unroll
       for (int k4 = 0; k4 < kKC / 4; ++k4) {
-        float a[MBW];
+        float a_frag[MBW];
 #pragma unroll
-        for (int m = 0; m < MBW; ++m) a[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
+        for (int m = 0; m < MBW; ++m) a_frag[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float bv = xs[(nb * 16 + jn) * kXS + k4 * 4 + kq];
 #pragma unroll
           for (int m = 0; m < MBW; ++m)
-            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[nb][m], 0, 0, 0);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_frag[m], bv, acc[nb][m], 0, 0, 0);
         }
       }
     }
