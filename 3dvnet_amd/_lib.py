@@ -52,8 +52,10 @@ SIGNATURES = {
     'v3d_hash_bytes': (c_size_t, [c_int]),
     'v3d_hash_build': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'v3d_sparse_neighbors': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'v3d_sparse_interp_workspace_bytes': (c_size_t, [c_int, c_int]),
     'v3d_sparse_interp_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
-                                      c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+                                      c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                      c_void_p]),
     'v3d_sort_unique_workspace_bytes': (c_size_t, [c_int]),
     'v3d_sort_unique_u64': (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p, c_size_t, c_void_p]),
     'v3d_strided_keys': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

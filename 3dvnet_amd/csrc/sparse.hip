@@ -70,38 +70,59 @@ __global__ void neighbors_kernel(HashTable t, const int* __restrict__ out_coords
   }
 }
 
-// Sparse trilinear interpolation.  C/4 threads per query, float4 channels each.
-__global__ __launch_bounds__(256) void sparse_interp_kernel(HashTable t, const float* __restrict__ feats,
-                                                            int C, int ts, const float* __restrict__ pts,
-                                                            const long long* __restrict__ pts_batch,
-                                                            int n_hyp, const float* __restrict__ min_pts,
-                                                            float res, int n_query, float* __restrict__ out,
-                                                            int ld_out, int col0) {
+// Sparse trilinear interpolation in two kernels:
+//  1. corners: one thread per (query, corner) -- the 8 hash probes of a query run in parallel lanes and
+//     leave (row, weight) pairs in a small scratch table (row -1 = absent corner, weight unused);
+//  2. gather:  C/4 threads per query, float4 channels each; the 8 feature-row loads are independent
+//     (no probe in between), so they are all in flight together.
+__global__ __launch_bounds__(256) void interp_corners_kernel(HashTable t, int ts, const float* __restrict__ pts,
+                                                             const long long* __restrict__ pts_batch, int n_hyp,
+                                                             const float* __restrict__ min_pts, float res,
+                                                             int n_query, int* __restrict__ crow,
+                                                             float* __restrict__ cw) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int q = gid >> 3, corner = gid & 7;
+  if (q >= n_query) return;
+  const int b = (int)pts_batch[q / n_hyp];
+  // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
+  float w = 1.f;
+  float cc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float qc = ((pts[(size_t)q * 3 + d] - min_pts[b * 3 + d]) / res) * (float)ts;
+    const float c = floorf(qc / (float)ts) * (float)ts + (((corner >> d) & 1) ? ts : 0);
+    w *= 1.f - fabsf(qc - c) / ts;
+    cc[d] = c;
+  }
+  int row = -1;
+  // coordinates far outside the packed range cannot be present
+  if (cc[0] >= -kGuard && cc[1] >= -kGuard && cc[2] >= -kGuard && cc[0] <= 60000.f && cc[1] <= 60000.f && cc[2] <= 60000.f)
+    row = hash_find(t, pack_key(b, (int)cc[0], (int)cc[1], (int)cc[2]));
+  crow[gid] = row;
+  cw[gid] = w;
+}
+
+__global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restrict__ feats, int C,
+                                                            const int* __restrict__ crow,
+                                                            const float* __restrict__ cw, int n_query,
+                                                            float* __restrict__ out, int ld_out, int col0) {
   const int tpq = C / 4;                       // threads per query
   const int q = (blockIdx.x * 256 + threadIdx.x) / tpq;
   const int c4 = ((blockIdx.x * 256 + threadIdx.x) % tpq) * 4;
   if (q >= n_query) return;
-  const int b = (int)pts_batch[q / n_hyp];
-  // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
-  float qc[3], lo[3];
+  int rows[8];
+  float w[8];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    qc[d] = ((pts[(size_t)q * 3 + d] - min_pts[b * 3 + d]) / res) * (float)ts;
-    lo[d] = floorf(qc[d] / (float)ts) * (float)ts;
-  }
+  for (int k = 0; k < 8; ++k) { rows[k] = crow[q * 8 + k]; w[k] = cw[q * 8 + k]; }
+  float4 f[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    f[k] = rows[k] >= 0 ? *reinterpret_cast<const float4*>(feats + (size_t)rows[k] * C + c4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int corner = 0; corner < 8; ++corner) {
-    const float cx = lo[0] + ((corner & 1) ? ts : 0), cy = lo[1] + ((corner & 2) ? ts : 0),
-                cz = lo[2] + ((corner & 4) ? ts : 0);
-    const float w = (1.f - fabsf(qc[0] - cx) / ts) * (1.f - fabsf(qc[1] - cy) / ts) * (1.f - fabsf(qc[2] - cz) / ts);
-    // coordinates far outside the packed range cannot be present
-    if (cx < -kGuard || cy < -kGuard || cz < -kGuard || cx > 60000.f || cy > 60000.f || cz > 60000.f) continue;
-    const int row = hash_find(t, pack_key(b, (int)cx, (int)cy, (int)cz));
-    if (row >= 0) {
-      const float4 f = *reinterpret_cast<const float4*>(feats + (size_t)row * C + c4);
-      acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
-    }
+  for (int k = 0; k < 8; ++k) {        // corner order x fastest, as in the single-kernel formulation
+    if (rows[k] >= 0) { acc.x += w[k] * f[k].x; acc.y += w[k] * f[k].y; acc.z += w[k] * f[k].z; acc.w += w[k] * f[k].w; }
   }
   float* o = out + (size_t)q * ld_out + col0 + c4;
   o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
@@ -151,10 +172,15 @@ extern "C" int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* 
   return V3D_OK;
 }
 
+extern "C" size_t v3d_sparse_interp_workspace_bytes(int n_pts, int n_hyp) {
+  return v3d::align_up((size_t)n_pts * n_hyp * 8 * 4, 256) * 2;
+}
+
 extern "C" int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C,
                                      int tensor_stride, const float* pts, const int64_t* pts_batch,
                                      int n_pts, int n_hyp, const float* min_pts, float res, float* out,
-                                     int ld_out, int col0, void* stream) {
+                                     int ld_out, int col0, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   V3D_REQUIRE(table && feats && pts && pts_batch && min_pts && out, V3D_ERR_BAD_ARG,
               "v3d_sparse_interp_f32: null argument");
   V3D_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0, V3D_ERR_UNSUPPORTED,
@@ -165,10 +191,16 @@ extern "C" int v3d_sparse_interp_f32(const void* table, int n_in, const float* f
   if (nq == 0) return V3D_OK;
   hipStream_t s = (hipStream_t)stream;
   HashTable t = table_view(const_cast<void*>(table), n_in);
+  V3D_REQUIRE(workspace && workspace_bytes >= v3d_sparse_interp_workspace_bytes(n_pts, n_hyp),
+              V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_sparse_interp_f32: workspace too small");
+  V3D_REQUIRE(nq * 8 < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_sparse_interp_f32: too many queries");
+  int* crow = (int*)workspace;
+  float* cw = (float*)((char*)workspace + v3d::align_up((size_t)nq * 8 * 4, 256));
   const long long threads = nq * (C / 4);
   v3d::TimedScope ts("sparse_interp", s);
-  sparse_interp_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(
-      t, feats, C, tensor_stride, pts, (const long long*)pts_batch, n_hyp, min_pts, res, (int)nq, out, ld_out, col0);
-  V3D_CHECK_LAUNCH("sparse_interp_kernel");
+  interp_corners_kernel<<<(unsigned)((nq * 8 + 255) / 256), 256, 0, s>>>(
+      t, tensor_stride, pts, (const long long*)pts_batch, n_hyp, min_pts, res, (int)nq, crow, cw);
+  interp_gather_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(feats, C, crow, cw, (int)nq, out, ld_out, col0);
+  V3D_CHECK_LAUNCH("interp_gather_kernel");
   return V3D_OK;
 }

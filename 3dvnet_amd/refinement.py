@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .mvsnet import _Workspace
 from .scenemodeling import PackedGemm, _PackCache
 
 
@@ -28,6 +29,7 @@ class HypothesisDecoder(nn.Module):
         self.net = nn.Sequential(conv1d_bn_relu(in_dim, h_dim), conv1d_bn_relu(h_dim, h_dim),
                                  conv1d_bn_relu(h_dim, h_dim), nn.Conv1d(h_dim, 1, kernel_size, 1, padding))
         self._cache = _PackCache(self)
+        self._ws = _Workspace()
 
     def _build(self):
         packs = []
@@ -56,6 +58,8 @@ class HypothesisDecoder(nn.Module):
         if pts_feat is not None:
             feats[:, :, total - cf:] = pts_feat
         col = total - cf
+        wbytes = lib.v3d_sparse_interp_workspace_bytes(n_pts, n_hyp)
+        ws = self._ws.get('interp', wbytes, dev)
         for x in xs:                                   # coarse -> fine, each level prepended (:41)
             lv = x['sparse']
             col -= x['feats'].shape[1]
@@ -70,7 +74,7 @@ class HypothesisDecoder(nn.Module):
             rc = lib.v3d_sparse_interp_f32(lv.table.data_ptr(), lv.n, f.data_ptr(), f.shape[1],
                                            int(x['stride']), pts.data_ptr(), pts_batch.data_ptr(), n_pts,
                                            n_hyp, min_pts.data_ptr(), float(x['res']), feats.data_ptr(),
-                                           total, col, _lib.stream_ptr(dev))
+                                           total, col, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
             _lib.check(rc, 'v3d_sparse_interp_f32')
         return feats
 

@@ -162,15 +162,17 @@ int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
  *   v3d_sparse_interp_f32 MinkowskiInterpolation (refinement.py:26,39): trilinear interpolation of
  *                         feats [N,C] at pts [n_pts, n_hyp, 3] (world), query coordinate
  *                         ((p - min_pts[batch]) / res) * tensor_stride, missing corners add 0; result
- *                         written to out[q*ld_out + col0 .. +C).
+ *                         written to out[q*ld_out + col0 .. +C); workspace >= v3d_sparse_interp_workspace_bytes.
  * ------------------------------------------------------------------------------------------ */
 size_t v3d_hash_bytes(int n);
 int v3d_hash_build(const int32_t* coords, int n, void* table, size_t table_bytes, void* stream);
 int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* out_coords, int n_out, int step,
                          int32_t* nbr, void* stream);
+size_t v3d_sparse_interp_workspace_bytes(int n_pts, int n_hyp);
 int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C, int tensor_stride,
                           const float* pts, const int64_t* pts_batch, int n_pts, int n_hyp,
-                          const float* min_pts, float res, float* out, int ld_out, int col0, void* stream);
+                          const float* min_pts, float res, float* out, int ld_out, int col0,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row B3 (mv3d/utils.py:38-64 incl. the un-vendored torch_geometric voxel_grid / torch_cluster grid,
