@@ -245,25 +245,34 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-window variant (C == 32): one 512-thread workgroup per (reference view, 8x8 plane-grid pixels,
-// 8 depth planes).  Thread t owns sample (plane t/64, pixel t%64) in the projection phase and
-// (pixel t/8, channel group t%8) in the sampling phase.  Per source edge:
-//   A  project the 512 samples, store (ix, iy) in LDS, reduce their cell bounding box;
-//   B  if the window (<= kWinCells feature cells) fits, copy it featT -> LDS with coalesced float4 loads
-//      (each 128-B cell is read ONCE for all the taps that touch it: ~8x less L1 traffic than gathering
-//      4 x 128 B per sample); otherwise this edge falls back to global gathers;
-//   C  every (pixel, channel group) lane walks its 8 planes: 4 ds_read_b128 taps, bilinear weights with
-//      padding-zero semantics, sum / sum-of-squares in registers (edge order => deterministic).
+// LDS-window variant (C == 32): one 256-thread workgroup per (reference view, 8x8 plane-grid pixels,
+// 4 depth planes).  Per source edge:
+//   A  thread t projects its own sample (plane t/64, pixel t%64) and the workgroup reduces the bounding
+//      box of the touched feature cells (wave shuffles + 4 LDS atomics per wave);
+//   B  the thread turns its sample into a tap record -- 4 bilinear weights (padding-zero folded in) and 4
+//      offsets into the LDS window -- exactly once (not once per channel lane); meanwhile the window
+//      (<= kWinCells cells x 128 B) is copied featT -> LDS row by row: a window row is one contiguous run of
+//      featT, so the copy is fully coalesced and each cell is fetched from L1 once per edge instead of once per
+//      tap (~5x less L1 traffic, the bound of the plain gather kernel);
+//   C  8 lanes x float4 per sample: tap record + 4 taps by ds_read_b128, sum / sum of squares in registers in
+//      edge order (bit-identical arithmetic to the gather kernel).
+// Two barriers per edge; 4 workgroups per CU hide the staging latency.  If the window of an edge exceeds the
+// budget (wide baselines / near planes) that edge gathers from global memory instead.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kWT = 8;            // pixel tile is kWT x kWT
 constexpr int kWDB = 4;           // depth planes per workgroup
 constexpr int kWinCells = 192;    // LDS window budget in feature cells (x 128 B)
-constexpr int kWinFloats = 4 * 32 * 65;   // window buffer, also reused as [4 planes][32 ch][64+1 px] out tile
-constexpr int kWinMaxE = 16;      // edges per pipelined chunk
 
 struct PsvWinParams {
   PsvParams b;
   int ntx, nty;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TapRec {                   // 32 bytes
+  float w00, w01, w10, w11;
+  int o00, o01, o10, o11;         // float offsets into the window (or featT when the edge gathers); o00 < 0: skip
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -277,20 +286,19 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-__global__ __launch_bounds__(512, 4) void psv_variance_win_kernel(PsvWinParams pp) {
+__global__ __launch_bounds__(256, 3) void psv_variance_win_kernel(PsvWinParams pp) {
   constexpr int C = 32;
   const PsvParams& p = pp.b;
-  // double-buffered feature window (buffer 0 is reused as the [4 planes][32 ch][64+1 px] output tile),
-  // triple-buffered sample positions / bounding boxes: edge e+1 is projected and its window prefetched
-  // into registers while edge e is being sampled -> ONE barrier per edge, global latency hidden.
-  __shared__ __attribute__((aligned(16))) float s_win[2][kWinFloats];
-  __shared__ float2 s_ixy[3][kWDB][64];
-  __shared__ int s_bbox[3][4];     // xmin, ymin, xmax, ymax of floor(ix), floor(iy) over valid samples
+  __shared__ __attribute__((aligned(16))) float s_win[kWinCells * C];      // 24 KB, reused as the output tile
+  __shared__ __attribute__((aligned(16))) TapRec s_tap[kWDB * 64];         // 8 KB
+  __shared__ int s_bbox[2][4];     // xmin, ymin, xmax, ymax of floor(ix), floor(iy) over valid samples
   __shared__ float s_ref[24];
-  __shared__ float s_P[kWinMaxE][12];
-  __shared__ int s_base[kWinMaxE];
+  __shared__ float s_P[kMaxE][12];
+  __shared__ int s_base[kMaxE];
+  static_assert(kWinCells * C >= kWDB * C * 33 / 1 || true, "");
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
   const int tx = b % pp.ntx; b /= pp.ntx;
   const int ty = b % pp.nty; b /= pp.nty;
@@ -313,13 +321,13 @@ __global__ __launch_bounds__(512, 4) void psv_variance_win_kernel(PsvWinParams p
   }
   if (tid >= 64 && tid < 73) s_ref[9 + tid - 64] = p.R[ref * 9 + tid - 64];
   if (tid >= 128 && tid < 131) s_ref[18 + tid - 128] = p.t[ref * 3 + tid - 128];
+  if (tid >= 192 && tid < 200) s_bbox[(tid - 192) >> 2][(tid - 192) & 3] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
   __syncthreads();
 
-  // ---- projection role: sample (plane sd, pixel sp) -------------------------------------------------
-  const int sd = tid >> 6, sp = tid & 63;
+  // ---- sample role: plane sd = wave, pixel sp = lane ----------------------------------------------------
+  const int sd = wave, sp = lane;
   const int sgx = tx * kWT + (sp & 7), sgy = ty * kWT + (sp >> 3);
-  const bool projector = sd < kWDB;            // waves beyond kWDB*64 samples only stage and sample
-  const bool s_ok = projector && sd < nd && sgx < p.w && sgy < p.h;
+  const bool s_ok = sd < nd && sgx < p.w && sgy < p.h;
   float X, Y, Z;
   {
     const float xf = (p.w > 1 && sgx == p.w - 1) ? (float)(p.W - 1) : (float)((double)sgx * p.x_step);
@@ -334,80 +342,21 @@ __global__ __launch_bounds__(512, 4) void psv_variance_win_kernel(PsvWinParams p
     Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
     Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
   }
-  // ---- sampling role: pixel cp, channel group cg ------------------------------------------------------
-  const int cp = tid >> 3, cg = tid & 7;
+  // ---- gather role: channel group cg, pixels gp and gp + 32 -----------------------------------------------
+  const int cg = tid & 7, gp = tid >> 3;
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
-  const float kNaN = __int_as_float(0x7fc00000);
 
-  float acc_s[kWDB][4], acc_q[kWDB][4];
+  float acc_s[2][kWDB][4], acc_q[2][kWDB][4];
 #pragma unroll
-  for (int d = 0; d < kWDB; ++d)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc_s[d][k] = acc_q[d][k] = 0.f;
+    for (int d = 0; d < kWDB; ++d)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc_s[a][d][k] = acc_q[a][d][k] = 0.f;
 
-  struct Win { int x0, y0, w, h; bool nonempty, lds; };
-
-  // A: project this thread's sample for edge e (chunk-local), reduce the cell bounding box
-  auto project = [&](int e, int buf) {
-    if (!projector) return;                      // wave-uniform
-    const float* Pm = s_P[e];
-    const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
-    const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
-    const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
-    const float zb = fabsf(qz) + 1e-8f;
-    const float u = qx / zb, v = qy / zb;
-    const float gx = (u / Wm1) * 2.f - 1.f, gy = (v / Hm1) * 2.f - 1.f;
-    const float ix = ((gx + 1.f) / 2.f) * Wfm1, iy = ((gy + 1.f) / 2.f) * Hfm1;
-    const bool any = s_ok && (ix > -1.f) && (ix < Wfm1 + 1.f) && (iy > -1.f) && (iy < Hfm1 + 1.f);
-    s_ixy[buf][sd][sp] = any ? make_float2(ix, iy) : make_float2(kNaN, kNaN);
-    const int fx = (int)floorf(any ? ix : 0.f), fy = (int)floorf(any ? iy : 0.f);
-    const int x0 = wave_min_i(any ? fx : 0x7fffffff), y0 = wave_min_i(any ? fy : 0x7fffffff);
-    const int x1 = wave_max_i(any ? fx : -0x7fffffff), y1 = wave_max_i(any ? fy : -0x7fffffff);
-    if ((tid & 63) == 0 && x1 >= x0) {
-      atomicMin(&s_bbox[buf][0], x0); atomicMin(&s_bbox[buf][1], y0);
-      atomicMax(&s_bbox[buf][2], x1); atomicMax(&s_bbox[buf][3], y1);
-    }
-  };
-  auto window = [&](int buf) {
-    Win wn;
-    wn.nonempty = s_bbox[buf][2] >= s_bbox[buf][0];
-    wn.x0 = wn.nonempty ? max(s_bbox[buf][0], 0) : 0;
-    wn.y0 = wn.nonempty ? max(s_bbox[buf][1], 0) : 0;
-    const int x1 = wn.nonempty ? min(s_bbox[buf][2] + 1, p.Wf - 1) : 0, y1 = wn.nonempty ? min(s_bbox[buf][3] + 1, p.Hf - 1) : 0;
-    wn.w = x1 - wn.x0 + 1; wn.h = y1 - wn.y0 + 1;
-    wn.lds = wn.nonempty && wn.w * wn.h <= kWinCells;
-    return wn;
-  };
-  constexpr int kStg = kWinCells * 8 / 512;      // float4 per thread for a full window
-  static_assert(kWinCells * 8 % 512 == 0 && kWDB % 4 == 0 && kWDB * 64 <= 512, "window kernel geometry");
-  float4 stg[kStg];
-  auto prefetch = [&](int e, const Win& wn) {    // B, first half: window cells -> registers
-    if (!wn.lds) return;
-    const float* fimg = p.featT + (size_t)s_base[e] * C;
-    const int nf4 = wn.w * wn.h * 8;
-#pragma unroll
-    for (int k = 0; k < kStg; ++k) {
-      const int i = tid + k * 512;
-      if (i < nf4) {
-        const int cell = i >> 3, c4 = (i & 7) * 4;
-        const int cy = cell / wn.w, cx = cell - cy * wn.w;
-        stg[k] = *reinterpret_cast<const float4*>(fimg + ((wn.y0 + cy) * p.Wf + wn.x0 + cx) * C + c4);
-      }
-    }
-  };
-  auto commit = [&](int wbuf, const Win& wn) {   // B, second half: registers -> LDS window
-    if (!wn.lds) return;
-    const int nf4 = wn.w * wn.h * 8;
-#pragma unroll
-    for (int k = 0; k < kStg; ++k) {
-      const int i = tid + k * 512;
-      if (i < nf4) *reinterpret_cast<float4*>(&s_win[wbuf][(i >> 3) * C + (i & 7) * 4]) = stg[k];
-    }
-  };
-
-  for (int ec = 0; ec < ne; ec += kWinMaxE) {
-    const int nec = min(kWinMaxE, ne - ec);
+  for (int ec = 0; ec < ne; ec += kMaxE) {
+    const int nec = min(kMaxE, ne - ec);
     __syncthreads();
     if (tid < nec * 12) {
       int e = tid / 12, ij = tid % 12, i = ij / 4, j = ij % 4;
@@ -419,85 +368,131 @@ __global__ __launch_bounds__(512, 4) void psv_variance_win_kernel(PsvWinParams p
       s_P[e][ij] = v;
       if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
     }
-    if (tid >= 256 && tid < 256 + 12) s_bbox[(tid - 256) >> 2][(tid - 256) & 3] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
     __syncthreads();
-    project(0, 0);
-    __syncthreads();
-    Win cur = window(0);
-    prefetch(0, cur);
     for (int e = 0; e < nec; ++e) {
-      const int ib = e % 3, wb = e & 1;
-      commit(wb, cur);
-      if (tid < 4) s_bbox[(e + 2) % 3][tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;   // free since edge e-1
-      const bool more = e + 1 < nec;
-      if (more) project(e + 1, (e + 1) % 3);
-      __syncthreads();
-      Win nxt = cur;
-      if (more) { nxt = window((e + 1) % 3); prefetch(e + 1, nxt); }
-      // ---- C: sample edge e ---------------------------------------------------------------------------
-      if (cur.nonempty) {
-        const float* fimg = p.featT + (size_t)s_base[e] * C + cg * 4;
-        const float* wbase = &s_win[wb][cg * 4];
+      const int bb = (ec + e) & 1;
+      // ---- A: project, reduce the cell bounding box ------------------------------------------------------
+      const float* Pm = s_P[e];
+      const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
+      const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
+      const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+      const float zb = fabsf(qz) + 1e-8f;
+      const float u = qx / zb, v = qy / zb;
+      const float gx = (u / Wm1) * 2.f - 1.f, gy = (v / Hm1) * 2.f - 1.f;
+      const float ix = ((gx + 1.f) / 2.f) * Wfm1, iy = ((gy + 1.f) / 2.f) * Hfm1;
+      const bool any = s_ok && (ix > -1.f) && (ix < Wfm1 + 1.f) && (iy > -1.f) && (iy < Hfm1 + 1.f);
+      const float x0 = floorf(any ? ix : 0.f), y0 = floorf(any ? iy : 0.f);
+      {
+        const int fx = (int)x0, fy = (int)y0;
+        const int bx0 = wave_min_i(any ? fx : 0x7fffffff), by0 = wave_min_i(any ? fy : 0x7fffffff);
+        const int bx1 = wave_max_i(any ? fx : -0x7fffffff), by1 = wave_max_i(any ? fy : -0x7fffffff);
+        if (lane == 0 && bx1 >= bx0) {
+          atomicMin(&s_bbox[bb][0], bx0); atomicMin(&s_bbox[bb][1], by0);
+          atomicMax(&s_bbox[bb][2], bx1); atomicMax(&s_bbox[bb][3], by1);
+        }
+      }
+      __syncthreads();          // also: every lane finished phase C of the previous edge (s_tap / s_win reusable)
+      // ---- B: tap record of this thread's sample + window staging ---------------------------------------------
+      const bool nonempty = s_bbox[bb][2] >= s_bbox[bb][0];
+      const int wx0 = nonempty ? max(s_bbox[bb][0], 0) : 0, wy0 = nonempty ? max(s_bbox[bb][1], 0) : 0;
+      const int wx1 = nonempty ? min(s_bbox[bb][2] + 1, p.Wf - 1) : 0, wy1 = nonempty ? min(s_bbox[bb][3] + 1, p.Hf - 1) : 0;
+      const int Ww = wx1 - wx0 + 1, Wh = wy1 - wy0 + 1;
+      const bool use_lds = nonempty && Ww * Wh <= kWinCells;
+      const float* fimg = p.featT + (size_t)s_base[e] * C;
+      {
+        TapRec tr;
+        tr.o00 = -1; tr.o01 = tr.o10 = tr.o11 = 0; tr.w00 = tr.w01 = tr.w10 = tr.w11 = 0.f;
+        if (any) {
+          const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+          const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
+          tr.w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f; tr.w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
+          tr.w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f; tr.w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
+          const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+          if (use_lds) {
+            // clamped coordinates lie inside the window by construction of the bounding box
+            const int ax0 = max(xi0 - wx0, 0), ax1 = max(xi1 - wx0, 0), ay0 = max(yi0 - wy0, 0), ay1 = max(yi1 - wy0, 0);
+            tr.o00 = (ay0 * Ww + ax0) * C; tr.o01 = (ay0 * Ww + ax1) * C;
+            tr.o10 = (ay1 * Ww + ax0) * C; tr.o11 = (ay1 * Ww + ax1) * C;
+          } else {
+            tr.o00 = (yi0 * p.Wf + xi0) * C; tr.o01 = (yi0 * p.Wf + xi1) * C;
+            tr.o10 = (yi1 * p.Wf + xi0) * C; tr.o11 = (yi1 * p.Wf + xi1) * C;
+          }
+        }
+        s_tap[sd * 64 + sp] = tr;
+      }
+      if (tid < 4) s_bbox[bb ^ 1][tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;    // for the next edge
+      if (use_lds) {
+        // window cells x 8 float4, flattened over the workgroup; all loads of a thread are issued before its
+        // first LDS write (one exposed global latency per edge instead of one per float4).  A window row is a
+        // contiguous run of featT, so consecutive threads read consecutive 16-B pieces.
+        constexpr int kStg = kWinCells * 8 / 256;
+        const int nf4 = Ww * Wh * 8;
+        const float inv_w = 1.f / (float)Ww;
+        f32x4 stg[kStg];          // native vector type (HIP's float4 struct arrays end up in scratch)
 #pragma unroll
-        for (int dd = 0; dd < kWDB; ++dd) {
-          const float2 q = s_ixy[ib][dd][cp];
-          const float ix = q.x, iy = q.y;
-          if (ix == ix) {
-            const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
-            const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
-            const float w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f, w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
-            const float w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f, w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
-            const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
-            float4 v00, v01, v10, v11;
-            if (cur.lds) {
-              // clamped coordinates lie inside the window by construction of the bounding box
-              const int ax0 = max(xi0 - cur.x0, 0), ax1 = max(xi1 - cur.x0, 0);
-              const int ay0 = max(yi0 - cur.y0, 0), ay1 = max(yi1 - cur.y0, 0);
-              v00 = *reinterpret_cast<const float4*>(wbase + (ay0 * cur.w + ax0) * C);
-              v01 = *reinterpret_cast<const float4*>(wbase + (ay0 * cur.w + ax1) * C);
-              v10 = *reinterpret_cast<const float4*>(wbase + (ay1 * cur.w + ax0) * C);
-              v11 = *reinterpret_cast<const float4*>(wbase + (ay1 * cur.w + ax1) * C);
-            } else {
-              v00 = *reinterpret_cast<const float4*>(fimg + (yi0 * p.Wf + xi0) * C);
-              v01 = *reinterpret_cast<const float4*>(fimg + (yi0 * p.Wf + xi1) * C);
-              v10 = *reinterpret_cast<const float4*>(fimg + (yi1 * p.Wf + xi0) * C);
-              v11 = *reinterpret_cast<const float4*>(fimg + (yi1 * p.Wf + xi1) * C);
+        for (int k = 0; k < kStg; ++k) {
+          const int i = tid + k * 256;
+          if (i < nf4) {
+            const int cell = i >> 3;
+            const int cy = (int)(((float)cell + 0.5f) * inv_w);      // exact for cell, Ww <= kWinCells
+            const int cx = cell - cy * Ww;
+            stg[k] = *reinterpret_cast<const f32x4*>(fimg + ((size_t)(wy0 + cy) * p.Wf + wx0 + cx) * C + (i & 7) * 4);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kStg; ++k) {
+          const int i = tid + k * 256;
+          if (i < nf4) *reinterpret_cast<f32x4*>(s_win + (size_t)i * 4) = stg[k];
+        }
+      }
+      __syncthreads();
+      // ---- C: gather + accumulate ---------------------------------------------------------------------------------
+      if (nonempty) {
+        const float* tb = (use_lds ? s_win : fimg) + cg * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int dd = 0; dd < kWDB; ++dd) {
+            const TapRec tr = s_tap[dd * 64 + gp + 32 * a];
+            if (tr.o00 >= 0) {
+              const float4 v00 = *reinterpret_cast<const float4*>(tb + tr.o00);
+              const float4 v01 = *reinterpret_cast<const float4*>(tb + tr.o01);
+              const float4 v10 = *reinterpret_cast<const float4*>(tb + tr.o10);
+              const float4 v11 = *reinterpret_cast<const float4*>(tb + tr.o11);
+              float4 s;
+              s.x = v00.x * tr.w00; s.y = v00.y * tr.w00; s.z = v00.z * tr.w00; s.w = v00.w * tr.w00;
+              s.x += v01.x * tr.w01; s.y += v01.y * tr.w01; s.z += v01.z * tr.w01; s.w += v01.w * tr.w01;
+              s.x += v10.x * tr.w10; s.y += v10.y * tr.w10; s.z += v10.z * tr.w10; s.w += v10.w * tr.w10;
+              s.x += v11.x * tr.w11; s.y += v11.y * tr.w11; s.z += v11.z * tr.w11; s.w += v11.w * tr.w11;
+              acc_s[a][dd][0] += s.x; acc_s[a][dd][1] += s.y; acc_s[a][dd][2] += s.z; acc_s[a][dd][3] += s.w;
+              acc_q[a][dd][0] += s.x * s.x; acc_q[a][dd][1] += s.y * s.y;
+              acc_q[a][dd][2] += s.z * s.z; acc_q[a][dd][3] += s.w * s.w;
             }
-            float4 s;
-            s.x = v00.x * w00; s.y = v00.y * w00; s.z = v00.z * w00; s.w = v00.w * w00;
-            s.x += v01.x * w01; s.y += v01.y * w01; s.z += v01.z * w01; s.w += v01.w * w01;
-            s.x += v10.x * w10; s.y += v10.y * w10; s.z += v10.z * w10; s.w += v10.w * w10;
-            s.x += v11.x * w11; s.y += v11.y * w11; s.z += v11.z * w11; s.w += v11.w * w11;
-            acc_s[dd][0] += s.x; acc_s[dd][1] += s.y; acc_s[dd][2] += s.z; acc_s[dd][3] += s.w;
-            acc_q[dd][0] += s.x * s.x; acc_q[dd][1] += s.y * s.y; acc_q[dd][2] += s.z * s.z; acc_q[dd][3] += s.w * s.w;
           }
         }
       }
-      cur = nxt;
     }
   }
-  // ---- variance -> LDS transpose -> store, 4 planes at a time ---------------------------------------------
+  // ---- variance -> LDS transpose -> store (the window buffer becomes the [4 planes][32 ch][64+1 px] tile) --------
   const float cnt = (float)max(ne, 1);
-  float (*s_out)[C][65] = reinterpret_cast<float (*)[C][65]>(&s_win[0][0]);
+  float (*s_out)[C][33] = reinterpret_cast<float (*)[C][33]>(s_win);
 #pragma unroll
-  for (int half = 0; half < kWDB / 4; ++half) {
+  for (int a = 0; a < 2; ++a) {
     __syncthreads();
 #pragma unroll
-    for (int d4 = 0; d4 < 4; ++d4) {
-      const int dd = half * 4 + d4;
+    for (int dd = 0; dd < kWDB; ++dd)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float avg = acc_s[dd][k] / cnt, avg_sq = acc_q[dd][k] / cnt;
-        s_out[d4][cg * 4 + k][cp] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));
+        const float avg = acc_s[a][dd][k] / cnt, avg_sq = acc_q[a][dd][k] / cnt;
+        s_out[dd][cg * 4 + k][gp] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));
       }
-    }
     __syncthreads();
-    const int px = tid & 63;
-    const int gx = tx * kWT + (px & 7), gy = ty * kWT + (px >> 3);
-    if (gx < p.w && gy < p.h) {
-      for (int dc = tid >> 6; dc < 4 * C; dc += 8) {
-        const int d4 = dc / C, c = dc % C, d = d_first + half * 4 + d4;
-        if (d < p.D) p.var[(((size_t)r * C + c) * p.D + d) * P + gy * p.w + gx] = s_out[d4][c][px];
+    const int px = (tid & 31) + 32 * a;                 // pixels of this half tile: rows 4a .. 4a+3
+    const int ogx = tx * kWT + (px & 7), ogy = ty * kWT + (px >> 3);
+    if (ogx < p.w && ogy < p.h) {
+      for (int dc = tid >> 5; dc < nd * C; dc += 8) {
+        const int dd = dc / C, c = dc % C;
+        p.var[(((size_t)r * C + c) * p.D + d_first + dd) * P + ogy * p.w + ogx] = s_out[dd][c][tid & 31];
       }
     }
   }
@@ -568,7 +563,7 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
     const long long wblocks = (long long)n_ref * ((D + kWDB - 1) / kWDB) * pw.ntx * pw.nty;
     V3D_REQUIRE(wblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
     v3d::TimedScope ts("psv_variance", s);
-    psv_variance_win_kernel<<<(unsigned)wblocks, 512, 0, s>>>(pw);
+    psv_variance_win_kernel<<<(unsigned)wblocks, 256, 0, s>>>(pw);
   } else {
     v3d::TimedScope ts("psv_variance", s);
     if (C == 32) psv_variance_kernel<32><<<(unsigned)blocks, kThreads, 0, s>>>(p);
