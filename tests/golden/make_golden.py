@@ -198,8 +198,9 @@ def golden_scene():
         e = torch.tensor([[2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5], [1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6]])
         gt = sc['depth'] + 0.1
         gt[0, :2] = 0.2
+        mets = ref.metrics.calc_2d_depth_metrics(sc['depth'], gt)
         save('H_misc', edges=e, sliced=ref.utils.slice_edges(e.clone(), 3, 5, 0), depth_pred=sc['depth'],
-             depth_gt=gt, abs_rel=ref.metrics.calc_2d_depth_metrics(sc['depth'], gt)['abs_rel'])
+             depth_gt=gt, abs_rel=mets['abs_rel'], **{'met_' + k: v for k, v in mets.items()})
 
 
 if __name__ == '__main__':

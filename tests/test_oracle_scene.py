@@ -196,3 +196,23 @@ def test_upsample_chain_stage3():
         ref = osc.propagation_net(gd, ref, sd)
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     assert out.shape == (3, 32, 40)
+
+
+def test_results_format_and_metrics_next_row(tmp_path):
+    """2D metrics against the reference's calc_2d_depth_metrics golden; preds.npz keys and
+    the intrinsics rescale of mv3d/eval/main.py:74-101."""
+    g = load_golden('H_misc')
+    res = v3d('results')
+    mets = res.depth_metrics_2d(t(g['depth_pred']), t(g['depth_gt']))
+    for k, v in mets.items():
+        np.testing.assert_allclose(float(v), float(g['met_' + k]), rtol=1e-5, atol=1e-8, err_msg=k)
+    Batch = v3d('batch').Batch
+    K = torch.tensor([[[100., 0., 50.], [0., 120., 40.], [0., 0., 1.]]]).repeat(5, 1, 1)
+    b = Batch(torch.zeros(5, 3, 80, 100), torch.eye(3).repeat(5, 1, 1), torch.zeros(5, 3), K, None, None)
+    rec = res.write_preds(str(tmp_path / 'preds.npz'), '/data/scene0707_00', np.ones((3, 40, 50), np.float32), b,
+                          [1, 2, 3], np.arange(100, 105))
+    z = np.load(str(tmp_path / 'preds.npz'))
+    assert sorted(z.files) == ['K', 'depth_preds', 'img_idx', 'rotmats', 'scene', 'tvecs']
+    assert str(z['scene']) == 'scene0707_00' and z['img_idx'].tolist() == [101, 102, 103]
+    np.testing.assert_allclose(z['K'][0], [[50., 0., 25.], [0., 60., 20.], [0., 0., 1.]])
+    assert float(K[1, 0, 0]) == 100.0          # the batch's own intrinsics are left untouched
