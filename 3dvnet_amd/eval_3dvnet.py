@@ -17,6 +17,7 @@ import torch
 
 from .batch import Batch
 from . import utils
+from .mvsnet import edges_to_csr
 
 INIT_DEPTH_BATCH = 18      # eval-3dvnet.py:12-14
 OFFSET_BATCH = 16
@@ -98,16 +99,22 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         edges_local = (utils.slice_edges(batch.ref_src_edges, r0 + k, r1 + k, 0) - r0).to(device)
         depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
         gather_fn = (lambda p, f, b: gather_pointcloud(p, f, b, group)) if world > 1 else None
+        # the chunk edge lists (and their CSR form on the device) are the same for every sweep: build them once
+        chunks = []
+        for b0 in range(0, n_local, offset_batch):
+            b1 = min(b0 + offset_batch, n_local)
+            e = utils.slice_edges(edges_local, b0 + k, b1 + k, 0) - b0
+            chunks.append((b0, b1, e, edges_to_csr(e) if e.is_cuda else None))
         for offsets in offsets_list:
             xs = net.model_scene(all_depth, depth_batch, feats_local, rot, tv, K, edges_local,
                                  gather_fn=gather_fn)
             for offset in offsets:
-                for b0 in range(0, n_local, offset_batch):
-                    b1 = min(b0 + offset_batch, n_local)
-                    e = utils.slice_edges(edges_local, b0 + k, b1 + k, 0) - b0
+                for b0, b1, e, csr in chunks:
+                    kw = {} if csr is None else {'csr': csr}
                     all_depth[b0:b1] += net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
                                                           feats_local[b0:b1 + 2 * k], rot[b0:b1 + 2 * k],
-                                                          tv[b0:b1 + 2 * k], K[b0:b1 + 2 * k], e, offset, 3)
+                                                          tv[b0:b1 + 2 * k], K[b0:b1 + 2 * k], e, offset, 3,
+                                                          **kw)
         if upsample:
             # ---- stage 3 (:101-125): plane grid -> 1/4 -> 1/2 -> full resolution, guided by the quarter /
             # half features and the image of each reference view (images k .. k + n_local of the halo'd slice)

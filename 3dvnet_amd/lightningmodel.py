@@ -16,7 +16,7 @@ from .upsampling import PropagationNet
 
 
 def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges, img_size, offset=0.0,
-                         n=0, workspace=None):
+                         n=0, workspace=None, csr=None):
     """Rows B1-B2 / C1: -> (pts [n_ref*P, 2n+1, 3], var [n_ref*P, 2n+1, C])."""
     if not depth_pred.is_cuda:
         raise _lib.V3DLibraryError('backproject_variance: tensors must live on a HIP device (no CPU fallback)')
@@ -24,7 +24,7 @@ def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges
     dev = depth_pred.device
     feat = img_feats.contiguous().float()
     n_img, C, Hf, Wf = feat.shape
-    _, ref_img, edge_ofs, edge_src = edges_to_csr(ref_src_edges.to(dev))
+    _, ref_img, edge_ofs, edge_src = csr if csr is not None else edges_to_csr(ref_src_edges.to(dev))
     n_ref, h, w = depth_pred.shape
     assert n_ref == ref_img.shape[0], 'one depth map per reference view'
     n_hyp = 2 * n + 1
@@ -66,6 +66,7 @@ class PL3DVNet(nn.Module):
         self.refine_half = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
         self.refine_full = PropagationNet(in_dim=3 + 1, h_dim=32)
         self._ws = _Workspace()
+        self._offset_vals = {}
 
     def make_initial_depth_predictions(self, batch, depth_config):
         """lightningmodel.py:124-130."""
@@ -102,15 +103,19 @@ class PL3DVNet(nn.Module):
         return (xs, pts) if return_pts else xs
 
     def run_pointflow(self, xs, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
-                      offset, n):
-        """lightningmodel.py:187-242 -> offset prediction [n_ref, h, w]."""
+                      offset, n, csr=None):
+        """lightningmodel.py:187-242 -> offset prediction [n_ref, h, w].  ``csr`` (optional) is the result of
+        ``mvsnet.edges_to_csr(ref_src_edges)`` when the caller sweeps the same edge list repeatedly."""
         n_imgs = depth_pred.shape[0]
         n_pts = depth_pred.shape[1] * depth_pred.shape[2]
         pts_hyp, pts_feat = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
                                                  self.hparams.img_size, offset=offset, n=n,
-                                                 workspace=self._ws)
+                                                 workspace=self._ws, csr=csr)
         pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
-        offset_vals = torch.linspace(-n * offset, n * offset, 2 * n + 1)
+        key = (float(offset), int(n), str(depth_pred.device))
+        if key not in self._offset_vals:      # torch.linspace on the CPU then moved, like lightningmodel.py:238-240
+            self._offset_vals[key] = torch.linspace(-n * offset, n * offset, 2 * n + 1).to(depth_pred.device)
+        offset_vals = self._offset_vals[key]
         feats = self.decoder.features(xs, pts_hyp, pts_feat, pts_batch)
         _, expect = self.decoder.decode(feats, offset_vals)
         return expect.view(n_imgs, *depth_pred.shape[1:])
