@@ -24,6 +24,7 @@
 //
 // The final `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
 // and the depth softmax + expectation is a per-pixel streaming reduction.
+#include <cstdlib>
 #include <vector>
 
 #include "v3d_common.h"
@@ -403,6 +404,165 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   }
 }
 
+// ---- conv0 on split-bf16 matrix cores -----------------------------------------------------------------
+// conv0 (32 -> 8 channels at full resolution) carries 68 % of the regulariser's MACs.  bf16 MFMA runs at 16x
+// the fp32-MFMA rate, so every fp32 operand is split x = hi + lo into two bf16 values (hi = RNE(x),
+// lo = RNE(x - hi): 16 mantissa bits together) and the product is evaluated as hi*hi + hi*lo + lo*hi with
+// fp32 accumulation: 3 bf16 MFMAs (K = 32) replace 8 fp32 MFMAs (K = 4).  Measured error of this layer
+// 7e-6 of max|out| (fp32 MFMA: 7e-7) and <= 1e-5 relative on the final depth (gate: 1e-4) -- DESIGN.md.
+// Same pair-mode geometry as the fp32 kernel: rows = 2 x-shifts x 8 output channels; one MFMA covers the 4 x
+// taps of a (kz, ky) kernel row (k = 8*kx' + ci) for a group of 8 input channels.  LDS holds the halo'd tile
+// channel-last in 16-byte slots (8 bf16 of one voxel), one array for hi and one for lo, so a B fragment is
+// a single ds_read_b128; A fragments (weights, split on the host) sit in LDS per channel group.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct C0 {
+  static constexpr int TD = 4, TH = 8, TW = 28, ID = TD + 2, IH = TH + 2, IW = TW + 2;
+  static constexpr int NVOXI = ID * IH * IW;                 // 1800 voxels in the halo'd tile
+  static constexpr int CG = 8, NCH = 32 / CG;                // channels per chunk, chunks
+  static constexpr int SROWS = ID * IH;                      // 60 spatial rows (z, y) of IW voxels
+  static constexpr int NITS = (SROWS + 7) / 8;               // 8 lane groups of 32 lanes per iteration
+  static constexpr int WU32 = 9 * 2 * 64 * 4;                // weight words per chunk (hi + lo fragments)
+  static constexpr int NWIT = WU32 / 256;                    // 18
+  static constexpr int NPAIR = TD * TH * (TW / 2);           // 448 x-pairs
+  static constexpr int NBW = NPAIR / 16 / 4;                 // 7 voxel-pair blocks per wave
+  static constexpr size_t LDS_BYTES = (size_t)NVOXI * 16 * 2 + (size_t)WU32 * 4 + 2 * 64 * 4;
+  static_assert(NPAIR % 64 == 0 && WU32 % 256 == 0, "geometry");
+};
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* const xh = reinterpret_cast<u32x4*>(smem);                           // [NVOXI] hi slots
+  u32x4* const xl = xh + C0::NVOXI;                                           // [NVOXI] lo slots
+  unsigned* const wsu = reinterpret_cast<unsigned*>(xl + C0::NVOXI);          // [WU32] weight fragments
+  int* const rowg = reinterpret_cast<int*>(wsu + C0::WU32);                   // [64] global offset of a spatial row
+  int* const rowd = rowg + 64;                                                // [64] first voxel of the row in the tile
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * C0::TD, oy0 = ty * C0::TH, ox0 = tx * C0::TW;
+  const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
+  const float* inb = p.in + (size_t)n * 32 * in_plane;
+  constexpr int kRowOob = -2147483647 - 1;
+
+  if (tid < 64) {
+    const int rz = tid / C0::IH, ry = tid % C0::IH;
+    const int gz = iz0 + rz, gy = iy0 + ry;
+    const bool ok = tid < C0::SROWS && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+    rowg[tid] = ok ? (gz * p.Hi + gy) * p.Wi + ix0 : kRowOob;
+    rowd[tid] = tid < C0::SROWS ? (rz * C0::IH + ry) * C0::IW : -1;
+  }
+  __syncthreads();
+
+  // per-lane first voxel of each of this wave's pair blocks (+ kq = the x tap this lane supplies)
+  int boff[C0::NBW];
+#pragma unroll
+  for (int j = 0; j < C0::NBW; ++j) {
+    const int v = (wave * C0::NBW + j) * 16 + jn;
+    const int z = v / (C0::TH * (C0::TW / 2)), y = (v / (C0::TW / 2)) % C0::TH, xp = v % (C0::TW / 2);
+    boff[j] = (z * C0::IH + y) * C0::IW + 2 * xp + kq;
+  }
+  f32x4 acc[C0::NBW];
+#pragma unroll
+  for (int j = 0; j < C0::NBW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging role: 32 lanes = x of one spatial row, 8 rows per iteration, 8 channels per lane
+  const int grp = tid >> 5, lx = tid & 31;
+  const int sgx = ix0 + lx;
+  const bool xok = lx < C0::IW;
+  const bool xin = xok && sgx >= 0 && sgx < p.Wi;
+  float pre[C0::NITS][C0::CG];
+  unsigned wreg[C0::NWIT];
+  auto issue = [&](int chunk) __attribute__((always_inline)) {
+    const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
+#pragma unroll
+    for (int it = 0; it < C0::NITS; ++it) {
+      const int g = rowg[it * 8 + grp];
+#pragma unroll
+      for (int c = 0; c < C0::CG; ++c) pre[it][c] = (g != kRowOob && xin) ? inc[(size_t)c * in_plane + g] : 0.f;
+    }
+    const unsigned* wc = reinterpret_cast<const unsigned*>(p.wp) + (size_t)chunk * C0::WU32 + tid;
+#pragma unroll
+    for (int i = 0; i < C0::NWIT; ++i) wreg[i] = wc[i * 256];
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < C0::NITS; ++it) {
+      const int d = rowd[it * 8 + grp];
+      if (d >= 0 && xok) {
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          h[c] = bf16_rne(pre[it][c]);
+          l[c] = bf16_rne(pre[it][c] - __uint_as_float(h[c] << 16));
+        }
+        xh[d + lx] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        xl[d + lx] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C0::NWIT; ++i) wsu[i * 256 + tid] = wreg[i];
+  };
+
+  issue(0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < C0::NCH; ++chunk) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (chunk + 1 < C0::NCH) issue(chunk + 1);
+    const u32x4* wf = reinterpret_cast<const u32x4*>(wsu) + lane;
+#pragma unroll 1
+    for (int kzy = 0; kzy < 9; ++kzy) {
+      const int tapoff = ((kzy / 3) * C0::IH + kzy % 3) * C0::IW;
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, wf[(kzy * 2) * 64]);
+      const bf16x8 a_lo = __builtin_bit_cast(bf16x8, wf[(kzy * 2 + 1) * 64]);
+#pragma unroll
+      for (int j = 0; j < C0::NBW; ++j) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[boff[j] + tapoff]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xl[boff[j] + tapoff]);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1 (same as the fp32 pair mode)
+  const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+  const int sx = kq >> 1, cbase = 4 * (kq & 1);
+#pragma unroll
+  for (int j = 0; j < C0::NBW; ++j) {
+    const int v = (wave * C0::NBW + j) * 16 + jn;
+    const int z = v / (C0::TH * (C0::TW / 2)), y = (v / (C0::TW / 2)) % C0::TH, x = 2 * (v % (C0::TW / 2)) + sx;
+    const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+    if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+    const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cbase + r;
+      float val = acc[j][r] + p.bias[co];
+      if (p.relu) val = fmaxf(val, 0.f);
+      const size_t o = ((size_t)n * 8 + co) * out_plane + sp;
+      if (p.skip) val += p.skip[o];
+      p.out[o] = val;
+    }
+  }
+}
+
 // ---- prob conv (base -> 1 channel, bias, no BN/ReLU; mvsnet.py:152,162) ---------------------------
 // A 1-channel output would waste 15/16 of an MFMA, so this layer is register-blocked VALU work:
 // a workgroup owns a PT_D x PT_H x (PT_XG*PT_RX) output tile; CK input channels of the halo'd tile
@@ -593,10 +753,36 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
 
 }  // namespace
 
+namespace {
+int launch_conv0_bf16(const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
+                      int Di, int Hi, int Wi, hipStream_t s) {
+  ConvParams p;
+  p.in = in; p.wp = wbf; p.bias = bias; p.skip = skip; p.out = out; p.n = n;
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
+  p.ntz = (Di + C0::TD - 1) / C0::TD; p.nty = (Hi + C0::TH - 1) / C0::TH; p.ntx = (Wi + C0::TW - 1) / C0::TW;
+  p.relu = 1;
+  const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
+  V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: bad grid");
+  V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)C0::LDS_BYTES));
+    attr_set = true;
+  }
+  {
+    v3d::TimedScope ts("costreg_conv0", s);
+    conv0_bf16x2_kernel<<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH("conv0_bf16x2_kernel");
+  return V3D_OK;
+}
+}  // namespace
+
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, c0bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -649,6 +835,35 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
               wp[((((size_t)chunk * NT + tap) * C4 + c4) * MB + m) * 64 + lane] = v;
             }
   }
+  {
+    // split-bf16 image of conv0 for conv0_bf16x2_kernel: [chunk 4][kzy 9][hi, lo][lane 64][4 words]
+    const int l = 0;
+    h->c0bf_ofs = reserve((size_t)C0::NCH * C0::WU32);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->c0bf_ofs);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int chunk = 0; chunk < C0::NCH; ++chunk)
+      for (int kzy = 0; kzy < 9; ++kzy)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = lane & 15, kxp = lane >> 4, sx = row >> 3, co = row & 7, kx = kxp - sx;
+          unsigned hi[8], lo[8];
+          for (int e = 0; e < 8; ++e) {
+            const int ci = chunk * 8 + e;
+            float v = 0.f;
+            if (kx >= 0 && kx <= 2) {
+              const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+              v = conv_w[l][((size_t)co * 32 + ci) * 27 + kzy * 3 + kx] * sc;
+            }
+            hi[e] = rne(v);
+            lo[e] = rne(v - up(hi[e]));
+          }
+          for (int part = 0; part < 2; ++part) {
+            const unsigned* src = part ? lo : hi;
+            unsigned* dst = wb + (((size_t)chunk * 9 + kzy) * 2 + part) * 256 + lane * 4;
+            for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+          }
+        }
+  }
   h->prob_w_ofs = reserve((size_t)base * 27);
   memcpy(host.data() + h->prob_w_ofs, prob_w, sizeof(float) * base * 27);
   h->prob_b_ofs = reserve(1);
@@ -673,7 +888,11 @@ static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, c
   const float* wp = h->dev + h->wp_ofs[layer];
   const float* bias = h->dev + h->bias_ofs[layer];
   switch (layer) {
-    case 0: return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+    case 0: {
+      static const bool fp32_path = getenv("V3D_CONV0_FP32") != nullptr;     // developer A/B switch
+      if (fp32_path) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+      return launch_conv0_bf16(in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
+    }
     case 1: return launch_conv<L1>("costreg_conv1", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
     case 2: return launch_conv<L2>("costreg_conv2", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
     case 3: return launch_conv<L3>("costreg_conv3", in, wp, bias, skip, out, n, Di, Hi, Wi, s);

@@ -149,8 +149,10 @@ def test_costreg_single_layers(layer, cuda):
         ref = skip + ref
     out = net.run_layer(layer, x.to(cuda), None if skip is None else skip.to(cuda))
     torch.cuda.synchronize()
-    tol = 1e-5 * max(1.0, float(ref.abs().max()))
-    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=tol)
+    # conv0 runs on split-bf16 matrix cores (operands carry 16 mantissa bits): measured 7e-6 of max|out|;
+    # every other layer is exact-fp32 MFMA
+    tol = (4e-5 if layer == 0 else 1e-5) * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5 if layer else 0, atol=tol)
 
 
 def test_full_size_properties_cfg2_batch(cuda):
