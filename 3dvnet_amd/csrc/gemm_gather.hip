@@ -19,6 +19,7 @@
 // Segments whose row map is empty for the whole tile are skipped (structured sparsity).
 // Epilogue (all optional): + bias, GroupNorm(rows), + residual, ReLU, scatter-max into pool[idx[m]]
 // (order-independent => deterministic), row-major store.
+#include <cstdlib>
 #include <vector>
 
 #include "v3d_common.h"
@@ -26,6 +27,14 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 
 constexpr int kMaxSeg = 27;
 constexpr int kKC = 32;      // K chunk
@@ -60,7 +69,13 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // MBW: channel blocks (16 outputs) per wave (N <= 64 * MBW); NB: 16-row blocks per workgroup tile
 // (tile = 16 * NB rows: 128 for large problems, 32 when M is small so that more workgroups than CUs
 // exist and gather latency is hidden by occupancy).
-template <int MBW, int NB>
+// BF16: operands are split x = hi + lo into two bf16 values (16 mantissa bits together) and a product block is
+// evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- 3 bf16 MFMAs
+// (K = 32) instead of 8 fp32 MFMAs (K = 4), i.e. 5.3x the matrix rate at ~7e-6 relative layer error (the
+// depth gate is 1e-4).  The activation tile is then [row][32 k] bf16 (64 B rows, hi and lo
+// arrays) with the 16-B k-group slot XOR-swizzled by the row so that every ds_read_b128 lane group hits 16
+// distinct slots; weight fragments are split and packed on the host.
+template <int MBW, int NB, bool BF16>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   constexpr int kTM = 16 * NB;
   constexpr int NPASS = (kTM + 31) / 32;      // staging passes of 32 rows
@@ -161,9 +176,22 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
       if (srow + 32 * i < kTM) {
         f32x4 v = xr[i];
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        float* d = xs + (srow + 32 * i) * kXS + sc4;
-        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-        *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        const int row = srow + 32 * i;
+        if constexpr (BF16) {
+          // this thread holds k = sc4 .. sc4+3 of the row: half of the 8-wide k group kg = sc4 / 8
+          const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+          const int slot = kg ^ ((((row & 15) >> 3) & 1) * 3);
+          const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
+          const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
+          const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+          u32x2* xh2 = reinterpret_cast<u32x2*>(xs);
+          xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
+          xh2[((kTM + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+        } else {
+          float* d = xs + row * kXS + sc4;
+          *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+          *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        }
       }
     }
 #pragma unroll
@@ -190,17 +218,40 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
         if (a + 2 < nact) rows_of(s_list[a + 2], rnxt);       // one whole segment ahead of its first use
       }
       // ---- MFMA ------------------------------------------------------------------------------------------
+      if constexpr (BF16) {
+        const u32x4* wq = reinterpret_cast<const u32x4*>(ws);
+        const u32x4* xq = reinterpret_cast<const u32x4*>(xs);
+        const int bslot = kq ^ (((jn >> 3) & 1) * 3);
+        bf16x8 a_hi[MBW], a_lo[MBW];
 #pragma unroll
-      for (int k4 = 0; k4 < kKC / 4; ++k4) {
-        float a_frag[MBW];
-#pragma unroll
-        for (int m = 0; m < MBW; ++m) a_frag[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
+        for (int m = 0; m < MBW; ++m) {
+          a_hi[m] = __builtin_bit_cast(bf16x8, wq[(wave * MBW + m) * 64 + lane]);
+          a_lo[m] = __builtin_bit_cast(bf16x8, wq[(MB + wave * MBW + m) * 64 + lane]);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const float bv = xs[(nb * 16 + jn) * kXS + k4 * 4 + kq];
+          const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xq[(nb * 16 + jn) * 4 + bslot]);
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xq[(kTM + nb * 16 + jn) * 4 + bslot]);
 #pragma unroll
-          for (int m = 0; m < MBW; ++m)
-            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_frag[m], bv, acc[nb][m], 0, 0, 0);
+          for (int m = 0; m < MBW; ++m) {
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[m], b_hi, acc[nb][m], 0, 0, 0);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[m], b_lo, acc[nb][m], 0, 0, 0);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[m], b_hi, acc[nb][m], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k4 = 0; k4 < kKC / 4; ++k4) {
+          float a_frag[MBW];
+#pragma unroll
+          for (int m = 0; m < MBW; ++m) a_frag[m] = ws[((k4 * MB + wave * MBW + m) * 64) + lane];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float bv = xs[(nb * 16 + jn) * kXS + k4 * 4 + kq];
+#pragma unroll
+            for (int m = 0; m < MBW; ++m)
+              acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_frag[m], bv, acc[nb][m], 0, 0, 0);
+          }
         }
       }
     }
@@ -272,7 +323,7 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 struct v3d_gemm_weights {
   int N, K, KP, n_seg, MBW;
   float* dev;       // packed fragments followed by bias[N] (0 if none), gn_w[N], gn_b[N]
-  size_t bias_ofs, gnw_ofs, gnb_ofs;
+  size_t bias_ofs, gnw_ofs, gnb_ofs, bf_ofs;
   int has_bias, has_gn;
 };
 
@@ -289,7 +340,7 @@ extern "C" int v3d_gemm_pack(const float* w_host, long long stride_seg, long lon
   h->MBW = N > 64 ? 2 : 1;
   const int MB = 4 * h->MBW, nkc = h->KP / kKC;
   const size_t wslab = (size_t)MB * 16 * kKC;
-  std::vector<float> host((size_t)n_seg * nkc * wslab + 3 * 128, 0.f);
+  std::vector<float> host((size_t)n_seg * nkc * wslab + 3 * 128, 0.f);   // grown below for the bf16 image
   for (int s = 0; s < n_seg; ++s)
     for (int kc = 0; kc < nkc; ++kc)
       for (int k4 = 0; k4 < kKC / 4; ++k4)
@@ -306,6 +357,36 @@ extern "C" int v3d_gemm_pack(const float* w_host, long long stride_seg, long lon
   h->bias_ofs = (size_t)n_seg * nkc * wslab;
   h->gnw_ofs = h->bias_ofs + 128;
   h->gnb_ofs = h->gnw_ofs + 128;
+  // split-bf16 image: per (segment, chunk): [hi, lo][MB][64 lanes][4 words]; lane l holds output co = mb*16 + (l & 15),
+  // k = chunk*32 + 8*(l >> 4) + e (e = 0..7, two bf16 per word)
+  h->bf_ofs = h->gnb_ofs + 128;
+  host.resize(h->bf_ofs + (size_t)n_seg * nkc * wslab, 0.f);
+  {
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->bf_ofs);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int s = 0; s < n_seg; ++s)
+      for (int kc = 0; kc < nkc; ++kc)
+        for (int mb = 0; mb < MB; ++mb)
+          for (int lane = 0; lane < 64; ++lane) {
+            unsigned hi[8], lo[8];
+            for (int e = 0; e < 8; ++e) {
+              const int co = mb * 16 + (lane & 15), k = kc * kKC + 8 * (lane >> 4) + e;
+              float v = 0.f;
+              if (co < N && k < K) {
+                v = w_host[s * stride_seg + co * stride_co + k * stride_k];
+                if (scale_host) v *= scale_host[co];
+              }
+              hi[e] = rne(v);
+              lo[e] = rne(v - up(hi[e]));
+            }
+            for (int part = 0; part < 2; ++part) {
+              const unsigned* src = part ? lo : hi;
+              unsigned* dst = wb + (size_t)(s * nkc + kc) * wslab + ((size_t)(part * MB + mb) * 64 + lane) * 4;
+              for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+            }
+          }
+  }
   h->has_bias = bias_host != nullptr;
   h->has_gn = gn_w_host != nullptr && gn_b_host != nullptr;
   for (int i = 0; i < N; ++i) {
@@ -358,15 +439,18 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   const bool small = M < 128 * 1024;           // fewer than ~4 tiles of 128 rows per CU: use 32-row tiles
   const int tm = small ? 32 : 128;
   const unsigned blocks = (unsigned)((M + tm - 1) / tm);
+  static const bool fp32_path = getenv("V3D_GEMM_FP32") != nullptr;    // exact-fp32 MFMA instead of split bf16
+  if (!fp32_path) p.wp = h->dev + h->bf_ofs;
   {
     v3d::TimedScope ts(h->n_seg == 27 ? "sparse_conv_gemm" : h->n_seg == 3 ? "conv1d_gemm" : "linear_gemm", s);
-    if (h->MBW == 2) {
-      if (small) gemm_gather_kernel<2, 2><<<blocks, 256, 0, s>>>(p);
-      else gemm_gather_kernel<2, 8><<<blocks, 256, 0, s>>>(p);
-    } else {
-      if (small) gemm_gather_kernel<1, 2><<<blocks, 256, 0, s>>>(p);
-      else gemm_gather_kernel<1, 8><<<blocks, 256, 0, s>>>(p);
-    }
+#define V3D_GG(MBW_, NB_)                                                                  \
+  do {                                                                                     \
+    if (fp32_path) gemm_gather_kernel<MBW_, NB_, false><<<blocks, 256, 0, s>>>(p);         \
+    else gemm_gather_kernel<MBW_, NB_, true><<<blocks, 256, 0, s>>>(p);                    \
+  } while (0)
+    if (h->MBW == 2) { if (small) V3D_GG(2, 2); else V3D_GG(2, 8); }
+    else { if (small) V3D_GG(1, 2); else V3D_GG(1, 8); }
+#undef V3D_GG
   }
   V3D_CHECK_LAUNCH("gemm_gather_kernel");
   return V3D_OK;
