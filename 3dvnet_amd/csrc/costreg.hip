@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
 
-  int b = blockIdx.x;
+  int b = v3d::xcd_contiguous_block();     // neighbouring tiles (shared halo) on the same XCD's L2
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
@@ -436,6 +436,9 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// SPLIT_IN: `p.in` is the split-bf16 volume written by psv_variance_kernel<32, true>
+// ([n][4 chunks][hi, lo][D][H][W] 16-byte slots): staging is then 16-byte copies, no conversion.
+template <bool SPLIT_IN>
 __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);                           // [NVOXI] hi slots
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
-  int b = blockIdx.x;
+  int b = v3d::xcd_contiguous_block();     // neighbouring tiles (shared halo) on the same XCD's L2
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
@@ -484,33 +487,57 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   const int sgx = ix0 + lx;
   const bool xok = lx < C0::IW;
   const bool xin = xok && sgx >= 0 && sgx < p.Wi;
-  float pre[C0::NITS][C0::CG];
+  constexpr int NITS_S = (2 * C0::SROWS + 7) / 8;               // split input: 60 hi rows then 60 lo rows
+  float pre[SPLIT_IN ? 1 : C0::NITS][C0::CG];
+  u32x4 pres[SPLIT_IN ? NITS_S : 1];
   unsigned wreg[C0::NWIT];
+  const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * 8 * in_plane + lx;
   auto issue = [&](int chunk) __attribute__((always_inline)) {
-    const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
+    if constexpr (SPLIT_IN) {
 #pragma unroll
-    for (int it = 0; it < C0::NITS; ++it) {
-      const int g = rowg[it * 8 + grp];
+      for (int it = 0; it < NITS_S; ++it) {
+        const int rr = it * 8 + grp;
+        const int part = rr >= C0::SROWS ? 1 : 0;
+        const int g = rowg[rr - part * C0::SROWS];             // rows 60..63 of the table are out of range
+        pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin)
+                       ? __builtin_nontemporal_load(ins + (size_t)(chunk * 2 + part) * in_plane + g)
+                       : (u32x4){0u, 0u, 0u, 0u};
+      }
+    } else {
+      const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
 #pragma unroll
-      for (int c = 0; c < C0::CG; ++c) pre[it][c] = (g != kRowOob && xin) ? inc[(size_t)c * in_plane + g] : 0.f;
+      for (int it = 0; it < C0::NITS; ++it) {
+        const int g = rowg[it * 8 + grp];
+#pragma unroll
+        for (int c = 0; c < C0::CG; ++c) pre[it][c] = (g != kRowOob && xin) ? inc[(size_t)c * in_plane + g] : 0.f;
+      }
     }
     const unsigned* wc = reinterpret_cast<const unsigned*>(p.wp) + (size_t)chunk * C0::WU32 + tid;
 #pragma unroll
     for (int i = 0; i < C0::NWIT; ++i) wreg[i] = wc[i * 256];
   };
   auto commit = [&]() __attribute__((always_inline)) {
+    if constexpr (SPLIT_IN) {
 #pragma unroll
-    for (int it = 0; it < C0::NITS; ++it) {
-      const int d = rowd[it * 8 + grp];
-      if (d >= 0 && xok) {
-        unsigned h[8], l[8];
+      for (int it = 0; it < NITS_S; ++it) {
+        const int rr = it * 8 + grp;
+        const int part = rr >= C0::SROWS ? 1 : 0;
+        if (rr < 2 * C0::SROWS && xok) (part ? xl : xh)[rowd[rr - part * C0::SROWS] + lx] = pres[it];
+      }
+    } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          h[c] = bf16_rne(pre[it][c]);
-          l[c] = bf16_rne(pre[it][c] - __uint_as_float(h[c] << 16));
+      for (int it = 0; it < C0::NITS; ++it) {
+        const int d = rowd[it * 8 + grp];
+        if (d >= 0 && xok) {
+          unsigned h[8], l[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            h[c] = bf16_rne(pre[it][c]);
+            l[c] = bf16_rne(pre[it][c] - __uint_as_float(h[c] << 16));
+          }
+          xh[d + lx] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+          xl[d + lx] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
         }
-        xh[d + lx] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-        xl[d + lx] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
       }
     }
 #pragma unroll
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict_
   __shared__ float xs[PT_CK * PT_PLANE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
+  int b = v3d::xcd_contiguous_block();     // neighbouring tiles (shared halo) on the same XCD's L2
   const int tx = b % ntx; b /= ntx;
   const int ty = b % nty; b /= nty;
   const int tz = b % ntz;
@@ -664,6 +691,224 @@ __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict_
     for (int i = 0; i < PT_RX; ++i) {
       const int gx = ox0 + cxg * PT_RX + i;
       if (gx < W) o[gx] = acc[i] + bsv;
+    }
+  }
+}
+
+// ---- conv9 + prob fused (mvsnet.py:161-162): x_reg = prob(conv0 + ReLU(BN(deconv9(u8)))) --------------------
+// The 8-channel full-resolution tensor between the last deconvolution and the 1-channel prob conv (308 MB per
+// 32 references, written once and read once) never leaves the CU: a workgroup owns a 4 x 8 x 28 tile of the
+// prob output, computes the deconvolution on the tile + 1 halo (6 x 10 x 30) with split-bf16 MFMAs, adds the
+// conv0 skip, parks the result in LDS and runs the 3x3x3x8 prob conv from there.
+//
+// Deconvolution as a GEMM over "cells".  ConvTranspose3d(k=3, stride 2, pad 1, output_padding 1) gives
+// out[o] = sum_i in[i] w[o - 2i + 1], so per axis output 2j+1 = in[j] w[2] + in[j+1] w[0] and output 2j+2 =
+// in[j+1] w[1].  Cell j therefore owns outputs (2j+1, 2j+2) and reads inputs (j, j+1); the halo'd tile starts
+// at an odd output, i.e. it is exactly 3 x 5 x 15 cells.  One MFMA tile: 16 columns = the 15 cells of an x row
+// (+1 idle), 16 rows = 2 x parities x 8 output channels, K = 32 = 2 x inputs x 16 input channels; the
+// (z, y) parities / inputs are separate blocks, of which 9 of 16 hold weights (the 27 taps).
+struct C9 {
+  static constexpr int TD = 4, TH = 8, TW = 28;                    // prob output tile
+  static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;      // u9 tile with halo
+  static constexpr int CZ = HD / 2, CY = HH / 2, CX = HW / 2;      // 3 x 5 x 15 cells
+  static constexpr int VZ = CZ + 1, VY = CY + 1, VX = CX + 2;      // 4 x 6 x (16 + 1 idle) input voxels
+  static constexpr int NVOX = VZ * VY * VX;
+  static constexpr int RS = 32;                                    // u9 tile row stride in floats
+  static constexpr int U9_BYTES = 8 * HD * HH * RS * 4;            // 61440
+  static constexpr int IN_BYTES = NVOX * 2 * 16 * 2;               // hi + lo, two 8-channel halves per voxel
+  static constexpr int LDS_BYTES = U9_BYTES > IN_BYTES ? U9_BYTES : IN_BYTES;
+  static constexpr int NCB = CZ * CY;                              // 15 cell rows = MFMA column blocks
+  static constexpr int WU32 = 9 * 2 * 64 * 4;                      // weight image words
+};
+
+struct C9Params {
+  const float* u8;     // [n, 16, D/2, H/2, W/2]
+  const float* c0;     // [n, 8, D, H, W] skip
+  const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)
+  const float* bias9;  // [8] folded BN bias
+  const float* wprob;  // [8, 27]
+  const float* bprob;  // [1]
+  float* out;          // [n, D, H, W]
+  int n, D, H, W, ntz, nty, ntx;
+};
+
+__global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C9::LDS_BYTES];
+  u32x4* const xh = reinterpret_cast<u32x4*>(smem);             // [NVOX][2 halves] hi slots
+  u32x4* const xl = xh + C9::NVOX * 2;                          // lo slots
+  float* const u9s = reinterpret_cast<float*>(smem);            // [8][HD][HH][RS], reuses the input tile
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  int b = v3d::xcd_contiguous_block();
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * C9::TD, oy0 = ty * C9::TH, ox0 = tx * C9::TW;
+  const int D2 = p.D >> 1, H2 = p.H >> 1, W2 = p.W >> 1;
+  const int iz0 = (oz0 >> 1) - 1, iy0 = (oy0 >> 1) - 1, ix0 = (ox0 >> 1) - 1;
+  const size_t in_plane = (size_t)D2 * H2 * W2;
+  const size_t out_plane = (size_t)p.D * p.H * p.W;
+
+  // weight fragments stay in registers: block (tz3, ty3), tz3 = {(pz 0, dz 0), (0, 1), (1, 1)} likewise ty3
+  bf16x8 a_hi[9], a_lo[9];
+  {
+    const u32x4* wq = reinterpret_cast<const u32x4*>(p.wbf) + lane;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      a_hi[i] = __builtin_bit_cast(bf16x8, wq[(i * 2) * 64]);
+      a_lo[i] = __builtin_bit_cast(bf16x8, wq[(i * 2 + 1) * 64]);
+    }
+  }
+
+  // ---- stage the 4 x 6 x 16 x 16ch input tile as split bf16, channel-last ---------------------------------
+  {
+    float v[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int it = tid + 256 * i;
+      const int half = it / 384, vox = it % 384;
+      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
+      const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+      const float* src = p.u8 + ((size_t)n * 16 + half * 8) * in_plane + ((size_t)gz * H2 + gy) * W2 + gx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = ok ? src[(size_t)e * in_plane] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int it = tid + 256 * i;
+      const int half = it / 384, vox = it % 384;
+      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+      unsigned h[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        h[e] = bf16_rne(v[i][e]);
+        l[e] = bf16_rne(v[i][e] - __uint_as_float(h[e] << 16));
+      }
+      const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + half;
+      xh[slot] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      xl[slot] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    }
+    if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
+      const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
+      xh[slot] = (u32x4){0u, 0u, 0u, 0u};
+      xl[slot] = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  __syncthreads();
+
+  // ---- deconvolution: wave w owns cell rows w, w+4, w+8, w+12 --------------------------------------------
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cbi = 0; cbi < 4; ++cbi) {
+    const int cb = wave + 4 * cbi;
+    if (cb < C9::NCB) {
+      const int cz = cb / C9::CY, cy = cb % C9::CY;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int slot = (((cz + dz) * C9::VY + (cy + dy)) * C9::VX + jn + (kq >> 1)) * 2 + (kq & 1);
+          const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[slot]);
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xl[slot]);
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              if ((pz == 0 || dz == 1) && (py == 0 || dy == 1)) {
+                const int blk = (pz == 1 ? 2 : dz) * 3 + (py == 1 ? 2 : dy);
+                f32x4& c = acc[cbi][pz * 2 + py];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[blk], b_hi, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[blk], b_lo, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[blk], b_hi, c, 0, 0, 0);
+              }
+            }
+        }
+    }
+  }
+  __syncthreads();      // the input tile is dead: its LDS becomes the u9 tile
+
+  // ---- BN bias + ReLU + conv0 skip -> u9 tile (zero outside the volume = the prob conv's padding) ------------
+  {
+    const int px = kq >> 1, cbase = 4 * (kq & 1);
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias9[cbase + r];
+    const float* skip = p.c0 + ((size_t)n * 8 + cbase) * out_plane;
+#pragma unroll
+    for (int cbi = 0; cbi < 4; ++cbi) {
+      const int cb = wave + 4 * cbi;
+      if (cb < C9::NCB) {
+        const int cz = cb / C9::CY, cy = cb % C9::CY;
+        // all 16 skip values of the step are requested before any is used (clamped addresses, no branches)
+        float sk[4][4];
+        bool inside[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
+          inside[rb] = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
+          const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sk[rb][r] = skip[(size_t)r * out_plane + sp];
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int hz = 2 * cz + (rb >> 1), hy = 2 * cy + (rb & 1), hx = 2 * jn + px;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float val = inside[rb] ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + sk[rb][r] : 0.f;
+            if (jn < C9::CX) u9s[((cbase + r) * (C9::HD * C9::HH) + hz * C9::HH + hy) * C9::RS + hx] = val;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // 16 skip loads in flight per step, not 64 (address registers)
+    }
+  }
+  __syncthreads();
+
+  // ---- prob conv: thread = (z = wave, y, 4 consecutive x) --------------------------------------------------
+  {
+    const int y = lane >> 3, xg = lane & 7;
+    if (xg < C9::TW / 4) {
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 1
+      for (int ch = 0; ch < 8; ++ch) {
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* row = u9s + (ch * (C9::HD * C9::HH) + (wave + kz) * C9::HH + (y + ky)) * C9::RS + 4 * xg;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row);
+            const float2 c = *reinterpret_cast<const float2*>(row + 4);
+            const float* wk = p.wprob + ch * 27 + (kz * 3 + ky) * 3;          // wave-uniform -> s_load
+            const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+            o0 += a.x * w0 + a.y * w1 + a.z * w2;
+            o1 += a.y * w0 + a.z * w1 + a.w * w2;
+            o2 += a.z * w0 + a.w * w1 + c.x * w2;
+            o3 += a.w * w0 + c.x * w1 + c.y * w2;
+          }
+        }
+      }
+      const int gz = oz0 + wave, gy = oy0 + y, gx = ox0 + 4 * xg;
+      if (gz < p.D && gy < p.H && gx < p.W) {
+        const float bsv = p.bprob[0];
+        float* o = p.out + (size_t)n * out_plane + ((size_t)gz * p.H + gy) * p.W + gx;
+        if (gx + 3 < p.W) {
+          *reinterpret_cast<f32x4*>(o) = (f32x4){o0 + bsv, o1 + bsv, o2 + bsv, o3 + bsv};
+        } else {
+          o[0] = o0 + bsv;
+          if (gx + 1 < p.W) o[1] = o1 + bsv;
+          if (gx + 2 < p.W) o[2] = o2 + bsv;
+        }
+      }
     }
   }
 }
@@ -754,7 +999,7 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
 }  // namespace
 
 namespace {
-int launch_conv0_bf16(const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
+int launch_conv0_bf16(bool split_in, const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
                       int Di, int Hi, int Wi, hipStream_t s) {
   ConvParams p;
   p.in = in; p.wp = wbf; p.bias = bias; p.skip = skip; p.out = out; p.n = n;
@@ -766,13 +1011,16 @@ int launch_conv0_bf16(const float* in, const float* wbf, const float* bias, cons
   V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
   static bool attr_set = false;
   if (!attr_set) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)C0::LDS_BYTES));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
     attr_set = true;
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-    conv0_bf16x2_kernel<<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    if (split_in) conv0_bf16x2_kernel<true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else conv0_bf16x2_kernel<false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH("conv0_bf16x2_kernel");
   return V3D_OK;
@@ -782,7 +1030,7 @@ int launch_conv0_bf16(const float* in, const float* wbf, const float* bias, cons
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, c0bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, c0bf_ofs, c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -864,6 +1112,35 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
           }
         }
   }
+  {
+    // split-bf16 image of conv9 for conv9_prob_kernel: [block 9][hi, lo][lane 64][4 words]; block = tz3 * 3 + ty3 with
+    // t?3 = {(parity 0, input 0), (0, 1), (1, 1)} <-> kernel tap {2, 0, 1}; rows = x parity * 8 + co, k = x input * 16 + ci
+    const int l = 9;
+    h->c9bf_ofs = reserve((size_t)C9::WU32);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->c9bf_ofs);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    static const int tap3[3] = {2, 0, 1};
+    for (int blk = 0; blk < 9; ++blk)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, px = m >> 3, co = m & 7, kq = lane >> 4, dx = kq >> 1;
+        const int kz = tap3[blk / 3], ky = tap3[blk % 3];
+        const int kx = px == 0 ? (dx == 0 ? 2 : 0) : (dx == 1 ? 1 : -1);
+        const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+        unsigned hi[8], lo[8];
+        for (int e = 0; e < 8; ++e) {
+          const int ci = (kq & 1) * 8 + e;
+          const float v = kx < 0 ? 0.f : conv_w[l][((size_t)ci * 8 + co) * 27 + kz * 9 + ky * 3 + kx] * sc;
+          hi[e] = rne(v);
+          lo[e] = rne(v - up(hi[e]));
+        }
+        for (int part = 0; part < 2; ++part) {
+          const unsigned* src = part ? lo : hi;
+          unsigned* dst = wb + ((size_t)blk * 2 + part) * 256 + lane * 4;
+          for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+        }
+      }
+  }
   h->prob_w_ofs = reserve((size_t)base * 27);
   memcpy(host.data() + h->prob_w_ofs, prob_w, sizeof(float) * base * 27);
   h->prob_b_ofs = reserve(1);
@@ -891,7 +1168,7 @@ static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, c
     case 0: {
       static const bool fp32_path = getenv("V3D_CONV0_FP32") != nullptr;     // developer A/B switch
       if (fp32_path) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
-      return launch_conv0_bf16(in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
+      return launch_conv0_bf16(false, in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
     }
     case 1: return launch_conv<L1>("costreg_conv1", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
     case 2: return launch_conv<L2>("costreg_conv2", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
@@ -933,10 +1210,10 @@ extern "C" size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights*, int n_
   return plan_ws(n_ref, D, h, w).total;
 }
 
-extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var,
-                                     const float* depth_vals, int n, int D, int H, int W,
-                                     float* depth, float* reg, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const float* var,
+                              const float* depth_vals, int n, int D, int H, int W,
+                              float* depth, float* reg, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(h && var && depth_vals && depth && workspace, V3D_ERR_BAD_ARG,
               "v3d_costreg_depth_f32: null argument");
   V3D_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0,
@@ -951,7 +1228,13 @@ extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* 
   int rc;
 #define RUN(layer, in, skip, out, d, hh, ww) \
   if ((rc = run_layer(h, layer, in, skip, out, n, d, hh, ww, s)) != V3D_OK) return rc;
-  RUN(0, var, nullptr, F(ws.c0), D, H, W);
+  if (split_in) {
+    if ((rc = launch_conv0_bf16(true, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], nullptr, F(ws.c0), n, D, H,
+                                W, s)) != V3D_OK)
+      return rc;
+  } else {
+    RUN(0, var, nullptr, F(ws.c0), D, H, W);
+  }
   RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
   RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
   RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
@@ -960,15 +1243,31 @@ extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* 
   RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
   RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
   RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
-  RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
-#undef RUN
-  {
-    v3d::TimedScope ts("costreg_prob", s);
-    const int ntz = (D + PT_D - 1) / PT_D, nty = (H + PT_H - 1) / PT_H, ntx = (W + PT_W - 1) / PT_W;
-    prob_conv_kernel<8><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(
-        F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
+  static const bool unfused9 = getenv("V3D_CONV9_UNFUSED") != nullptr;      // developer A/B switch
+  if (!unfused9) {
+    C9Params q;
+    q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
+    q.wprob = h->dev + h->prob_w_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
+    q.n = n; q.D = D; q.H = H; q.W = W;
+    q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
+    const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
+    V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
+    {
+      v3d::TimedScope ts("costreg_conv9_prob", s);
+      conv9_prob_kernel<<<(unsigned)blocks, 256, 0, s>>>(q);
+    }
+    V3D_CHECK_LAUNCH("conv9_prob_kernel");
+  } else {
+    RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
+    {
+      v3d::TimedScope ts("costreg_prob", s);
+      const int ntz = (D + PT_D - 1) / PT_D, nty = (H + PT_H - 1) / PT_H, ntx = (W + PT_W - 1) / PT_W;
+      prob_conv_kernel<8><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(
+          F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
+    }
+    V3D_CHECK_LAUNCH("prob_conv_kernel");
   }
-  V3D_CHECK_LAUNCH("prob_conv_kernel");
+#undef RUN
   const size_t npix = (size_t)n * H * W;
   {
     v3d::TimedScope ts("soft_argmin", s);
@@ -976,4 +1275,17 @@ extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* 
   }
   V3D_CHECK_LAUNCH("soft_argmin_kernel");
   return V3D_OK;
+}
+
+extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var, const float* depth_vals, int n,
+                                     int D, int H, int W, float* depth, float* reg, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return costreg_depth_impl(false, h, var, depth_vals, n, D, H, W, depth, reg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int v3d_costreg_depth_split(const v3d_costreg_weights* h, const void* var_split, const float* depth_vals,
+                                       int n, int D, int H, int W, float* depth, float* reg, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return costreg_depth_impl(true, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg, workspace,
+                            workspace_bytes, stream);
 }

@@ -67,7 +67,19 @@ struct TapInfo {      // one (pixel, edge) pair, 32 bytes
   int o00, o01, o10, o11;     // element offsets of the 4 taps into featT (already * C); -1 = skip all
 };
 
-template <int C>
+// SPLIT: write the variance as the regulariser's first layer consumes it (costreg.hip, conv0_bf16x2_kernel):
+// every value split x = hi + lo into two bf16, channel-last in 16-byte slots of 8 channels,
+// [n_ref][4 channel groups][hi, lo][D][h][w][8] -- the same 4 bytes per value as fp32, and bit-identical to
+// splitting the fp32 volume later, but conv0 then stages tiles with plain 16-byte copies.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned psv_bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int C, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
   constexpr int LP = C / 4;               // lanes per pixel
   constexpr int PPP = kThreads / LP;      // pixels per phase-2 pass
@@ -75,14 +87,16 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
   static_assert(kPix % PPP == 0, "tile");
 
   __shared__ TapInfo s_tap[kMaxE * kPix];
-  __shared__ float s_out[C][kPix + 1];
+  __shared__ __attribute__((aligned(16))) float s_out[C][kPix + 1];
   __shared__ float s_ref[24];             // Kinv(9) R(9) t(3)
   __shared__ float s_P[kMaxE][12];
 
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  const int ptile = b % p.n_ptile; b /= p.n_ptile;
   const int n_dchunk = (p.D + kDB - 1) / kDB;
+  // every XCD takes a contiguous run of reference views, so its L2 holds the source feature maps of one
+  // reference (~E x 400 KB) instead of all 8 dies streaming the sources of every reference in flight
+  int b = v3d::xcd_contiguous_block();
+  const int ptile = b % p.n_ptile; b /= p.n_ptile;
   const int dchunk = b % n_dchunk;
   const int r = b / n_dchunk;
   const int P = p.h * p.w;
@@ -221,23 +235,53 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
     }
     // ---- variance, transpose through LDS, coalesced store -------------------------------------
     const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
+    if constexpr (SPLIT) {
+      static_assert(!SPLIT || C == 32, "split layout is defined for 32 channels");
+      // s_out reused as [8 groups][kPix + 1] 16-byte slots (the +1 keeps the 4 channel groups off one bank)
+      u32x2* const s_sp = reinterpret_cast<u32x2*>(&s_out[0][0]);
+      const int chunk = cg >> 1, half = cg & 1;
 #pragma unroll
-    for (int a = 0; a < NPASS; ++a) {
-      const int px = a * PPP + pix_in_pass;
+      for (int a = 0; a < NPASS; ++a) {
+        const int px = a * PPP + pix_in_pass;
+        unsigned h[4], l[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float avg = acc_s[a][k] / cnt;
-        float avg_sq = acc_q[a][k] / cnt;
-        s_out[cg * 4 + k][px] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
+        for (int k = 0; k < 4; ++k) {
+          const float avg = acc_s[a][k] / cnt;
+          const float avg_sq = acc_q[a][k] / cnt;
+          const float v = __fsub_rn(avg_sq, __fmul_rn(avg, avg));            // mvsnet.py:216
+          h[k] = psv_bf16_rne(v);
+          l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
+        }
+        s_sp[(((chunk * 2 + 0) * (kPix + 1)) + px) * 2 + half] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        s_sp[(((chunk * 2 + 1) * (kPix + 1)) + px) * 2 + half] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
       }
-    }
-    __syncthreads();
-    {
-      const int px = tid % kPix;
-      const int gp = ptile * kPix + px;
-      if (gp < P) {
-        for (int c = tid / kPix; c < C; c += kThreads / kPix)
-          p.var[(((size_t)r * C + c) * p.D + d) * P + gp] = s_out[c][px];
+      __syncthreads();
+      u32x4* const out = reinterpret_cast<u32x4*>(p.var);
+      const u32x4* const s_q = reinterpret_cast<const u32x4*>(s_sp);
+      for (int i = tid; i < 8 * kPix; i += kThreads) {
+        const int g = i / kPix, px = i % kPix;
+        const int gp = ptile * kPix + px;
+        if (gp < P) __builtin_nontemporal_store(s_q[g * (kPix + 1) + px], &out[(((size_t)r * 8 + g) * p.D + d) * P + gp]);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < NPASS; ++a) {
+        const int px = a * PPP + pix_in_pass;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float avg = acc_s[a][k] / cnt;
+          float avg_sq = acc_q[a][k] / cnt;
+          s_out[cg * 4 + k][px] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
+        }
+      }
+      __syncthreads();
+      {
+        const int px = tid % kPix;
+        const int gp = ptile * kPix + px;
+        if (gp < P) {
+          for (int c = tid / kPix; c < C; c += kThreads / kPix)
+            __builtin_nontemporal_store(s_out[c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
+        }
       }
     }
   }
@@ -514,7 +558,7 @@ extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
   return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256);
 }
 
-extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const float* R,
+static int psv_variance_impl(bool split, const float* feat, const float* K, const float* R,
                                     const float* t, const int32_t* ref_img,
                                     const int32_t* edge_ofs, const int32_t* edge_src, int n_img,
                                     int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
@@ -525,6 +569,8 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
               V3D_ERR_BAD_ARG, "v3d_psv_variance_f32: null pointer argument");
   V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED,
               "v3d_psv_variance_f32: C=%d unsupported (16 or 32)", C);
+  V3D_REQUIRE(!split || C == 32, V3D_ERR_UNSUPPORTED,
+              "v3d_psv_variance_split: C=%d unsupported (the split layout is defined for 32 channels)", C);
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 &&
                   D > 0 && h > 0 && w > 0,
               V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: bad shape");
@@ -556,7 +602,7 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
   // The LDS-window kernel is correct (same parity tests) but currently slower than the gather kernel
   // (2.1-2.9 ms vs 1.3 ms per 32-view launch); it stays opt-in for further work.
   static const bool use_win = getenv("V3D_PSV_WINDOW") != nullptr;
-  if (C == 32 && use_win) {
+  if (C == 32 && use_win && !split) {
     PsvWinParams pw;
     pw.b = p;
     pw.ntx = (w + kWT - 1) / kWT; pw.nty = (h + kWT - 1) / kWT;
@@ -566,9 +612,30 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
     psv_variance_win_kernel<<<(unsigned)wblocks, 256, 0, s>>>(pw);
   } else {
     v3d::TimedScope ts("psv_variance", s);
-    if (C == 32) psv_variance_kernel<32><<<(unsigned)blocks, kThreads, 0, s>>>(p);
-    else psv_variance_kernel<16><<<(unsigned)blocks, kThreads, 0, s>>>(p);
+    const unsigned grid = (unsigned)blocks;
+    if (split) psv_variance_kernel<32, true><<<grid, kThreads, 0, s>>>(p);
+    else if (C == 32) psv_variance_kernel<32, false><<<grid, kThreads, 0, s>>>(p);
+    else psv_variance_kernel<16, false><<<grid, kThreads, 0, s>>>(p);
   }
   V3D_CHECK_LAUNCH("psv_variance_kernel");
   return V3D_OK;
+}
+
+extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const float* R, const float* t,
+                                    const int32_t* ref_img, const int32_t* edge_ofs, const int32_t* edge_src,
+                                    int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                                    double depth_start, double depth_interval, int D, int h, int w, float* var,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return psv_variance_impl(false, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
+                           depth_start, depth_interval, D, h, w, var, workspace, workspace_bytes, stream);
+}
+
+extern "C" int v3d_psv_variance_split(const float* feat, const float* K, const float* R, const float* t,
+                                      const int32_t* ref_img, const int32_t* edge_ofs, const int32_t* edge_src,
+                                      int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                                      double depth_start, double depth_interval, int D, int h, int w,
+                                      void* var_split, void* workspace, size_t workspace_bytes, void* stream) {
+  return psv_variance_impl(true, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
+                           depth_start, depth_interval, D, h, w, (float*)var_split, workspace, workspace_bytes,
+                           stream);
 }

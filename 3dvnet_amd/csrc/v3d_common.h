@@ -62,6 +62,15 @@ struct TimedScope {
   }
 };
 
+// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs (id & 7), each with a
+// private 4 MB L2.  This bijection of [0, gridDim.x) hands every XCD one contiguous run of the logical tile order
+// instead, so neighbouring tiles (shared halos, the same reference view's source maps) meet in the same L2.
+__device__ __forceinline__ int xcd_contiguous_block() {
+  const int total = (int)gridDim.x, per = total >> 3, rem = total & 7;
+  const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+  return x * per + (x < rem ? x : rem) + i;
+}
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 

@@ -135,11 +135,15 @@ class CostRegNet(nn.Module):
     def regularize_depth(self, x, depth_vals, return_reg=False):
         """Rows A5-A6 fused: x [B,Cin,D,h,w] variance volume, depth_vals [D] ->
         depth [B,h,w] (and x_reg [B,D,h,w] when return_reg)."""
-        _require_cuda(x, 'CostRegNet')
+        split = isinstance(x, SplitVariance)
+        _require_cuda(x.data if split else x, 'CostRegNet')
         assert not self.training, 'inference only: BatchNorm is folded with running statistics'
         lib = _lib.load()
-        x = x.contiguous().float()
-        B, C, D, h, w = x.shape
+        if split:
+            (B, C, D, h, w), x = x.shape, x.data
+        else:
+            x = x.contiguous().float()
+            B, C, D, h, w = x.shape
         assert C == self.in_channels
         handle = self.packed_handle()
         depth = torch.empty((B, h, w), dtype=torch.float32, device=x.device)
@@ -147,10 +151,10 @@ class CostRegNet(nn.Module):
         nbytes = lib.v3d_costreg_workspace_bytes(handle, B, D, h, w)
         ws = self._ws.get('costreg', nbytes, x.device)
         depth_vals = depth_vals.to(device=x.device, dtype=torch.float32).contiguous()
-        rc = lib.v3d_costreg_depth_f32(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w,
-                                       _lib.ptr(depth), _lib.ptr(reg), _lib.ptr(ws), ws.numel(),
-                                       _lib.stream_ptr(x.device))
-        _lib.check(rc, 'v3d_costreg_depth_f32')
+        fn = lib.v3d_costreg_depth_split if split else lib.v3d_costreg_depth_f32
+        rc = fn(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth), _lib.ptr(reg),
+                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        _lib.check(rc, 'v3d_costreg_depth_split' if split else 'v3d_costreg_depth_f32')
         return (depth, reg) if return_reg else depth
 
     def run_layer(self, layer, x, skip=None):
@@ -196,10 +200,25 @@ def edges_to_csr(ref_src_edges):
     return ref_idx, ref_idx.to(torch.int32).contiguous(), edge_ofs, edge_src
 
 
+class SplitVariance:
+    """The variance volume in the regulariser's private input format (include/v3d.h,
+    v3d_psv_variance_split): every fp32 value stored as a bf16 hi + bf16 lo pair, channel-last in
+    16-byte slots.  Same bytes as the fp32 volume and the same numbers conv0 would derive from it;
+    only `CostRegNet.regularize_depth` consumes it."""
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @property
+    def device(self):
+        return self.data.device
+
+
 def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, depth_start,
                          depth_interval, n_planes, img_size, depth_img_size, workspace=None,
-                         csr=None):
-    """Rows A1-A4 (mvsnet.py:186-216): variance cost volume [n_ref, C, D, h, w]."""
+                         csr=None, split=False):
+    """Rows A1-A4 (mvsnet.py:186-216): variance cost volume [n_ref, C, D, h, w]
+    (`split=True`: the same volume as a `SplitVariance`, C == 32 only)."""
     _require_cuda(features_quarter, 'plane_sweep_variance')
     lib = _lib.load()
     feat = features_quarter.contiguous().float()
@@ -214,14 +233,13 @@ def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, dep
     nbytes = lib.v3d_psv_workspace_bytes(n_img, C, Hf, Wf)
     ws = (workspace or _Workspace()).get('psv', nbytes, dev)
     Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
-    rc = lib.v3d_psv_variance_f32(_lib.ptr(feat), _lib.ptr(Kc), _lib.ptr(Rc), _lib.ptr(tc),
-                                  _lib.ptr(ref_img), _lib.ptr(edge_ofs), _lib.ptr(edge_src),
-                                  n_img, n_ref, n_edges, C, Hf, Wf, int(img_size[0]),
-                                  int(img_size[1]), float(depth_start), float(depth_interval),
-                                  int(n_planes), int(h), int(w), _lib.ptr(var), _lib.ptr(ws),
-                                  ws.numel(), _lib.stream_ptr(dev))
-    _lib.check(rc, 'v3d_psv_variance_f32')
-    return var
+    fn = lib.v3d_psv_variance_split if split else lib.v3d_psv_variance_f32
+    rc = fn(_lib.ptr(feat), _lib.ptr(Kc), _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(ref_img),
+            _lib.ptr(edge_ofs), _lib.ptr(edge_src), n_img, n_ref, n_edges, C, Hf, Wf, int(img_size[0]),
+            int(img_size[1]), float(depth_start), float(depth_interval), int(n_planes), int(h), int(w),
+            _lib.ptr(var), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, 'v3d_psv_variance_split' if split else 'v3d_psv_variance_f32')
+    return SplitVariance(var, var.shape) if split else var
 
 
 class MVSNet(nn.Module):
@@ -255,10 +273,14 @@ class MVSNet(nn.Module):
 
     def cost_volume_depth(self, features_quarter, batch, depth_start, depth_interval, n_planes,
                           depth_img_size, return_intermediates=False, csr=None):
-        """Rows A1-A6 from quarter-resolution features."""
+        """Rows A1-A6 from quarter-resolution features.  Unless the caller asks for the
+        intermediates, the variance volume travels to the regulariser in its split-bf16 input
+        format (identical depth, no conversion pass in conv0)."""
+        split = not return_intermediates and features_quarter.shape[1] == 32
         var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
                                    batch.ref_src_edges, depth_start, depth_interval, n_planes,
-                                   self.img_size, depth_img_size, workspace=self._ws, csr=csr)
+                                   self.img_size, depth_img_size, workspace=self._ws, csr=csr,
+                                   split=split)
         vals = self.depth_values(depth_start, depth_interval, n_planes, var.device)
         if return_intermediates:
             depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True)

@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3  # dense fp32 MFMA == fp32 vector peak
 
 # (Cin, Cout, divisor of D*h*w giving the voxel count the 27*Cin*Cout MACs are spent on): output voxels
@@ -44,13 +45,19 @@ def kernel_roofline(name, avg_ms, shape):
         nbytes = 4.0 * (n_img * C * Hf * Wf + n_ref * C * vox)
         a = nbytes / (avg_ms * 1e-3) / 1e9
         return dict(bound='hbm', achieved=a, peak=PEAK_HBM_GBS, unit='GB/s', frac=a / PEAK_HBM_GBS)
-    if name.startswith('costreg_conv'):
-        ci, co, div = COSTREG_LAYERS[int(name[len('costreg_conv'):])]
+    if name == 'costreg_conv9_prob':
+        # fused deconv9 + skip + prob: reads u8 (16 ch at half resolution) and the conv0 skip (8 ch), writes 1 ch
+        nbytes = 4.0 * n_ref * (16 * (vox // 8) + 8 * vox + vox)
+    elif name.startswith('costreg_conv'):
+        layer = int(name[len('costreg_conv'):])
+        ci, co, div = COSTREG_LAYERS[layer]
         flops = 2.0 * 27 * ci * co * (vox // div) * n_ref
         a = flops / (avg_ms * 1e-3) / 1e12
-        return dict(bound='mfma', achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=a / PEAK_F32_MFMA_TFLOPS)
-    if name == 'costreg_prob':
+        # conv0 runs on bf16 MFMAs with every fp32 product split into 3 bf16 products (hi*hi + hi*lo + lo*hi):
+        # its ceiling in algorithmic FLOPs is the dense bf16 peak / 3; the other layers use fp32 MFMAs
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if layer == 0 else PEAK_F32_MFMA_TFLOPS
+        return dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak)
+    elif name == 'costreg_prob':
         nbytes = 4.0 * n_ref * vox * (8 + 1)
     elif name == 'soft_argmin':
         nbytes = 4.0 * n_ref * (vox + h * w)

@@ -71,6 +71,17 @@ int v3d_psv_variance_f32(const float* feat, const float* K, const float* R, cons
                          double depth_start, double depth_interval, int D, int h, int w,
                          float* var, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same computation, but `var_split` receives the volume in the regulariser's private input format (no
+ * reference counterpart; it only exists to keep the 1.2 GB volume from being re-formatted by the next kernel):
+ * every fp32 value x stored as bf16 hi = RNE(x) and bf16 lo = RNE(x - hi), channel-last in 16-byte slots of
+ * 8 channels, [n_ref][4 channel groups][hi, lo][D][h][w][8].  n_ref*C*D*h*w*4 bytes like `var`; C must be 32.
+ * hi + lo reproduces what conv0's own on-the-fly split of `var` produces, bit for bit. */
+int v3d_psv_variance_split(const float* feat, const float* K, const float* R, const float* t,
+                         const int32_t* ref_img, const int32_t* edge_ofs, const int32_t* edge_src,
+                         int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                         double depth_start, double depth_interval, int D, int h, int w,
+                         void* var_split, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rows A5-A6: CostRegNet (dense 3D-conv U-Net, BatchNorm folded) + soft-argmin depth.
  * Replaces mvsnet.py:133-163 (CostRegNet.forward) and mvsnet.py:219-227.
@@ -98,6 +109,10 @@ void v3d_costreg_free(v3d_costreg_weights* handle);
  *   workspace  >= v3d_costreg_workspace_bytes(...) */
 size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights* handle, int n_ref, int D, int h, int w);
 int v3d_costreg_depth_f32(const v3d_costreg_weights* handle, const float* var,
+                          const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
+                          float* reg, void* workspace, size_t workspace_bytes, void* stream);
+/* As above with the variance volume in the split format written by v3d_psv_variance_split. */
+int v3d_costreg_depth_split(const v3d_costreg_weights* handle, const void* var_split,
                           const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
                           float* reg, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -37,8 +37,40 @@ def _run_hip(net, feat, R, tv, K, edges, depth_cfg, plane_size, dev):
     with torch.no_grad():
         depth, var, reg = net.cost_volume_depth(feat.to(dev), b, float(d0), float(dd), int(D),
                                                 tuple(plane_size), return_intermediates=True)
+        # the product path hands the variance to the regulariser in its split-bf16 input format: same numbers
+        # (conv0 performs the identical hi/lo split on the fp32 volume), so the depth must be bit-identical
+        depth_split = net.cost_volume_depth(feat.to(dev), b, float(d0), float(dd), int(D), tuple(plane_size))
+        if feat.shape[1] == 32:
+            sv = v3d('mvsnet').plane_sweep_variance(feat.to(dev), b.rotmats, b.tvecs, b.K, b.ref_src_edges,
+                                                    float(d0), float(dd), int(D), net.img_size,
+                                                    tuple(plane_size), split=True)
+            assert torch.equal(_decode_split(sv), _split_roundtrip(var))
     torch.cuda.synchronize()
+    assert torch.equal(depth_split, depth), 'split-variance path differs from the fp32-variance path'
     return depth.cpu(), var.cpu(), reg.cpu()
+
+
+def _bf16_rne_bits(x):
+    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff
+
+
+def _split_roundtrip(var):
+    """hi + lo of the fp32 volume, the value the split format stores (include/v3d.h)."""
+    hb = _bf16_rne_bits(var)
+    hi = torch.where(hb >= 0x8000, (hb << 16) - (1 << 32), hb << 16).to(torch.int32).view(torch.float32)
+    lb = _bf16_rne_bits(var - hi)
+    lo = torch.where(lb >= 0x8000, (lb << 16) - (1 << 32), lb << 16).to(torch.int32).view(torch.float32)
+    return hi + lo
+
+
+def _decode_split(sv):
+    """[n][4 groups][hi, lo][D][h][w][8 bf16] -> fp32 [n, 32, D, h, w] as hi + lo."""
+    n, C, D, h, w = sv.shape
+    raw = sv.data.contiguous().view(torch.int16).view(n, 4, 2, D, h, w, 8)
+    f = (raw.to(torch.int32) << 16).view(torch.float32)
+    x = f[:, :, 0] + f[:, :, 1]                                  # [n, 4, D, h, w, 8]
+    return x.permute(0, 1, 5, 2, 3, 4).reshape(n, 32, D, h, w)
 
 
 @pytest.mark.parametrize('name', ['A_tiny_flat', 'A_tiny_sharp', 'A_tiny_rotated'])
