@@ -25,6 +25,7 @@
 // The final `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
 // and the depth softmax + expectation is a per-pixel streaming reduction.
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "v3d_common.h"
@@ -36,6 +37,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // kConvS1 / kConvS2: k3 p1 conv with stride 1 / 2.  kDeconvS2: k3 s2 p1 output_padding-1 transposed
 // conv.  kConvS1Pair: stride-1 conv for COUT == 8 -- the 16 MFMA rows hold 2 x-shifts x 8 output
@@ -43,6 +45,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // kernel does not reach), each voxel block is 16 x-PAIRS: 18 MFMAs per 16 output voxels instead of
 // the 27 a half-empty 16-row tile would cost.
 enum { kConvS1 = 0, kConvS2 = 1, kDeconvS2 = 2, kConvS1Pair = 3 };
+
+#ifdef V3D_PHASE_TIMING
+// developer build only (-DV3D_PHASE_TIMING): wave 0 of every workgroup accumulates the cycles between marks in
+// registers and writes them to its own slot at the end (no atomics: they would stall the memory pipe being timed)
+constexpr int kPhaseSlots = 1 << 16;
+__device__ unsigned long long g_phase[8 * kPhaseSlots];
+#define PHASE_DECL                                  \
+  long long ph_t = __builtin_readcyclecounter();    \
+  long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i)                                   \
+  do {                                                  \
+    long long t_ = __builtin_readcyclecounter();        \
+    ph_acc[i] += t_ - ph_t;                             \
+    ph_t = t_;                                          \
+  } while (0)
+#define PHASE_FLUSH                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < kPhaseSlots)                                                 \
+      for (int i_ = 0; i_ < 8; ++i_) g_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_];   \
+  } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_FLUSH
+#endif
 
 struct ConvParams {
   const float* in;
@@ -203,19 +230,25 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
     for (int i = 0; i < C::NWIT; ++i)
       if (i * 256 + tid < C::WCH) ws[i * 256 + tid] = wreg[i];
   };
+  PHASE_DECL;
   if constexpr (C::PF) pf_issue(0);
+  PHASE_MARK(0);
 
 #pragma unroll 1
   for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
     __syncthreads();
+    PHASE_MARK(1);
     if constexpr (C::PF) {
 #if V3D_ABLATE == 2
       if (chunk == 0) pf_commit();
       __syncthreads();
 #else
       pf_commit();
+      PHASE_MARK(2);
       __syncthreads();
+      PHASE_MARK(3);
       if (chunk + 1 < C::NCHUNK) pf_issue(chunk + 1);
+      PHASE_MARK(4);
 #endif
     } else {
       // batched staging: SU independent rows are in flight per lane before the LDS writes, so
@@ -320,6 +353,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
     }
   }
 
+  PHASE_MARK(5);
   // ---- epilogue: bias, ReLU, skip, store ([n, COUT, Do, Ho, Wo]) -------------------------------
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
   if constexpr (MODE == kDeconvS2) {
@@ -402,6 +436,8 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
       }
     }
   }
+  PHASE_MARK(6);
+  PHASE_FLUSH;
 }
 
 // ---- conv0 on split-bf16 matrix cores -----------------------------------------------------------------
@@ -425,10 +461,8 @@ struct C0 {
   static constexpr int NITS = (SROWS + 7) / 8;               // 8 lane groups of 32 lanes per iteration
   static constexpr int WU32 = 9 * 2 * 64 * 4;                // weight words per chunk (hi + lo fragments)
   static constexpr int NWIT = WU32 / 256;                    // 18
-  static constexpr int NPAIR = TD * TH * (TW / 2);           // 448 x-pairs
-  static constexpr int NBW = NPAIR / 16 / 4;                 // 7 voxel-pair blocks per wave
   static constexpr size_t LDS_BYTES = (size_t)NVOXI * 16 * 2 + (size_t)WU32 * 4 + 2 * 64 * 4;
-  static_assert(NPAIR % 64 == 0 && WU32 % 256 == 0, "geometry");
+  static_assert(WU32 % 256 == 0, "geometry");
 };
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {
@@ -470,17 +504,13 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   }
   __syncthreads();
 
-  // per-lane first voxel of each of this wave's pair blocks (+ kq = the x tap this lane supplies)
-  int boff[C0::NBW];
+  // MFMA role: wave w owns output rows y = 2w, 2w+1 for all TD planes; one column block = the 14 x pairs of a row
+  // (lanes 14, 15 idle), so an input row fetched from LDS feeds up to 3 output planes (z reuse).
+  static_assert(C0::TH == 8 && C0::TW == 28, "wave -> row mapping");
+  constexpr int NACC = C0::TD * 2;
+  f32x4 acc[NACC];
 #pragma unroll
-  for (int j = 0; j < C0::NBW; ++j) {
-    const int v = (wave * C0::NBW + j) * 16 + jn;
-    const int z = v / (C0::TH * (C0::TW / 2)), y = (v / (C0::TW / 2)) % C0::TH, xp = v % (C0::TW / 2);
-    boff[j] = (z * C0::IH + y) * C0::IW + 2 * xp + kq;
-  }
-  f32x4 acc[C0::NBW];
-#pragma unroll
-  for (int j = 0; j < C0::NBW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // staging role: 32 lanes = x of one spatial row, 8 rows per iteration, 8 channels per lane
   const int grp = tid >> 5, lx = tid & 31;
@@ -488,41 +518,50 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   const bool xok = lx < C0::IW;
   const bool xin = xok && sgx >= 0 && sgx < p.Wi;
   constexpr int NITS_S = (2 * C0::SROWS + 7) / 8;               // split input: 60 hi rows then 60 lo rows
+  constexpr int NWQ = (C0::WU32 / 4 + 255) / 256;               // 16-byte weight loads per thread (4.5 -> 5)
   float pre[SPLIT_IN ? 1 : C0::NITS][C0::CG];
   u32x4 pres[SPLIT_IN ? NITS_S : 1];
-  unsigned wreg[C0::NWIT];
+  u32x4 wreg[NWQ];
   const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * 8 * in_plane + lx;
-  auto issue = [&](int chunk) __attribute__((always_inline)) {
+  // The loads of the next chunk are issued in three parts between the MFMA groups of the current chunk: the
+  // vector-memory pipe takes ~16 cycles per 1 KB instruction, which would otherwise stall the wave in front of
+  // its MFMAs for the whole batch (measured 3.3k cycles per chunk).
+  auto issue_part = [&](int chunk, auto part_c) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_c)::value;
     if constexpr (SPLIT_IN) {
+      constexpr int per = (NITS_S + 2) / 3;
 #pragma unroll
-      for (int it = 0; it < NITS_S; ++it) {
+      for (int it = part * per; it < (part + 1) * per && it < NITS_S; ++it) {
         const int rr = it * 8 + grp;
-        const int part = rr >= C0::SROWS ? 1 : 0;
-        const int g = rowg[rr - part * C0::SROWS];             // rows 60..63 of the table are out of range
+        const int hl = rr >= C0::SROWS ? 1 : 0;
+        const int g = rowg[rr - hl * C0::SROWS];               // rows 60..63 of the table are out of range
         pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin)
-                       ? __builtin_nontemporal_load(ins + (size_t)(chunk * 2 + part) * in_plane + g)
+                       ? __builtin_nontemporal_load(ins + (size_t)(chunk * 2 + hl) * in_plane + g)
                        : (u32x4){0u, 0u, 0u, 0u};
       }
     } else {
+      constexpr int per = (C0::NITS + 2) / 3;
       const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
 #pragma unroll
-      for (int it = 0; it < C0::NITS; ++it) {
+      for (int it = part * per; it < (part + 1) * per && it < C0::NITS; ++it) {
         const int g = rowg[it * 8 + grp];
 #pragma unroll
         for (int c = 0; c < C0::CG; ++c) pre[it][c] = (g != kRowOob && xin) ? inc[(size_t)c * in_plane + g] : 0.f;
       }
     }
-    const unsigned* wc = reinterpret_cast<const unsigned*>(p.wp) + (size_t)chunk * C0::WU32 + tid;
+    const u32x4* wc = reinterpret_cast<const u32x4*>(p.wp) + (size_t)chunk * (C0::WU32 / 4) + tid;
+    constexpr int wper = (NWQ + 2) / 3;
 #pragma unroll
-    for (int i = 0; i < C0::NWIT; ++i) wreg[i] = wc[i * 256];
+    for (int i = part * wper; i < (part + 1) * wper && i < NWQ; ++i)
+      wreg[i] = (i * 256 + tid < C0::WU32 / 4) ? wc[i * 256] : (u32x4){0u, 0u, 0u, 0u};
   };
   auto commit = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT_IN) {
 #pragma unroll
       for (int it = 0; it < NITS_S; ++it) {
         const int rr = it * 8 + grp;
-        const int part = rr >= C0::SROWS ? 1 : 0;
-        if (rr < 2 * C0::SROWS && xok) (part ? xl : xh)[rowd[rr - part * C0::SROWS] + lx] = pres[it];
+        const int hl = rr >= C0::SROWS ? 1 : 0;
+        if (rr < 2 * C0::SROWS && xok) (hl ? xl : xh)[rowd[rr - hl * C0::SROWS] + lx] = pres[it];
       }
     } else {
 #pragma unroll
@@ -541,53 +580,114 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < C0::NWIT; ++i) wsu[i * 256 + tid] = wreg[i];
+    for (int i = 0; i < NWQ; ++i)
+      if (i * 256 + tid < C0::WU32 / 4) reinterpret_cast<u32x4*>(wsu)[i * 256 + tid] = wreg[i];
+  };
+  // one ky slice of the 27 taps: the 3 kz weight fragments stay in registers, every input row read from LDS feeds
+  // up to 3 output planes
+  auto mfma_ky = [&](int ky) __attribute__((always_inline)) {
+    const u32x4* wf = reinterpret_cast<const u32x4*>(wsu) + lane;
+    bf16x8 a_hi[3], a_lo[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      a_hi[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2) * 64]);
+      a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
+    }
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy) {
+      const int rowbase = (wave * 2 + yy + ky) * C0::IW + 2 * jn + kq;
+#pragma unroll
+      for (int iz = 0; iz < C0::ID; ++iz) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[rowbase + iz * C0::IH * C0::IW]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xl[rowbase + iz * C0::IH * C0::IW]);
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z = iz - kz;
+          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z * 2 + yy], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z = iz - kz;
+          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z * 2 + yy], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z = iz - kz;
+          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z * 2 + yy], 0, 0, 0);
+        }
+      }
+    }
   };
 
-  issue(0);
+  PHASE_DECL;
+  issue_part(0, std::integral_constant<int, 0>{});
+  issue_part(0, std::integral_constant<int, 1>{});
+  issue_part(0, std::integral_constant<int, 2>{});
+  PHASE_MARK(0);
 #pragma unroll 1
   for (int chunk = 0; chunk < C0::NCH; ++chunk) {
     __syncthreads();
+    PHASE_MARK(1);
     commit();
+    PHASE_MARK(2);
     __syncthreads();
-    if (chunk + 1 < C0::NCH) issue(chunk + 1);
-    const u32x4* wf = reinterpret_cast<const u32x4*>(wsu) + lane;
-#pragma unroll 1
-    for (int kzy = 0; kzy < 9; ++kzy) {
-      const int tapoff = ((kzy / 3) * C0::IH + kzy % 3) * C0::IW;
-      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, wf[(kzy * 2) * 64]);
-      const bf16x8 a_lo = __builtin_bit_cast(bf16x8, wf[(kzy * 2 + 1) * 64]);
+    PHASE_MARK(3);
+    const bool more = chunk + 1 < C0::NCH;
+    if (more) issue_part(chunk + 1, std::integral_constant<int, 0>{});
+    mfma_ky(0);
+    if (more) issue_part(chunk + 1, std::integral_constant<int, 1>{});
+    mfma_ky(1);
+    if (more) issue_part(chunk + 1, std::integral_constant<int, 2>{});
+    mfma_ky(2);
+    PHASE_MARK(5);
+  }
+
+  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1.  The tile goes through LDS ([co][z][y][28 x], co stride
+  // padded by 4 floats against bank conflicts) so that it leaves as 16-byte row segments instead of 32 4-byte
+  // stores per lane.
+  constexpr int OCS = C0::TD * C0::TH * C0::TW + 4;
+  float* const os = reinterpret_cast<float*>(smem);
+  __syncthreads();                 // every wave is done reading the input tile
+  {
+    const int sx = kq >> 1, cbase = 4 * (kq & 1);
+    float bias[4];
 #pragma unroll
-      for (int j = 0; j < C0::NBW; ++j) {
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[boff[j] + tapoff]);
-        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xl[boff[j] + tapoff]);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
+    if (jn < C0::TW / 2) {
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        const int row = (j >> 1) * C0::TH + wave * 2 + (j & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float val = acc[j][r] + bias[r];
+          if (p.relu) val = fmaxf(val, 0.f);
+          os[(cbase + r) * OCS + row * C0::TW + 2 * jn + sx] = val;
+        }
       }
     }
   }
-
-  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1 (same as the fp32 pair mode)
+  __syncthreads();
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
-  const int sx = kq >> 1, cbase = 4 * (kq & 1);
+  constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
 #pragma unroll
-  for (int j = 0; j < C0::NBW; ++j) {
-    const int v = (wave * C0::NBW + j) * 16 + jn;
-    const int z = v / (C0::TH * (C0::TW / 2)), y = (v / (C0::TW / 2)) % C0::TH, x = 2 * (v % (C0::TW / 2)) + sx;
-    const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + x;
+  for (int k = 0; k < (NQ + 255) / 256; ++k) {
+    const int i = k * 256 + tid;
+    if (i >= NQ) break;
+    const int co = i / (C0::TD * C0::TH * QPR), rem = i % (C0::TD * C0::TH * QPR);
+    const int row = rem / QPR, q = rem % QPR;
+    const int gz = oz0 + row / C0::TH, gy = oy0 + row % C0::TH, gx = ox0 + 4 * q;
     if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
-    const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cbase + r;
-      float val = acc[j][r] + p.bias[co];
-      if (p.relu) val = fmaxf(val, 0.f);
-      const size_t o = ((size_t)n * 8 + co) * out_plane + sp;
-      if (p.skip) val += p.skip[o];
-      p.out[o] = val;
+    f32x4 v = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C0::TW + 4 * q);
+    const size_t o = ((size_t)n * 8 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+    if (gx + 3 < p.Wo && (p.Wo & 3) == 0) {
+      if (p.skip) { const f32x4 sk = *reinterpret_cast<const f32x4*>(p.skip + o); v += sk; }
+      *reinterpret_cast<f32x4*>(p.out + o) = v;
+    } else {
+      for (int e = 0; e < 4 && gx + e < p.Wo; ++e) p.out[o + e] = v[e] + (p.skip ? p.skip[o + e] : 0.f);
     }
   }
+  PHASE_MARK(6);
+  PHASE_FLUSH;
 }
 
 // ---- prob conv (base -> 1 channel, bias, no BN/ReLU; mvsnet.py:152,162) ---------------------------
@@ -714,7 +814,7 @@ struct C9 {
   static constexpr int VZ = CZ + 1, VY = CY + 1, VX = CX + 2;      // 4 x 6 x (16 + 1 idle) input voxels
   static constexpr int NVOX = VZ * VY * VX;
   static constexpr int RS = 32;                                    // u9 tile row stride in floats
-  static constexpr int U9_BYTES = 8 * HD * HH * RS * 4;            // 61440
+  static constexpr int U9_BYTES = 8 * HD * HH * RS * 4;            // 61440: [4 channel pairs][HD][HH][RS][2]
   static constexpr int IN_BYTES = NVOX * 2 * 16 * 2;               // hi + lo, two 8-channel halves per voxel
   static constexpr int LDS_BYTES = U9_BYTES > IN_BYTES ? U9_BYTES : IN_BYTES;
   static constexpr int NCB = CZ * CY;                              // 15 cell rows = MFMA column blocks
@@ -726,7 +826,7 @@ struct C9Params {
   const float* c0;     // [n, 8, D, H, W] skip
   const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)
   const float* bias9;  // [8] folded BN bias
-  const float* wprob;  // [8, 27]
+  const float* wprob;  // [4 channel pairs, 27, 2]
   const float* bprob;  // [1]
   float* out;          // [n, D, H, W]
   int n, D, H, W, ntz, nty, ntx;
@@ -752,6 +852,23 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
   const size_t in_plane = (size_t)D2 * H2 * W2;
   const size_t out_plane = (size_t)p.D * p.H * p.W;
 
+  PHASE_DECL;
+  // ---- global reads are requested in batches with clamped addresses (no branches): (a) the 4 x 6 x 16 x 16ch
+  // input tile and the weight fragments now; vmcnt can track 63 loads, so the skip values follow after staging
+  float v[3][8];
+  bool vok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int it = tid + 256 * i;
+    const int half = it / 384, vox = it % 384;
+    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+    const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
+    vok[i] = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+    const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1), xc = min(max(gx, 0), W2 - 1);
+    const float* src = p.u8 + ((size_t)n * 16 + half * 8) * in_plane + ((size_t)zc * H2 + yc) * W2 + xc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = src[(size_t)e * in_plane];
+  }
   // weight fragments stay in registers: block (tz3, ty3), tz3 = {(pz 0, dz 0), (0, 1), (1, 1)} likewise ty3
   bf16x8 a_hi[9], a_lo[9];
   {
@@ -763,42 +880,54 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
     }
   }
 
-  // ---- stage the 4 x 6 x 16 x 16ch input tile as split bf16, channel-last ---------------------------------
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- stage the input tile as split bf16, channel-last ------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int it = tid + 256 * i;
+    const int half = it / 384, vox = it % 384;
+    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = vok[i] ? v[i][e] : 0.f;
+      h[e] = bf16_rne(x);
+      l[e] = bf16_rne(x - __uint_as_float(h[e] << 16));
+    }
+    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + half;
+    xh[slot] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    xl[slot] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+  }
+  if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
+    const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
+    xh[slot] = (u32x4){0u, 0u, 0u, 0u};
+    xl[slot] = (u32x4){0u, 0u, 0u, 0u};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (b) the conv0 skip values of this lane's 64 outputs: in flight during the MFMA phase
+  const int px = kq >> 1, cbase = 4 * (kq & 1);
+  float sk[4][4][4];
   {
-    float v[3][8];
+    const float* skip = p.c0 + ((size_t)n * 8 + cbase) * out_plane;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int it = tid + 256 * i;
-      const int half = it / 384, vox = it % 384;
-      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
-      const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-      const float* src = p.u8 + ((size_t)n * 16 + half * 8) * in_plane + ((size_t)gz * H2 + gy) * W2 + gx;
+    for (int cbi = 0; cbi < 4; ++cbi) {
+      const int cb = min(wave + 4 * cbi, C9::NCB - 1);
+      const int cz = cb / C9::CY, cy = cb % C9::CY;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = ok ? src[(size_t)e * in_plane] : 0.f;
-    }
+      for (int rb = 0; rb < 4; ++rb) {
+        const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
+        const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
+        const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int it = tid + 256 * i;
-      const int half = it / 384, vox = it % 384;
-      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-      unsigned h[8], l[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        h[e] = bf16_rne(v[i][e]);
-        l[e] = bf16_rne(v[i][e] - __uint_as_float(h[e] << 16));
+        for (int r = 0; r < 4; ++r) sk[cbi][rb][r] = skip[(size_t)r * out_plane + sp];
       }
-      const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + half;
-      xh[slot] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-      xl[slot] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-    }
-    if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
-      const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
-      xh[slot] = (u32x4){0u, 0u, 0u, 0u};
-      xl[slot] = (u32x4){0u, 0u, 0u, 0u};
     }
   }
+
+  PHASE_MARK(0);
   __syncthreads();
+  PHASE_MARK(1);
 
   // ---- deconvolution: wave w owns cell rows w, w+4, w+8, w+12 --------------------------------------------
   f32x4 acc[4][4];
@@ -833,84 +962,86 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
         }
     }
   }
+  PHASE_MARK(2);
   __syncthreads();      // the input tile is dead: its LDS becomes the u9 tile
+  PHASE_MARK(3);
 
   // ---- BN bias + ReLU + conv0 skip -> u9 tile (zero outside the volume = the prob conv's padding) ------------
+  // u9 tile layout [4 channel pairs][HD][HH][RS x][2]: a lane's channels (r, r+1) are one 8-byte write, and the
+  // prob conv below multiplies both channels of a pair with one packed FMA.
   {
-    const int px = kq >> 1, cbase = 4 * (kq & 1);
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = p.bias9[cbase + r];
-    const float* skip = p.c0 + ((size_t)n * 8 + cbase) * out_plane;
 #pragma unroll
     for (int cbi = 0; cbi < 4; ++cbi) {
       const int cb = wave + 4 * cbi;
-      if (cb < C9::NCB) {
+      if (cb < C9::NCB && jn < C9::CX) {
         const int cz = cb / C9::CY, cy = cb % C9::CY;
-        // all 16 skip values of the step are requested before any is used (clamped addresses, no branches)
-        float sk[4][4];
-        bool inside[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
-          inside[rb] = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-          const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
-          const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sk[rb][r] = skip[(size_t)r * out_plane + sp];
-        }
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
           const int hz = 2 * cz + (rb >> 1), hy = 2 * cy + (rb & 1), hx = 2 * jn + px;
+          const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+          const bool inside = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          float val[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float val = inside[rb] ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + sk[rb][r] : 0.f;
-            if (jn < C9::CX) u9s[((cbase + r) * (C9::HD * C9::HH) + hz * C9::HH + hy) * C9::RS + hx] = val;
-          }
+          for (int r = 0; r < 4; ++r) val[r] = inside ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + sk[cbi][rb][r] : 0.f;
+#pragma unroll
+          for (int rp = 0; rp < 2; ++rp)
+            *reinterpret_cast<f32x2*>(u9s + ((((cbase >> 1) + rp) * (C9::HD * C9::HH) + hz * C9::HH + hy) * C9::RS + hx) * 2) =
+                (f32x2){val[2 * rp], val[2 * rp + 1]};
         }
       }
-      __builtin_amdgcn_sched_barrier(0);     // 16 skip loads in flight per step, not 64 (address registers)
     }
   }
+  PHASE_MARK(4);
   __syncthreads();
+  PHASE_MARK(5);
 
-  // ---- prob conv: thread = (z = wave, y, 4 consecutive x) --------------------------------------------------
+  // ---- prob conv: thread = (z = wave, y, 4 consecutive x); both channels of a pair per packed FMA -------------
   {
     const int y = lane >> 3, xg = lane & 7;
     if (xg < C9::TW / 4) {
-      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f}, o2 = {0.f, 0.f}, o3 = {0.f, 0.f};
+      const f32x2* wp2 = reinterpret_cast<const f32x2*>(p.wprob);       // [4 pairs][27 taps][2]
 #pragma unroll 1
-      for (int ch = 0; ch < 8; ++ch) {
+      for (int cp = 0; cp < 4; ++cp) {
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
-            const float* row = u9s + (ch * (C9::HD * C9::HH) + (wave + kz) * C9::HH + (y + ky)) * C9::RS + 4 * xg;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(row);
-            const float2 c = *reinterpret_cast<const float2*>(row + 4);
-            const float* wk = p.wprob + ch * 27 + (kz * 3 + ky) * 3;          // wave-uniform -> s_load
-            const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
-            o0 += a.x * w0 + a.y * w1 + a.z * w2;
-            o1 += a.y * w0 + a.z * w1 + a.w * w2;
-            o2 += a.z * w0 + a.w * w1 + c.x * w2;
-            o3 += a.w * w0 + c.x * w1 + c.y * w2;
+            const f32x2* row = reinterpret_cast<const f32x2*>(u9s) +
+                               (cp * (C9::HD * C9::HH) + (wave + kz) * C9::HH + (y + ky)) * C9::RS + 4 * xg;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 2),
+                        q2 = *reinterpret_cast<const f32x4*>(row + 4);
+            const f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w},
+                        a4 = {q2.x, q2.y}, a5 = {q2.z, q2.w};
+            const f32x2* wk = wp2 + (cp * 27 + (kz * 3 + ky) * 3);           // wave-uniform -> s_load
+            const f32x2 w0 = wk[0], w1 = wk[1], w2 = wk[2];
+            o0 += a0 * w0; o0 += a1 * w1; o0 += a2 * w2;
+            o1 += a1 * w0; o1 += a2 * w1; o1 += a3 * w2;
+            o2 += a2 * w0; o2 += a3 * w1; o2 += a4 * w2;
+            o3 += a3 * w0; o3 += a4 * w1; o3 += a5 * w2;
           }
         }
       }
       const int gz = oz0 + wave, gy = oy0 + y, gx = ox0 + 4 * xg;
       if (gz < p.D && gy < p.H && gx < p.W) {
         const float bsv = p.bprob[0];
+        const f32x4 res = {o0.x + o0.y + bsv, o1.x + o1.y + bsv, o2.x + o2.y + bsv, o3.x + o3.y + bsv};
         float* o = p.out + (size_t)n * out_plane + ((size_t)gz * p.H + gy) * p.W + gx;
         if (gx + 3 < p.W) {
-          *reinterpret_cast<f32x4*>(o) = (f32x4){o0 + bsv, o1 + bsv, o2 + bsv, o3 + bsv};
+          *reinterpret_cast<f32x4*>(o) = res;
         } else {
-          o[0] = o0 + bsv;
-          if (gx + 1 < p.W) o[1] = o1 + bsv;
-          if (gx + 2 < p.W) o[2] = o2 + bsv;
+          o[0] = res.x;
+          if (gx + 1 < p.W) o[1] = res.y;
+          if (gx + 2 < p.W) o[2] = res.z;
         }
       }
     }
   }
+  PHASE_MARK(6);
+  PHASE_FLUSH;
 }
 
 // ---- soft-argmin over D (mvsnet.py:219-227): p = softmax(-x), depth = sum_d vals[d] p[d] ----------
@@ -1030,7 +1161,7 @@ int launch_conv0_bf16(bool split_in, const float* in, const float* wbf, const fl
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_b_ofs, c0bf_ofs, c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -1141,6 +1272,13 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
         }
       }
   }
+  {
+    // prob weights for the fused kernel, channel pairs interleaved: [4 pairs][27 taps][2]
+    h->prob_w2_ofs = reserve((size_t)base * 27);
+    for (int cp = 0; cp < 4; ++cp)
+      for (int t = 0; t < 27; ++t)
+        for (int e = 0; e < 2; ++e) host[h->prob_w2_ofs + ((size_t)cp * 27 + t) * 2 + e] = prob_w[(cp * 2 + e) * 27 + t];
+  }
   h->prob_w_ofs = reserve((size_t)base * 27);
   memcpy(host.data() + h->prob_w_ofs, prob_w, sizeof(float) * base * 27);
   h->prob_b_ofs = reserve(1);
@@ -1247,7 +1385,7 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
   if (!unfused9) {
     C9Params q;
     q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
-    q.wprob = h->dev + h->prob_w_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
+    q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
     q.n = n; q.D = D; q.H = H; q.W = W;
     q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
     const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
@@ -1289,3 +1427,15 @@ extern "C" int v3d_costreg_depth_split(const v3d_costreg_weights* h, const void*
   return costreg_depth_impl(true, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg, workspace,
                             workspace_bytes, stream);
 }
+
+#ifdef V3D_PHASE_TIMING
+extern "C" int v3d_debug_phase_read(unsigned long long* out8_host, int n_blocks) {
+  V3D_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)8 * kPhaseSlots);
+  V3D_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_phase), h.size() * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) out8_host[i] = 0;
+  for (int b = 0; b < n_blocks && b < kPhaseSlots; ++b)
+    for (int i = 0; i < 8; ++i) out8_host[i] += h[(size_t)b * 8 + i];
+  return V3D_OK;
+}
+#endif

@@ -15,3 +15,4 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_V
 python $R/profiles/summarize_rocpd.py pmc $T/sq2/r_results.db $O/pmc_sq2.csv
 tail -1 $O/bench_under_rocprof.log | cut -c1-160
 ls -la $O
+python $R/profiles/make_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv 64 $O/traffic.json
