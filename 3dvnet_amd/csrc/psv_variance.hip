@@ -218,10 +218,14 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
           const TapInfo ti = s_tap[e * kPix + px];
           float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ti.o00 >= 0) {
-            const float4 v00 = *reinterpret_cast<const float4*>(p.featT + ti.o00 + cg * 4);
-            const float4 v01 = *reinterpret_cast<const float4*>(p.featT + ti.o01 + cg * 4);
-            const float4 v10 = *reinterpret_cast<const float4*>(p.featT + ti.o10 + cg * 4);
-            const float4 v11 = *reinterpret_cast<const float4*>(p.featT + ti.o11 + cg * 4);
+            // uniform base + zero-extended 32-bit byte offset: the load takes the address as SGPR pair + VGPR
+            // offset, no 64-bit address arithmetic per tap
+            const char* fb = reinterpret_cast<const char*>(p.featT);
+            const unsigned cgb = cg * 16;
+            const float4 v00 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o00 * 4u + cgb));
+            const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o01 * 4u + cgb));
+            const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o10 * 4u + cgb));
+            const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
             s.x = v00.x * ti.w00; s.y = v00.y * ti.w00; s.z = v00.z * ti.w00; s.w = v00.w * ti.w00;
             s.x += v01.x * ti.w01; s.y += v01.y * ti.w01; s.z += v01.z * ti.w01; s.w += v01.w * ti.w01;
             s.x += v10.x * ti.w10; s.y += v10.y * ti.w10; s.z += v10.z * ti.w10; s.w += v10.w * ti.w10;
@@ -574,8 +578,8 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 &&
                   D > 0 && h > 0 && w > 0,
               V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: bad shape");
-  V3D_REQUIRE((size_t)n_img * Hf * Wf * C < (size_t)1 << 31, V3D_ERR_BAD_SHAPE,
-              "v3d_psv_variance_f32: feature tensor exceeds 2^31 elements");
+  V3D_REQUIRE((size_t)n_img * Hf * Wf * C < (size_t)1 << 30, V3D_ERR_BAD_SHAPE,
+              "v3d_psv_variance_f32: feature tensor exceeds 2^30 elements (32-bit byte offsets)");
   V3D_REQUIRE(workspace_bytes >= v3d_psv_workspace_bytes(n_img, C, Hf, Wf),
               V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_psv_variance_f32: workspace %zu < %zu",
               workspace_bytes, v3d_psv_workspace_bytes(n_img, C, Hf, Wf));
