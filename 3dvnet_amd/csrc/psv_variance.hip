@@ -19,6 +19,8 @@
 //   phase 3  the [C][64] tile is transposed through LDS and written as 256-B rows of `var`.
 #include <cstdlib>
 
+#include <vector>
+
 #include "v3d_common.h"
 
 namespace {
@@ -37,6 +39,7 @@ struct PsvParams {
   const int* edge_ofs;
   const int* edge_src;
   float* var;
+  const float* camp;   // [n_img][kCamStride] per-image camera block, see cam_setup_kernel
   int n_img, n_ref, Hf, Wf, H, W, D, h, w, n_ptile;
   double x_step, y_step, z_start, z_step, z_end;
 };
@@ -62,6 +65,67 @@ __global__ __launch_bounds__(256) void transpose_channel_last_kernel(const float
   }
 }
 
+#ifdef V3D_PHASE_TIMING
+// developer build only: per-phase cycle counters, see costreg.hip
+constexpr int kPhaseSlots = 1 << 16;
+__device__ unsigned long long g_psv_phase[8 * kPhaseSlots];
+#define PHASE_DECL                                  \
+  long long ph_t = __builtin_readcyclecounter();    \
+  long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i)                                   \
+  do {                                                  \
+    long long t_ = __builtin_readcyclecounter();        \
+    ph_acc[i] += t_ - ph_t;                             \
+    ph_t = t_;                                          \
+  } while (0)
+#define PHASE_FLUSH                                                                                       \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < kPhaseSlots)                                                     \
+      for (int i_ = 0; i_ < 8; ++i_) g_psv_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_];   \
+  } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_FLUSH
+#endif
+
+// Per-image camera block: [0..8] K^-1, [9..17] R, [18..20] t (used when the image is a reference view) and
+// [24..35] P = K [R|t] (used when it is a source view).
+constexpr int kCamStride = 36;
+
+__global__ void cam_setup_kernel(const float* __restrict__ K, const float* __restrict__ R,
+                                 const float* __restrict__ t, float* __restrict__ camp, int n_img) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n_img) return;
+  const float* Kp = K + img * 9;
+  const float* Rp = R + img * 9;
+  const float* tp = t + img * 3;
+  float* o = camp + img * kCamStride;
+  // K^-1 in fp64 (adjugate / determinant), rounded to f32 (utils.py:103 torch.inverse)
+  double a = Kp[0], bb = Kp[1], c = Kp[2], d = Kp[3], e = Kp[4], f = Kp[5], g = Kp[6], hh = Kp[7], i = Kp[8];
+  double det = a * (e * i - f * hh) - bb * (d * i - f * g) + c * (d * hh - e * g);
+  double id = 1.0 / det;
+  o[0] = (float)((e * i - f * hh) * id);
+  o[1] = (float)((c * hh - bb * i) * id);
+  o[2] = (float)((bb * f - c * e) * id);
+  o[3] = (float)((f * g - d * i) * id);
+  o[4] = (float)((a * i - c * g) * id);
+  o[5] = (float)((c * d - a * f) * id);
+  o[6] = (float)((d * hh - e * g) * id);
+  o[7] = (float)((bb * g - a * hh) * id);
+  o[8] = (float)((a * e - bb * d) * id);
+  for (int k = 0; k < 9; ++k) o[9 + k] = Rp[k];
+  for (int k = 0; k < 3; ++k) o[18 + k] = tp[k];
+  // projection matrix P = K [R|t] (mvsnet.py:196-197)
+  for (int r = 0; r < 3; ++r)
+    for (int j = 0; j < 4; ++j) {
+      float v;
+      if (j < 3) v = Kp[r * 3 + 0] * Rp[0 * 3 + j] + Kp[r * 3 + 1] * Rp[1 * 3 + j] + Kp[r * 3 + 2] * Rp[2 * 3 + j];
+      else v = Kp[r * 3 + 0] * tp[0] + Kp[r * 3 + 1] * tp[1] + Kp[r * 3 + 2] * tp[2];
+      o[24 + r * 4 + j] = v;
+    }
+}
+
 struct TapInfo {      // one (pixel, edge) pair, 32 bytes
   float w00, w01, w10, w11;   // nw, ne, sw, se weights (0 where the tap is out of range)
   int o00, o01, o10, o11;     // element offsets of the 4 taps into featT (already * C); -1 = skip all
@@ -71,6 +135,7 @@ struct TapInfo {      // one (pixel, edge) pair, 32 bytes
 // every value split x = hi + lo into two bf16, channel-last in 16-byte slots of 8 channels,
 // [n_ref][4 channel groups][hi, lo][D][h][w][8] -- the same 4 bytes per value as fp32, and bit-identical to
 // splitting the fp32 volume later, but conv0 then stages tiles with plain 16-byte copies.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -79,8 +144,13 @@ __device__ __forceinline__ unsigned psv_bf16_rne(float x) {
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int C, bool SPLIT>
-__global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
+// THREADS = 64: one wave per workgroup (16 pixels x 4 planes).  The projection, gather and store phases of a
+// workgroup are separated by barriers; with single-wave workgroups the barriers are free and the 24 resident
+// waves of a CU drift apart, so the L1 (the binding resource, busy only during the gather phase) always has some
+// wave gathering.
+template <int C, bool SPLIT, int THREADS>
+__global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
+  constexpr int kThreads = THREADS, kPix = THREADS / 4;
   constexpr int LP = C / 4;               // lanes per pixel
   constexpr int PPP = kThreads / LP;      // pixels per phase-2 pass
   constexpr int NPASS = kPix / PPP;
@@ -104,25 +174,8 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
   const int ne = e_end - e_begin;
   const int ref = p.ref_img[r];
 
-  if (tid == 0) {
-    // K^-1 in fp64 (adjugate / determinant), rounded to f32 (utils.py:103 torch.inverse)
-    const float* Kp = p.K + ref * 9;
-    double a = Kp[0], bb = Kp[1], c = Kp[2], d = Kp[3], e = Kp[4], f = Kp[5], g = Kp[6],
-           hh = Kp[7], i = Kp[8];
-    double det = a * (e * i - f * hh) - bb * (d * i - f * g) + c * (d * hh - e * g);
-    double id = 1.0 / det;
-    s_ref[0] = (float)((e * i - f * hh) * id);
-    s_ref[1] = (float)((c * hh - bb * i) * id);
-    s_ref[2] = (float)((bb * f - c * e) * id);
-    s_ref[3] = (float)((f * g - d * i) * id);
-    s_ref[4] = (float)((a * i - c * g) * id);
-    s_ref[5] = (float)((c * d - a * f) * id);
-    s_ref[6] = (float)((d * hh - e * g) * id);
-    s_ref[7] = (float)((bb * g - a * hh) * id);
-    s_ref[8] = (float)((a * e - bb * d) * id);
-  }
-  if (tid >= 64 && tid < 64 + 9) s_ref[9 + tid - 64] = p.R[ref * 9 + tid - 64];
-  if (tid >= 128 && tid < 128 + 3) s_ref[18 + tid - 128] = p.t[ref * 3 + tid - 128];
+  // K^-1 (9), R (9), t (3) of the reference view, prepared by cam_setup_kernel
+  if (tid < 21) s_ref[tid] = p.camp[ref * kCamStride + tid];
 
   // this thread's phase-2 role
   const int cg = tid % LP;
@@ -141,6 +194,7 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
 
+  PHASE_DECL;
   for (int dd = 0; dd < kDB; ++dd) {
     const int d = dchunk * kDB + dd;
     if (d >= p.D) break;
@@ -155,19 +209,15 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
     for (int ec = 0; ec < ne; ec += kMaxE) {
       const int nec = min(kMaxE, ne - ec);
       __syncthreads();   // previous users of s_tap / s_P / s_out are done; s_ref visible
-      // projection matrices P = K [R|t] of this chunk's source views (mvsnet.py:196-197)
-      if (tid < nec * 12) {
-        int e = tid / 12, ij = tid % 12, i = ij / 4, j = ij % 4;
-        int src = p.edge_src[e_begin + ec + e];
-        const float* Kp = p.K + src * 9;
-        const float* Rp = p.R + src * 9;
-        const float* tp = p.t + src * 3;
-        float v;
-        if (j < 3) v = Kp[i * 3 + 0] * Rp[0 * 3 + j] + Kp[i * 3 + 1] * Rp[1 * 3 + j] + Kp[i * 3 + 2] * Rp[2 * 3 + j];
-        else v = Kp[i * 3 + 0] * tp[0] + Kp[i * 3 + 1] * tp[1] + Kp[i * 3 + 2] * tp[2];
-        s_P[e][ij] = v;
+      PHASE_MARK(0);
+      // projection matrices P = K [R|t] of this chunk's source views (mvsnet.py:196-197); with a single chunk
+      // of edges (the usual case) they are the same for every plane of the workgroup: computed once
+      if (dd == 0 || ne > kMaxE) {
+        for (int i = tid; i < nec * 12; i += kThreads)
+          s_P[i / 12][i % 12] = p.camp[p.edge_src[e_begin + ec + i / 12] * kCamStride + 24 + i % 12];
       }
       __syncthreads();
+      PHASE_MARK(1);
       // ---- phase 1: project (pixel, edge) pairs ------------------------------------------
       {
         // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
@@ -209,7 +259,9 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
           s_tap[e * kPix + px1] = ti;
         }
       }
+      PHASE_MARK(2);
       __syncthreads();
+      PHASE_MARK(3);
       // ---- phase 2: gather + accumulate ----------------------------------------------------
 #pragma unroll
       for (int a = 0; a < NPASS; ++a) {
@@ -237,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
         }
       }
     }
+    PHASE_MARK(4);
     // ---- variance, transpose through LDS, coalesced store -------------------------------------
     const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
     if constexpr (SPLIT) {
@@ -288,9 +341,201 @@ __global__ __launch_bounds__(kThreads) void psv_variance_kernel(PsvParams p) {
         }
       }
     }
+    PHASE_MARK(5);
   }
+  PHASE_FLUSH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Plane-reuse variant (C == 32), the default.  The gather kernel above is bound by L1 bytes: 4 taps x 128 B per
+// (pixel, plane, source view).  But the samples of one pixel on consecutive planes walk along its epipolar line in
+// sub-pixel steps on most of the depth range, so their 2x2 footprints coincide (cfg2: the 16 taps of 4 consecutive
+// planes touch 5.1 distinct cells on average).  Here a single-wave workgroup owns 8 pixels x kDB planes; the 8
+// lanes of a pixel keep the footprint of the previous plane in registers and reload it only when the footprint
+// of the next plane differs, edge by edge.  Arithmetic and accumulation order per (pixel, plane) are those of
+// the gather kernel (bit-identical output).
+constexpr int kRPix = 8;      // pixels per wave
+constexpr int kRE = 2;        // edges per phase-1 pass: kRE x kDB x kRPix = 64 (pixel, plane, edge) items, one per lane
+
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
+  constexpr int C = 32;
+  __shared__ TapInfo s_tap[kRE * kDB * kRPix];
+  __shared__ __attribute__((aligned(16))) float s_out[kDB][C][kRPix + 1];
+  __shared__ float s_ref[24];
+  __shared__ float s_P[kMaxE][12];        // projection matrices of up to kMaxE consecutive edges
+  __shared__ int s_base[kMaxE];           // first feature cell of their source images
+
+  const int lane = threadIdx.x;
+  const int n_dchunk = (p.D + kDB - 1) / kDB;
+  int b = v3d::xcd_contiguous_block();
+  const int ptile = b % p.n_ptile; b /= p.n_ptile;
+  const int dchunk = b % n_dchunk;
+  const int r = b / n_dchunk;
+  const int P = p.h * p.w;
+  const int e_begin = p.edge_ofs[r], e_end = p.edge_ofs[r + 1];
+  const int ne = e_end - e_begin;
+  const int ref = p.ref_img[r];
+  if (lane < 21) s_ref[lane] = p.camp[ref * kCamStride + lane];
+  __syncthreads();
+
+  // phase-1 role: lane = (edge slot, plane, pixel); the world point of (pixel, plane) is the same for every edge
+  const int e1 = lane >> 5, pl1 = (lane >> 3) & 3, px1 = lane & 7;
+  const int gp1 = ptile * kRPix + px1;
+  const int d1 = dchunk * kDB + pl1;
+  float X, Y, Z;
+  {
+    const int gy = gp1 / p.w, gx = gp1 % p.w;
+    // numpy.linspace(0, W-1, w, dtype=float32): float64 arithmetic, last sample = stop
+    const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
+    const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
+    const float z = (d1 == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d1 * p.z_step);
+    // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
+    const float p0 = xf * z, p1 = yf * z, p2 = z;
+    const float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
+    const float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
+    const float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
+    X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
+    Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
+    Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+  }
+  const bool live1 = gp1 < P && d1 < p.D;
+  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+
+  // gather role: 8 lanes x float4 per pixel
+  const int gpx = lane >> 3;
+  const unsigned cgb = (lane & 7) * 16;
+  const char* const fb = reinterpret_cast<const char*>(p.featT);
+  f32x4 acc_s[kDB], acc_q[kDB];
+#pragma unroll
+  for (int k = 0; k < kDB; ++k) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  PHASE_DECL;
+  for (int ec = 0; ec < ne; ec += kRE) {
+    const int nec = min(kRE, ne - ec);
+    __syncthreads();                       // the previous pass is done with s_tap / s_P
+    PHASE_MARK(0);
+    if (ec % kMaxE == 0) {
+      const int nload = min(kMaxE, ne - ec) * 12;
+      for (int i = lane; i < nload; i += 64) {
+        const int src = p.edge_src[e_begin + ec + i / 12];
+        s_P[i / 12][i % 12] = p.camp[src * kCamStride + 24 + i % 12];
+        if (i % 12 == 0) s_base[i / 12] = src * p.Hf * p.Wf;
+      }
+      __syncthreads();
+    }
+    if (e1 < nec) {
+      const float* Pm = s_P[ec % kMaxE + e1];
+      const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
+      const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
+      const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+      const float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
+      const float u = qx / zb, v = qy / zb;
+      const float gx = (u / Wm1) * 2.f - 1.f;                    // mvsnet.py:205-206
+      const float gy = (v / Hm1) * 2.f - 1.f;
+      const float ix = ((gx + 1.f) / 2.f) * Wfm1;                // grid_sample, align_corners=True
+      const float iy = ((gy + 1.f) / 2.f) * Hfm1;
+      const float x0 = floorf(ix), y0 = floorf(iy);
+      const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+      const bool vx0 = (x0 >= 0.f) && (x0 <= Wfm1), vx1 = (x1 >= 0.f) && (x1 <= Wfm1);
+      const bool vy0 = (y0 >= 0.f) && (y0 <= Hfm1), vy1 = (y1 >= 0.f) && (y1 <= Hfm1);
+      TapInfo ti;
+      ti.w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f;
+      ti.w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
+      ti.w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f;
+      ti.w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
+      const bool any = (vx0 || vx1) && (vy0 || vy1) && live1;
+      const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0;
+      const int yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+      const int base = s_base[ec % kMaxE + e1];
+      ti.o00 = any ? (base + yi0 * p.Wf + xi0) * C : -1;
+      ti.o01 = (base + yi0 * p.Wf + xi1) * C;
+      ti.o10 = (base + yi1 * p.Wf + xi0) * C;
+      ti.o11 = (base + yi1 * p.Wf + xi1) * C;
+      s_tap[(e1 * kDB + pl1) * kRPix + px1] = ti;
+    }
+    __syncthreads();
+    PHASE_MARK(1);
+    for (int e = 0; e < nec; ++e) {
+      int c00 = -2, c11 = -2;            // footprint held in t00..t11 (o00 and o11 pin all four cells)
+      f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
+#pragma unroll
+      for (int pl = 0; pl < kDB; ++pl) {
+        const TapInfo ti = s_tap[(e * kDB + pl) * kRPix + gpx];
+        if (ti.o00 >= 0) {
+          if (ti.o00 != c00 || ti.o11 != c11) {
+            t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o00 * 4u + cgb));
+            t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o01 * 4u + cgb));
+            t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o10 * 4u + cgb));
+            t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
+            c00 = ti.o00; c11 = ti.o11;
+          }
+          f32x4 sv = t00 * ti.w00;
+          sv += t01 * ti.w01;
+          sv += t10 * ti.w10;
+          sv += t11 * ti.w11;
+          acc_s[pl] += sv;
+          acc_q[pl] += sv * sv;
+        }
+      }
+    }
+  }
+
+  PHASE_MARK(2);
+  // ---- variance -> LDS -> stores ------------------------------------------------------------------------------
+  __syncthreads();
+  const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
+  const int cg = lane & 7;
+  if constexpr (SPLIT) {
+    // s_out reused as [plane][8 groups][kRPix + 1] 16-byte slots
+    u32x2* const s_sp = reinterpret_cast<u32x2*>(&s_out[0][0][0]);
+    const int chunk = cg >> 1, half = cg & 1;
+#pragma unroll
+    for (int pl = 0; pl < kDB; ++pl) {
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float avg = acc_s[pl][k] / cnt;
+        const float avg_sq = acc_q[pl][k] / cnt;
+        const float v = __fsub_rn(avg_sq, __fmul_rn(avg, avg));            // mvsnet.py:216
+        h[k] = psv_bf16_rne(v);
+        l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
+      }
+      s_sp[(((pl * 8 + chunk * 2 + 0) * (kRPix + 1)) + gpx) * 2 + half] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+      s_sp[(((pl * 8 + chunk * 2 + 1) * (kRPix + 1)) + gpx) * 2 + half] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+    __syncthreads();
+    u32x4* const out = reinterpret_cast<u32x4*>(p.var);
+    const u32x4* const s_q = reinterpret_cast<const u32x4*>(s_sp);
+#pragma unroll
+    for (int k = 0; k < kDB * 8 * kRPix / 64; ++k) {
+      const int i = k * 64 + lane;
+      const int pl = i / (8 * kRPix), g = (i / kRPix) % 8, px = i % kRPix;
+      const int gp = ptile * kRPix + px, d = dchunk * kDB + pl;
+      if (gp < P && d < p.D)
+        __builtin_nontemporal_store(s_q[(pl * 8 + g) * (kRPix + 1) + px], &out[(((size_t)r * 8 + g) * p.D + d) * P + gp]);
+    }
+  } else {
+#pragma unroll
+    for (int pl = 0; pl < kDB; ++pl)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float avg = acc_s[pl][k] / cnt;
+        const float avg_sq = acc_q[pl][k] / cnt;
+        s_out[pl][cg * 4 + k][gpx] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
+      }
+    __syncthreads();
+    for (int i = lane; i < kDB * C * kRPix; i += 64) {
+      const int pl = i / (C * kRPix), c = (i / kRPix) % C, px = i % kRPix;
+      const int gp = ptile * kRPix + px, d = dchunk * kDB + pl;
+      if (gp < P && d < p.D) __builtin_nontemporal_store(s_out[pl][c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
+    }
+  }
+  PHASE_MARK(3);
+  PHASE_FLUSH;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // LDS-window variant (C == 32): one 256-thread workgroup per (reference view, 8x8 plane-grid pixels,
@@ -559,7 +804,9 @@ int v3d::transpose_channel_last(const float* feat, float* featT, int n_img, int 
 }
 
 extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
-  return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256);
+  // channel-last copy of the feature maps + the per-image camera blocks
+  return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256) +
+         v3d::align_up((size_t)n_img * kCamStride * sizeof(float), 256);
 }
 
 static int psv_variance_impl(bool split, const float* feat, const float* K, const float* R,
@@ -585,15 +832,22 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
               workspace_bytes, v3d_psv_workspace_bytes(n_img, C, Hf, Wf));
   hipStream_t s = (hipStream_t)stream;
   float* featT = (float*)workspace;
+  float* camp = (float*)((char*)workspace + v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256));
   v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
   V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
+  cam_setup_kernel<<<(n_img + 63) / 64, 64, 0, s>>>(K, R, t, camp, n_img);
+  V3D_CHECK_LAUNCH("cam_setup_kernel");
 
   PsvParams p;
   p.featT = featT; p.K = K; p.R = R; p.t = t;
-  p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.var = var;
+  p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.var = var; p.camp = camp;
   p.n_img = n_img; p.n_ref = n_ref; p.Hf = Hf; p.Wf = Wf; p.H = H; p.W = W; p.D = D;
   p.h = h; p.w = w;
-  p.n_ptile = (h * w + kPix - 1) / kPix;
+  // workgroup size: single-wave workgroups (16 pixels) unless V3D_PSV_THREADS=256 asks for the 64-pixel variant
+  static const int threads = getenv("V3D_PSV_THREADS") ? atoi(getenv("V3D_PSV_THREADS")) : 64;
+  V3D_REQUIRE(threads == 64 || threads == 256, V3D_ERR_BAD_ARG, "V3D_PSV_THREADS must be 64 or 256");
+  const int pix = threads / 4;
+  p.n_ptile = (h * w + pix - 1) / pix;
   p.x_step = w > 1 ? (double)(W - 1) / (double)(w - 1) : 0.0;
   p.y_step = h > 1 ? (double)(H - 1) / (double)(h - 1) : 0.0;
   const double depth_end = depth_start + (double)(D - 1) * depth_interval;
@@ -617,9 +871,22 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   } else {
     v3d::TimedScope ts("psv_variance", s);
     const unsigned grid = (unsigned)blocks;
-    if (split) psv_variance_kernel<32, true><<<grid, kThreads, 0, s>>>(p);
-    else if (C == 32) psv_variance_kernel<32, false><<<grid, kThreads, 0, s>>>(p);
-    else psv_variance_kernel<16, false><<<grid, kThreads, 0, s>>>(p);
+#define V3D_PSV(C_, SPLIT_)                                                        \
+  do {                                                                             \
+    if (threads == 64) psv_variance_kernel<C_, SPLIT_, 64><<<grid, 64, 0, s>>>(p); \
+    else psv_variance_kernel<C_, SPLIT_, 256><<<grid, 256, 0, s>>>(p);             \
+  } while (0)
+    static const bool plain_gather = getenv("V3D_PSV_GATHER") != nullptr;   // developer A/B switch
+    if (C == 32 && !plain_gather) {
+      const long long rblocks = (long long)n_ref * n_dchunk * ((h * w + kRPix - 1) / kRPix);
+      V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
+      p.n_ptile = (h * w + kRPix - 1) / kRPix;
+      if (split) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
+      else psv_variance_reuse_kernel<false><<<(unsigned)rblocks, 64, 0, s>>>(p);
+    } else if (split) V3D_PSV(32, true);
+    else if (C == 32) V3D_PSV(32, false);
+    else V3D_PSV(16, false);
+#undef V3D_PSV
   }
   V3D_CHECK_LAUNCH("psv_variance_kernel");
   return V3D_OK;
@@ -643,3 +910,15 @@ extern "C" int v3d_psv_variance_split(const float* feat, const float* K, const f
                            depth_start, depth_interval, D, h, w, (float*)var_split, workspace, workspace_bytes,
                            stream);
 }
+
+#ifdef V3D_PHASE_TIMING
+extern "C" int v3d_debug_psv_phase_read(unsigned long long* out8_host, int n_blocks) {
+  V3D_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)8 * kPhaseSlots);
+  V3D_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_psv_phase), h.size() * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) out8_host[i] = 0;
+  for (int b = 0; b < n_blocks && b < kPhaseSlots; ++b)
+    for (int i = 0; i < 8; ++i) out8_host[i] += h[(size_t)b * 8 + i];
+  return V3D_OK;
+}
+#endif

@@ -44,6 +44,13 @@ def main():
         net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
         net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
         fn(buf, n_blocks)
+    fn2 = lib.v3d_debug_psv_phase_read
+    fn2.restype = ctypes.c_int
+    fn2.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    buf2 = (ctypes.c_ulonglong * 8)()
+    nb2 = min(args.refs * 24 * 392, 65536)
+    fn2(buf2, nb2)
+    print('psv cycles per workgroup and phase:', ['%.0f' % (v / nb2) for v in buf2], 'total %.0f' % (sum(buf2) / nb2))
     print('cycles per workgroup and phase:', ['%.0f' % (v / n_blocks) for v in buf], 'total %.0f' % (sum(buf) / n_blocks))
 
 
