@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
 // a single ds_read_b128; A fragments (weights, split on the host) sit in LDS per channel group.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct C0 {
   static constexpr int TD = 4, TH = 8, TW = 28, ID = TD + 2, IH = TH + 2, IW = TW + 2;
@@ -472,7 +473,9 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 
 // SPLIT_IN: `p.in` is the split-bf16 volume written by psv_variance_kernel<32, true>
 // ([n][4 chunks][hi, lo][D][H][W] 16-byte slots): staging is then 16-byte copies, no conversion.
-template <bool SPLIT_IN>
+// SPLIT_OUT: the 8 output channels of a voxel leave as one hi slot and one lo slot of the split channel-last layout
+// ([n][hi, lo][D][H][W] 16-byte slots) consumed by convh_bf16x2_kernel (conv1) and conv9_prob_kernel (skip).
+template <bool SPLIT_IN, bool SPLIT_OUT>
 __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);                           // [NVOXI] hi slots
@@ -668,6 +671,28 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   }
   __syncthreads();
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+  if constexpr (SPLIT_OUT) {
+    constexpr int NV = C0::TD * C0::TH * C0::TW;
+    u32x4* const outs = reinterpret_cast<u32x4*>(p.out) + (size_t)n * 2 * out_plane;
+#pragma unroll
+    for (int k = 0; k < (NV + 255) / 256; ++k) {
+      const int i = k * 256 + tid;
+      if (i >= NV) break;
+      const int row = i / C0::TW, x = i % C0::TW;
+      const int gz = oz0 + row / C0::TH, gy = oy0 + row % C0::TH, gx = ox0 + x;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+      unsigned h[8], l[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float v = os[c * OCS + row * C0::TW + x];
+        h[c] = bf16_rne(v);
+        l[c] = bf16_rne(v - __uint_as_float(h[c] << 16));
+      }
+      const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+      outs[sp] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      outs[out_plane + sp] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    }
+  } else {
   constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
 #pragma unroll
   for (int k = 0; k < (NQ + 255) / 256; ++k) {
@@ -686,7 +711,195 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
       for (int e = 0; e < 4 && gx + e < p.Wo; ++e) p.out[o + e] = v[e] + (p.skip ? p.skip[o + e] : 0.f);
     }
   }
+  }
   PHASE_MARK(6);
+  PHASE_FLUSH;
+}
+
+// ---- conv1 / conv2 on split-bf16 matrix cores ------------------------------------------------------------------
+// The two half-resolution 16-output-channel layers (conv1: 8 -> 16 stride 2 on the full-resolution conv0 output,
+// conv2: 16 -> 16 stride 1) read their input in the split channel-last layout ([n][CIN/8 groups][hi, lo][D][H][W]
+// 16-byte slots), so staging is plain 16-byte copies, and the whole layer's weights sit in LDS: one staging pass,
+// one MFMA pass, one store pass per workgroup.  MFMA tile: 16 rows = output channels, 16 columns = the 14 x of an
+// output row (2 idle), K = 32 = 4 x taps x 8 channels (CIN 8, tap 3 zero) or 2 x taps x 16 channels (CIN 16, two
+// K steps per (kz, ky), the 4th tap zero).  Wave w owns output row y = w of every plane of the tile; an input row
+// read from LDS feeds every plane it contributes to.
+template <int CIN_, int STRIDE_, bool OUT_SPLIT_>
+struct CH {
+  static constexpr int CIN = CIN_, S = STRIDE_;
+  static constexpr bool OUT_SPLIT = OUT_SPLIT_;
+  static constexpr int G = CIN / 8;
+  static constexpr int TD = S == 2 ? 2 : 4, TH = 4, TW = 14;
+  static constexpr int ID = S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
+  static constexpr int NXS = G == 1 ? 1 : 2;
+  static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;      // idle lanes 14, 15 read a few slots past a row
+  static constexpr int NKS = 9 * NXS;
+  static constexpr int WQ = NKS * 2 * 64;                          // weight image in 16-byte words
+  static constexpr int NVO = TD * TH * TW;
+  static constexpr int LPR = IW <= 16 ? 16 : 32, RPI = 256 / LPR;  // staging: lanes per row, rows per iteration
+  static constexpr int NROWS = G * 2 * ID * IH, NIT = (NROWS + RPI - 1) / RPI;
+  static constexpr size_t LDS_BYTES = (size_t)(G * 2 * NVOXP + WQ) * 16;
+  static_assert(CIN == 8 || CIN == 16, "input channels");
+  static_assert((size_t)NVO * 16 * 4 <= (size_t)G * 2 * NVOXP * 16, "output staging fits in the input tile");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void convh_bf16x2_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [G][hi, lo][NVOXP] slots
+  u32x4* const wq = xs + C::G * 2 * C::NVOXP;                       // [NKS][hi, lo][64] weight fragments
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  int b = v3d::xcd_contiguous_block();
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * C::TD, oy0 = ty * C::TH, ox0 = tx * C::TW;
+  const int iz0 = C::S * oz0 - 1, iy0 = C::S * oy0 - 1, ix0 = C::S * ox0 - 1;
+  const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
+  const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+
+  PHASE_DECL;
+  // ---- stage: input tile rows (16-byte slots) and the weight image ---------------------------------------------
+  {
+    const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::G * 2 * in_plane;
+    const int lrow = tid / C::LPR, lx = tid % C::LPR;
+    const int gx = ix0 + lx;
+    const bool xok = lx < C::IW, xin = xok && gx >= 0 && gx < p.Wi;
+    u32x4 pre[C::NIT];
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int rr = it * C::RPI + lrow;
+      const int gp = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
+      const int gz = iz0 + rem / C::IH, gy = iy0 + rem % C::IH;
+      const bool ok = rr < C::NROWS && xin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+      const int zc = min(max(gz, 0), p.Di - 1), yc = min(max(gy, 0), p.Hi - 1), xc = min(max(gx, 0), p.Wi - 1);
+      const int gpc = min(gp, C::G * 2 - 1);
+      const u32x4 v = ins[(size_t)gpc * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + xc];
+      pre[it] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+    }
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.wp);
+    for (int i = tid; i < C::WQ; i += 256) wq[i] = wg[i];
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int rr = it * C::RPI + lrow;
+      const int gp = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
+      if (rr < C::NROWS && xok) xs[gp * C::NVOXP + rem * C::IW + lx] = pre[it];
+    }
+    if (tid < C::G * 2 * 8) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};
+  }
+  PHASE_MARK(0);
+  __syncthreads();
+  PHASE_MARK(1);
+
+  // ---- MFMA: wave w = output row y = w --------------------------------------------------------------------------
+  f32x4 acc[C::TD];
+#pragma unroll
+  for (int z = 0; z < C::TD; ++z) acc[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lg = C::G == 1 ? 0 : (kq & 1);                           // channel group this lane supplies
+  const int ltap = C::G == 1 ? kq : (kq >> 1);                       // x tap within the K step
+  const u32x4* const wf = wq + lane;
+#pragma unroll 1
+  for (int ky = 0; ky < 3; ++ky) {
+    bf16x8 a_hi[3][C::NXS], a_lo[3][C::NXS];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int xsi = 0; xsi < C::NXS; ++xsi) {
+        a_hi[kz][xsi] = __builtin_bit_cast(bf16x8, wf[(((kz * 3 + ky) * C::NXS + xsi) * 2) * 64]);
+        a_lo[kz][xsi] = __builtin_bit_cast(bf16x8, wf[(((kz * 3 + ky) * C::NXS + xsi) * 2 + 1) * 64]);
+      }
+    const int rowbase = (lg * 2) * C::NVOXP + (C::S * wave + ky) * C::IW + C::S * jn + ltap;
+#pragma unroll
+    for (int iz = 0; iz < C::ID; ++iz) {
+#pragma unroll
+      for (int xsi = 0; xsi < C::NXS; ++xsi) {
+        const int slot = rowbase + iz * C::IH * C::IW + 2 * xsi;
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[slot]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[slot + C::NVOXP]);
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z2 = iz - kz;
+          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz][xsi], b_hi, acc[z2 / C::S], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z2 = iz - kz;
+          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz][xsi], b_lo, acc[z2 / C::S], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z2 = iz - kz;
+          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz][xsi], b_hi, acc[z2 / C::S], 0, 0, 0);
+        }
+      }
+    }
+  }
+  PHASE_MARK(2);
+  __syncthreads();                 // the input tile is dead: its LDS stages the output tile
+  PHASE_MARK(3);
+
+  // ---- bias + ReLU, through LDS, out in 16-byte (split layout) or 8-byte (fp32 rows) pieces ---------------------
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = p.bias[4 * kq + r];
+  if constexpr (C::OUT_SPLIT) {
+    u32x2* const sp2 = reinterpret_cast<u32x2*>(smem);            // [2 groups][hi, lo][NVO] slots, halves of 8 bytes
+    if (jn < C::TW) {
+#pragma unroll
+      for (int z = 0; z < C::TD; ++z) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[z][r] + bias[r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          h[r] = bf16_rne(v);
+          l[r] = bf16_rne(v - __uint_as_float(h[r] << 16));
+        }
+        const int vox = (z * C::TH + wave) * C::TW + jn;
+        sp2[((((kq >> 1) * 2 + 0) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+      }
+    }
+    __syncthreads();
+    u32x4* const outs = reinterpret_cast<u32x4*>(p.out) + (size_t)n * 4 * out_plane;
+    const u32x4* const sq = reinterpret_cast<const u32x4*>(smem);
+    for (int i = tid; i < 4 * C::NVO; i += 256) {
+      const int gp = i / C::NVO, vox = i % C::NVO;
+      const int gz = oz0 + vox / (C::TH * C::TW), gy = oy0 + (vox / C::TW) % C::TH, gx = ox0 + vox % C::TW;
+      if (gz < p.Do && gy < p.Ho && gx < p.Wo) outs[(size_t)gp * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx] = sq[i];
+    }
+  } else {
+    constexpr int OCS = C::NVO + 2;
+    float* const os = reinterpret_cast<float*>(smem);             // [16 co][NVO (+2)]
+    if (jn < C::TW) {
+#pragma unroll
+      for (int z = 0; z < C::TD; ++z)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[z][r] + bias[r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          os[(4 * kq + r) * OCS + (z * C::TH + wave) * C::TW + jn] = v;
+        }
+    }
+    __syncthreads();
+    constexpr int NR = C::TD * C::TH, QPR = C::TW / 2;
+    for (int i = tid; i < 16 * NR * QPR; i += 256) {
+      const int co = i / (NR * QPR), row = (i / QPR) % NR, q = i % QPR;
+      const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 2 * q;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+      const float2 v = *reinterpret_cast<const float2*>(os + co * OCS + row * C::TW + 2 * q);
+      float* o = p.out + ((size_t)n * 16 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+      if (gx + 1 < p.Wo && (p.Wo & 1) == 0) *reinterpret_cast<float2*>(o) = v;
+      else { o[0] = v.x; if (gx + 1 < p.Wo) o[1] = v.y; }
+    }
+  }
+  PHASE_MARK(4);
   PHASE_FLUSH;
 }
 
@@ -823,7 +1036,7 @@ struct C9 {
 
 struct C9Params {
   const float* u8;     // [n, 16, D/2, H/2, W/2]
-  const float* c0;     // [n, 8, D, H, W] skip
+  const float* c0;     // conv0 output (skip) in the split channel-last layout [n][hi, lo][D][H][W][8 bf16]
   const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)
   const float* bias9;  // [8] folded BN bias
   const float* wprob;  // [4 channel pairs, 27, 2]
@@ -905,11 +1118,13 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
     xl[slot] = (u32x4){0u, 0u, 0u, 0u};
   }
   __builtin_amdgcn_sched_barrier(0);
-  // (b) the conv0 skip values of this lane's 64 outputs: in flight during the MFMA phase
+  // (b) the conv0 skip values of this lane's 64 outputs, in flight during the MFMA phase.  conv0's output is in the
+  // split channel-last layout ([n][hi, lo][D][H][W] slots of 8 channels): channels cbase..cbase+3 are 8 bytes of the hi
+  // slot and 8 bytes of the lo slot
   const int px = kq >> 1, cbase = 4 * (kq & 1);
-  float sk[4][4][4];
+  u32x2 skh[4][4], skl[4][4];
   {
-    const float* skip = p.c0 + ((size_t)n * 8 + cbase) * out_plane;
+    const u32x2* skip = reinterpret_cast<const u32x2*>(p.c0) + ((size_t)n * 2 * out_plane) * 2 + (kq & 1);
 #pragma unroll
     for (int cbi = 0; cbi < 4; ++cbi) {
       const int cb = min(wave + 4 * cbi, C9::NCB - 1);
@@ -919,12 +1134,11 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
         const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
         const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
         const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sk[cbi][rb][r] = skip[(size_t)r * out_plane + sp];
+        skh[cbi][rb] = skip[sp * 2];
+        skl[cbi][rb] = skip[(out_plane + sp) * 2];
       }
     }
   }
-
   PHASE_MARK(0);
   __syncthreads();
   PHASE_MARK(1);
@@ -983,9 +1197,14 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
           const int hz = 2 * cz + (rb >> 1), hy = 2 * cy + (rb & 1), hx = 2 * jn + px;
           const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
           const bool inside = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const u32x2 sh = skh[cbi][rb], sl = skl[cbi][rb];
+          const float skv[4] = {__uint_as_float(sh.x << 16) + __uint_as_float(sl.x << 16),
+                                __uint_as_float(sh.x & 0xffff0000u) + __uint_as_float(sl.x & 0xffff0000u),
+                                __uint_as_float(sh.y << 16) + __uint_as_float(sl.y << 16),
+                                __uint_as_float(sh.y & 0xffff0000u) + __uint_as_float(sl.y & 0xffff0000u)};
           float val[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) val[r] = inside ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + sk[cbi][rb][r] : 0.f;
+          for (int r = 0; r < 4; ++r) val[r] = inside ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + skv[r] : 0.f;
 #pragma unroll
           for (int rp = 0; rp < 2; ++rp)
             *reinterpret_cast<f32x2*>(u9s + ((((cbase >> 1) + rp) * (C9::HD * C9::HH) + hz * C9::HH + hy) * C9::RS + hx) * 2) =
@@ -1130,7 +1349,7 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
 }  // namespace
 
 namespace {
-int launch_conv0_bf16(bool split_in, const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
+int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
                       int Di, int Hi, int Wi, hipStream_t s) {
   ConvParams p;
   p.in = in; p.wp = wbf; p.bias = bias; p.skip = skip; p.out = out; p.n = n;
@@ -1142,18 +1361,51 @@ int launch_conv0_bf16(bool split_in, const float* in, const float* wbf, const fl
   V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
   static bool attr_set = false;
   if (!attr_set) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
     attr_set = true;
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-    if (split_in) conv0_bf16x2_kernel<true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else conv0_bf16x2_kernel<false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    if (split_in && split_out) conv0_bf16x2_kernel<true, true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else if (split_in) conv0_bf16x2_kernel<true, false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else if (split_out) conv0_bf16x2_kernel<false, true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else conv0_bf16x2_kernel<false, false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH("conv0_bf16x2_kernel");
+  return V3D_OK;
+}
+}  // namespace
+
+namespace {
+template <class C>
+int launch_convh(const char* name, const float* in, const float* wbf, const float* bias, float* out, int n, int Di,
+                 int Hi, int Wi, hipStream_t s) {
+  ConvParams p;
+  p.in = in; p.wp = wbf; p.bias = bias; p.skip = nullptr; p.out = out; p.n = n;
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  p.Do = (Di - 1) / C::S + 1; p.Ho = (Hi - 1) / C::S + 1; p.Wo = (Wi - 1) / C::S + 1;
+  p.ntz = (p.Do + C::TD - 1) / C::TD; p.nty = (p.Ho + C::TH - 1) / C::TH; p.ntx = (p.Wo + C::TW - 1) / C::TW;
+  p.relu = 1;
+  const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
+  V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
+  static bool attr_set = false;
+  if (!attr_set) {
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)convh_bf16x2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)C::LDS_BYTES));
+    attr_set = true;
+  }
+  {
+    v3d::TimedScope ts(name, s);
+    convh_bf16x2_kernel<C><<<(unsigned)blocks, 256, C::LDS_BYTES, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH(name);
   return V3D_OK;
 }
 }  // namespace
@@ -1161,7 +1413,7 @@ int launch_conv0_bf16(bool split_in, const float* in, const float* wbf, const fl
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c1bf_ofs, c2bf_ofs, c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -1272,6 +1524,37 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
         }
       }
   }
+  for (int l = 1; l <= 2; ++l) {
+    // split-bf16 images of conv1 / conv2 for convh_bf16x2_kernel: [K step = (kz, ky, xs)][hi, lo][lane 64][4 words];
+    // rows = output channel, k = 8 * (lane >> 4) + e: CIN 8: x tap = lane >> 4 (tap 3 = 0), ci = e;
+    // CIN 16: x tap = 2 xs + (lane >> 5), ci = 8 * ((lane >> 4) & 1) + e
+    const int cin = l == 1 ? 8 : 16, nxs = l == 1 ? 1 : 2;
+    const size_t words = (size_t)9 * nxs * 2 * 64 * 4;
+    const size_t ofs = reserve(words);
+    (l == 1 ? h->c1bf_ofs : h->c2bf_ofs) = ofs;
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + ofs);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int kzy = 0; kzy < 9; ++kzy)
+      for (int xs = 0; xs < nxs; ++xs)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = lane & 15, kq = lane >> 4;
+          const int kx = cin == 8 ? kq : 2 * xs + (kq >> 1);
+          const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+          unsigned hi[8], lo[8];
+          for (int e = 0; e < 8; ++e) {
+            const int ci = cin == 8 ? e : (kq & 1) * 8 + e;
+            const float v = kx > 2 ? 0.f : conv_w[l][((size_t)co * cin + ci) * 27 + kzy * 3 + kx] * sc;
+            hi[e] = rne(v);
+            lo[e] = rne(v - up(hi[e]));
+          }
+          for (int part = 0; part < 2; ++part) {
+            const unsigned* src = part ? lo : hi;
+            unsigned* dst = wb + (((size_t)kzy * nxs + xs) * 2 + part) * 256 + lane * 4;
+            for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+          }
+        }
+  }
   {
     // prob weights for the fused kernel, channel pairs interleaved: [4 pairs][27 taps][2]
     h->prob_w2_ofs = reserve((size_t)base * 27);
@@ -1306,7 +1589,7 @@ static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, c
     case 0: {
       static const bool fp32_path = getenv("V3D_CONV0_FP32") != nullptr;     // developer A/B switch
       if (fp32_path) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
-      return launch_conv0_bf16(false, in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
+      return launch_conv0_bf16(false, false, in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
     }
     case 1: return launch_conv<L1>("costreg_conv1", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
     case 2: return launch_conv<L2>("costreg_conv2", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
@@ -1366,23 +1649,43 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
   int rc;
 #define RUN(layer, in, skip, out, d, hh, ww) \
   if ((rc = run_layer(h, layer, in, skip, out, n, d, hh, ww, s)) != V3D_OK) return rc;
-  if (split_in) {
-    if ((rc = launch_conv0_bf16(true, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], nullptr, F(ws.c0), n, D, H,
-                                W, s)) != V3D_OK)
-      return rc;
-  } else {
+  // V3D_COSTREG_GENERIC=1 (developer A/B switch, fp32 volume only): every layer on the per-layer kernels with fp32
+  // [n, C, D, H, W] tensors in between.  Default: conv0 -> conv1 -> conv2 and the conv0 skip of the last layer use the
+  // split channel-last hand-off format (same bytes as fp32).
+  static const bool generic = getenv("V3D_COSTREG_GENERIC") != nullptr;
+  V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_COSTREG_GENERIC needs the fp32 variance volume");
+  if (generic) {
     RUN(0, var, nullptr, F(ws.c0), D, H, W);
+    RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
+    RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
+  } else {
+    if ((rc = launch_conv0_bf16(split_in, true, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], nullptr, F(ws.c0), n,
+                                D, H, W, s)) != V3D_OK)
+      return rc;
+#ifdef V3D_PHASE_TIMING
+    const int stop_after = getenv("V3D_STOP_AFTER") ? atoi(getenv("V3D_STOP_AFTER")) : 99;   // isolate one kernel's counters
+    if (stop_after == 0) return V3D_OK;
+#endif
+    if ((rc = launch_convh<CH<8, 2, true>>("costreg_conv1", F(ws.c0), h->dev + h->c1bf_ofs, h->dev + h->bias_ofs[1],
+                                           F(ws.c1), n, D, H, W, s)) != V3D_OK)
+      return rc;
+#ifdef V3D_PHASE_TIMING
+    if (stop_after == 1) return V3D_OK;
+#endif
+    if ((rc = launch_convh<CH<16, 1, false>>("costreg_conv2", F(ws.c1), h->dev + h->c2bf_ofs, h->dev + h->bias_ofs[2],
+                                             F(ws.c2), n, D / 2, H / 2, W / 2, s)) != V3D_OK)
+      return rc;
+#ifdef V3D_PHASE_TIMING
+    if (stop_after == 2) return V3D_OK;
+#endif
   }
-  RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
-  RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
   RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
   RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
   RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
   RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
   RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
   RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
-  static const bool unfused9 = getenv("V3D_CONV9_UNFUSED") != nullptr;      // developer A/B switch
-  if (!unfused9) {
+  if (!generic) {
     C9Params q;
     q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
     q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;

@@ -53,9 +53,9 @@ def kernel_roofline(name, avg_ms, shape):
         ci, co, div = COSTREG_LAYERS[layer]
         flops = 2.0 * 27 * ci * co * (vox // div) * n_ref
         a = flops / (avg_ms * 1e-3) / 1e12
-        # conv0 runs on bf16 MFMAs with every fp32 product split into 3 bf16 products (hi*hi + hi*lo + lo*hi):
+        # conv0, conv1, conv2 run on bf16 MFMAs with every fp32 product split into 3 bf16 products (hi*hi + hi*lo + lo*hi):
         # its ceiling in algorithmic FLOPs is the dense bf16 peak / 3; the other layers use fp32 MFMAs
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if layer == 0 else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if layer in (0, 1, 2) else PEAK_F32_MFMA_TFLOPS
         return dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak)
     elif name == 'costreg_prob':
         nbytes = 4.0 * n_ref * vox * (8 + 1)

@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--refs', type=int, default=32)
+    ap.add_argument('--blocks', type=int, default=0, help='workgroups of the kernel whose counters are read')
     args = ap.parse_args()
     syn = importlib.import_module('3dvnet_amd.synthetic')
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
@@ -39,7 +40,7 @@ def main():
     feat = inp['feat'].to(dev)
     d0, dd, D = inp['depth']
     buf = (ctypes.c_ulonglong * 8)()
-    n_blocks = args.refs * 24 * 7 * 2
+    n_blocks = args.blocks or args.refs * 24 * 7 * 2
     with torch.no_grad():
         net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
         net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
