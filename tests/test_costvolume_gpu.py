@@ -129,6 +129,30 @@ def test_hip_matches_oracle_multi_ref(cuda):
     np.testing.assert_allclose(depth.numpy(), depth_o.numpy(), rtol=DEPTH_RTOL, atol=0)
 
 
+def test_fused_path_partial_tiles_and_ragged_edges(cuda):
+    """Whole path A on a volume whose extents are multiples of 8 (the regulariser's requirement) but of none of the
+    kernels' tile sizes (24 x 24 x 40: partial 28- and 14-wide x tiles, partial z/y tiles on the coarse levels), with
+    ragged, unsorted edge lists (1, 3 and 9 sources), vs the oracle."""
+    syn = v3d('synthetic')
+    img_size, feat_size, plane_size, D = (96, 160), (24, 40), (24, 40), 24
+    R, tv, K = syn.make_cameras(12, img_size, seed=11)
+    feat = syn.make_features(12, 32, *feat_size, seed=11)
+    refs = [4] + [7] * 3 + [2] * 9
+    srcs = [4] + [6, 7, 8] + list(range(0, 9))
+    perm = torch.randperm(len(refs), generator=torch.Generator().manual_seed(1))
+    edges = torch.tensor([refs, srcs])[:, perm]
+    sd = syn.costregnet_weights(seed=5, sharpen=200.0)
+    d0, dd = 0.5, 0.1
+    with torch.no_grad():
+        depth_o, var_o, reg_o = ocv.mvsnet_depth(feat, R, tv, K, edges, sd, d0, dd, D, img_size, plane_size)
+    net = _net(sd, cuda, img_size)
+    depth, var, reg = _run_hip(net, feat, R, tv, K, edges, (d0, dd, D), plane_size, cuda)
+    np.testing.assert_allclose(var.numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
+    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=2e-4 * float(reg_o.abs().max()))
+    np.testing.assert_allclose(depth.numpy(), depth_o.numpy(), rtol=DEPTH_RTOL, atol=0)
+    assert float(depth_o.max() - depth_o.min()) > 0.5
+
+
 def test_psv_ragged_edges_and_odd_grid(cuda):
     """Ragged edge lists (1, 3 and 10 sources -- more than one LDS pass), a plane grid that is not
     a multiple of the 64-pixel tile, D not a multiple of the plane chunk, unsorted edge order."""
@@ -145,6 +169,10 @@ def test_psv_ragged_edges_and_odd_grid(cuda):
                                    plane_size)
     torch.cuda.synchronize()
     np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
+    # the split hand-off format of the same volume: hi + lo of exactly these numbers
+    sv = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 6, img_size, plane_size,
+                                  split=True)
+    assert torch.equal(_decode_split(sv), _split_roundtrip(var))
 
 
 def test_psv_feat_dim_16(cuda):
