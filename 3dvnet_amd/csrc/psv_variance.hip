@@ -278,14 +278,19 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
             const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o01 * 4u + cgb));
             const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o10 * 4u + cgb));
             const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
+            // fixed evaluation order (no compiler re-association): ((v00 w00 + v01 w01) + v10 w10) + v11 w11, each
+            // step one FMA -- the plane-reuse kernel below uses the same sequence, so the variants agree bit for bit
             s.x = v00.x * ti.w00; s.y = v00.y * ti.w00; s.z = v00.z * ti.w00; s.w = v00.w * ti.w00;
-            s.x += v01.x * ti.w01; s.y += v01.y * ti.w01; s.z += v01.z * ti.w01; s.w += v01.w * ti.w01;
-            s.x += v10.x * ti.w10; s.y += v10.y * ti.w10; s.z += v10.z * ti.w10; s.w += v10.w * ti.w10;
-            s.x += v11.x * ti.w11; s.y += v11.y * ti.w11; s.z += v11.z * ti.w11; s.w += v11.w * ti.w11;
+            s.x = __builtin_fmaf(v01.x, ti.w01, s.x); s.y = __builtin_fmaf(v01.y, ti.w01, s.y);
+            s.z = __builtin_fmaf(v01.z, ti.w01, s.z); s.w = __builtin_fmaf(v01.w, ti.w01, s.w);
+            s.x = __builtin_fmaf(v10.x, ti.w10, s.x); s.y = __builtin_fmaf(v10.y, ti.w10, s.y);
+            s.z = __builtin_fmaf(v10.z, ti.w10, s.z); s.w = __builtin_fmaf(v10.w, ti.w10, s.w);
+            s.x = __builtin_fmaf(v11.x, ti.w11, s.x); s.y = __builtin_fmaf(v11.y, ti.w11, s.y);
+            s.z = __builtin_fmaf(v11.z, ti.w11, s.z); s.w = __builtin_fmaf(v11.w, ti.w11, s.w);
           }
           acc_s[a][0] += s.x; acc_s[a][1] += s.y; acc_s[a][2] += s.z; acc_s[a][3] += s.w;
-          acc_q[a][0] += s.x * s.x; acc_q[a][1] += s.y * s.y;
-          acc_q[a][2] += s.z * s.z; acc_q[a][3] += s.w * s.w;
+          acc_q[a][0] = __builtin_fmaf(s.x, s.x, acc_q[a][0]); acc_q[a][1] = __builtin_fmaf(s.y, s.y, acc_q[a][1]);
+          acc_q[a][2] = __builtin_fmaf(s.z, s.z, acc_q[a][2]); acc_q[a][3] = __builtin_fmaf(s.w, s.w, acc_q[a][3]);
         }
       }
     }
@@ -402,6 +407,18 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   }
   const bool live1 = gp1 < P && d1 < p.D;
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  // x / c for a wave-uniform c with the correctly rounded reciprocal rc: q0 = x rc, one residual correction.  The result
+  // is the correctly rounded quotient (Markstein) for finite normal operands -- the same number as the IEEE division
+  // sequence, in 3 instead of ~10 instructions.
+  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
+  auto div_uniform = [](float x, float c, float rc) __attribute__((always_inline)) {
+#ifdef V3D_PSV_EXACT_DIV
+    return x / c;
+#else
+    const float q0 = x * rc;
+    return __builtin_fmaf(__builtin_fmaf(-q0, c, x), rc, q0);
+#endif
+  };
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
 
   // gather role: 8 lanes x float4 per pixel
@@ -433,8 +450,8 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
       const float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
       const float u = qx / zb, v = qy / zb;
-      const float gx = (u / Wm1) * 2.f - 1.f;                    // mvsnet.py:205-206
-      const float gy = (v / Hm1) * 2.f - 1.f;
+      const float gx = div_uniform(u, Wm1, rWm1) * 2.f - 1.f;    // mvsnet.py:205-206: u / (W - 1) * 2 - 1
+      const float gy = div_uniform(v, Hm1, rHm1) * 2.f - 1.f;
       const float ix = ((gx + 1.f) / 2.f) * Wfm1;                // grid_sample, align_corners=True
       const float iy = ((gy + 1.f) / 2.f) * Hfm1;
       const float x0 = floorf(ix), y0 = floorf(iy);
@@ -472,12 +489,12 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
             t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
             c00 = ti.o00; c11 = ti.o11;
           }
-          f32x4 sv = t00 * ti.w00;
-          sv += t01 * ti.w01;
-          sv += t10 * ti.w10;
-          sv += t11 * ti.w11;
+          f32x4 sv = t00 * ti.w00;                                   // same fixed FMA sequence as the gather kernel
+          sv = __builtin_elementwise_fma(t01, (f32x4){ti.w01, ti.w01, ti.w01, ti.w01}, sv);
+          sv = __builtin_elementwise_fma(t10, (f32x4){ti.w10, ti.w10, ti.w10, ti.w10}, sv);
+          sv = __builtin_elementwise_fma(t11, (f32x4){ti.w11, ti.w11, ti.w11, ti.w11}, sv);
           acc_s[pl] += sv;
-          acc_q[pl] += sv * sv;
+          acc_q[pl] = __builtin_elementwise_fma(sv, sv, acc_q[pl]);
         }
       }
     }
@@ -487,6 +504,15 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   // ---- variance -> LDS -> stores ------------------------------------------------------------------------------
   __syncthreads();
   const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
+  // x / cnt is an IEEE division (~10 instructions); for a power-of-two count (8 views in the headline configuration)
+  // x * (1 / cnt) is the same number exactly.  Wave-uniform choice.
+  const bool cnt_pow2 = (max(ne, 1) & (max(ne, 1) - 1)) == 0;
+  const float cnt_inv = 1.f / cnt;
+#ifdef V3D_PSV_EXACT_DIV
+  auto mean = [&](float x) __attribute__((always_inline)) { return x / cnt; };
+#else
+  auto mean = [&](float x) __attribute__((always_inline)) { return cnt_pow2 ? x * cnt_inv : x / cnt; };
+#endif
   const int cg = lane & 7;
   if constexpr (SPLIT) {
     // s_out reused as [plane][8 groups][kRPix + 1] 16-byte slots
@@ -497,8 +523,8 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       unsigned h[4], l[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float avg = acc_s[pl][k] / cnt;
-        const float avg_sq = acc_q[pl][k] / cnt;
+        const float avg = mean(acc_s[pl][k]);
+        const float avg_sq = mean(acc_q[pl][k]);
         const float v = __fsub_rn(avg_sq, __fmul_rn(avg, avg));            // mvsnet.py:216
         h[k] = psv_bf16_rne(v);
         l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
@@ -522,8 +548,8 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
     for (int pl = 0; pl < kDB; ++pl)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float avg = acc_s[pl][k] / cnt;
-        const float avg_sq = acc_q[pl][k] / cnt;
+        const float avg = mean(acc_s[pl][k]);
+        const float avg_sq = mean(acc_q[pl][k]);
         s_out[pl][cg * 4 + k][gpx] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
       }
     __syncthreads();

@@ -175,6 +175,24 @@ def test_psv_ragged_edges_and_odd_grid(cuda):
     assert torch.equal(_decode_split(sv), _split_roundtrip(var))
 
 
+def test_psv_kernel_variants_bit_identical(cuda):
+    """The default plane-reuse warp kernel (footprints kept in registers, reciprocal-based uniform divisions) and the
+    plain gather kernel (V3D_PSV_GATHER=1, IEEE divisions) must produce the same bits: the switch is read once per
+    process, so each variant hashes a few seeded volumes in its own interpreter (scripts/psv_hash.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {'V3D_PSV_GATHER': '1'}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'psv_hash.py')], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(('cfg', '7-edge'))])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
+
+
 def test_psv_feat_dim_16(cuda):
     syn, mvs = v3d('synthetic'), v3d('mvsnet')
     img_size, plane_size = (64, 80), (8, 8)
