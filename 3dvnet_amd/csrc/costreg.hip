@@ -716,41 +716,54 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   PHASE_FLUSH;
 }
 
-// ---- conv1 / conv2 on split-bf16 matrix cores ------------------------------------------------------------------
-// The two half-resolution 16-output-channel layers (conv1: 8 -> 16 stride 2 on the full-resolution conv0 output,
-// conv2: 16 -> 16 stride 1) read their input in the split channel-last layout ([n][CIN/8 groups][hi, lo][D][H][W]
-// 16-byte slots), so staging is plain 16-byte copies, and the whole layer's weights sit in LDS: one staging pass,
-// one MFMA pass, one store pass per workgroup.  MFMA tile: 16 rows = output channels, 16 columns = the 14 x of an
-// output row (2 idle), K = 32 = 4 x taps x 8 channels (CIN 8, tap 3 zero) or 2 x taps x 16 channels (CIN 16, two
-// K steps per (kz, ky), the 4th tap zero).  Wave w owns output row y = w of every plane of the tile; an input row
-// read from LDS feeds every plane it contributes to.
-template <int CIN_, int STRIDE_, bool OUT_SPLIT_>
-struct CH {
-  static constexpr int CIN = CIN_, S = STRIDE_;
-  static constexpr bool OUT_SPLIT = OUT_SPLIT_;
-  static constexpr int G = CIN / 8;
-  static constexpr int TD = S == 2 ? 2 : 4, TH = 4, TW = 14;
+// ---- conv1 .. conv6 on split-bf16 matrix cores -------------------------------------------------------------------
+// The stride-1 / stride-2 layers behind conv0 read their input in the split channel-last layout ([n][CIN/8 groups]
+// [hi, lo][D][H][W] 16-byte slots of 8 channels), so staging is plain 16-byte copies.  One workgroup = one output tile
+// x 16 output channels (blockIdx.y picks the channel group).  The input channels are consumed 8 at a time: a chunk's
+// halo'd tile and its 9 (kz, ky) weight fragments sit in LDS while the next chunk is already in registers.  MFMA
+// tile: 16 rows = output channels, 16 columns = one output x row of 14 (or two rows of 8 on the coarsest level),
+// K = 32 = 4 x taps x 8 channels (tap 3 carries zero weights).  Wave w owns output row(s) y of every plane of the
+// tile; an input row read from LDS feeds every plane it contributes to.  Output: fp32 [n, COUT, D, H, W] (for the
+// per-layer kernels that still follow), the split layout (for the next layer of this kind), or both.
+enum { kOutF32 = 1, kOutSplit = 2 };
+
+template <int CIN_, int COUT_, int STRIDE_, int WB_, int OUT_>
+struct CG {
+  static constexpr int CIN = CIN_, COUT = COUT_, S = STRIDE_, WB = WB_, OUT = OUT_;
+  static constexpr int NCH = CIN / 8, NCG = COUT / 16;
+  static constexpr int NRB = 16 / WB;                                  // output rows per MFMA column block
+  static constexpr int TD = S == 2 ? 2 : 4, TH = 4 * NRB, TW = WB;
   static constexpr int ID = S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
-  static constexpr int NXS = G == 1 ? 1 : 2;
-  static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;      // idle lanes 14, 15 read a few slots past a row
-  static constexpr int NKS = 9 * NXS;
-  static constexpr int WQ = NKS * 2 * 64;                          // weight image in 16-byte words
+  static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;         // idle lanes read a few slots past a row
+  static constexpr int WQ = 9 * 2 * 64;                                // 16-byte words of one chunk's weight image
   static constexpr int NVO = TD * TH * TW;
-  static constexpr int LPR = IW <= 16 ? 16 : 32, RPI = 256 / LPR;  // staging: lanes per row, rows per iteration
-  static constexpr int NROWS = G * 2 * ID * IH, NIT = (NROWS + RPI - 1) / RPI;
-  static constexpr size_t LDS_BYTES = (size_t)(G * 2 * NVOXP + WQ) * 16;
-  static_assert(CIN == 8 || CIN == 16, "input channels");
-  static_assert((size_t)NVO * 16 * 4 <= (size_t)G * 2 * NVOXP * 16, "output staging fits in the input tile");
+  static constexpr int LPR = IW <= 16 ? 16 : 32, RPI = 256 / LPR;      // staging: lanes per row, rows per iteration
+  static constexpr int NROWS = 2 * ID * IH, NIT = (NROWS + RPI - 1) / RPI;
+  static constexpr int NWIT = (WQ + 255) / 256;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * NVOXP + WQ) * 16;
+  static_assert(CIN % 8 == 0 && COUT % 16 == 0 && (WB == 14 || WB == 8), "shape");
+  static_assert((size_t)NVO * 64 <= (size_t)2 * NVOXP * 16, "split output staging fits in the input tile");
+  static_assert((size_t)16 * (NVO + 2) * 4 <= (size_t)2 * NVOXP * 16, "fp32 output staging fits in the input tile");
+};
+
+struct ConvGParams {
+  const void* in;      // split layout, CIN / 8 groups
+  const void* wp;      // [NCG][NCH][9][hi, lo][64 lanes][4 words]
+  const float* bias;   // [COUT]
+  float* out_f32;      // [n, COUT, Do, Ho, Wo] or null
+  void* out_split;     // split layout, COUT / 8 groups, or null
+  int n, Di, Hi, Wi, Do, Ho, Wo, ntz, nty, ntx;
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void convh_bf16x2_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void convg_bf16x2_kernel(ConvGParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [G][hi, lo][NVOXP] slots
-  u32x4* const wq = xs + C::G * 2 * C::NVOXP;                       // [NKS][hi, lo][64] weight fragments
+  u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [hi, lo][NVOXP] slots of the current chunk
+  u32x4* const wq = xs + 2 * C::NVOXP;                              // [9][hi, lo][64] weight fragments
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
+  const int cg = blockIdx.y;
   int b = v3d::xcd_contiguous_block();
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
@@ -761,131 +774,143 @@ __global__ __launch_bounds__(256, 2) void convh_bf16x2_kernel(ConvParams p) {
   const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
 
-  PHASE_DECL;
-  // ---- stage: input tile rows (16-byte slots) and the weight image ---------------------------------------------
-  {
-    const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::G * 2 * in_plane;
-    const int lrow = tid / C::LPR, lx = tid % C::LPR;
-    const int gx = ix0 + lx;
-    const bool xok = lx < C::IW, xin = xok && gx >= 0 && gx < p.Wi;
-    u32x4 pre[C::NIT];
+  // ---- staging: chunk c = input channel group c (hi rows then lo rows) + its weight image -----------------------
+  const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::NCH * 2 * in_plane;
+  const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)cg * C::NCH * C::WQ;
+  const int lrow = tid / C::LPR, lx = tid % C::LPR;
+  const int sgx = ix0 + lx;
+  const bool xok = lx < C::IW, xin = xok && sgx >= 0 && sgx < p.Wi;
+  const int sxc = min(max(sgx, 0), p.Wi - 1);
+  u32x4 pre[C::NIT], wreg[C::NWIT];
+  auto issue = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int rr = it * C::RPI + lrow;
-      const int gp = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
+      const int part = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
       const int gz = iz0 + rem / C::IH, gy = iy0 + rem % C::IH;
       const bool ok = rr < C::NROWS && xin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
-      const int zc = min(max(gz, 0), p.Di - 1), yc = min(max(gy, 0), p.Hi - 1), xc = min(max(gx, 0), p.Wi - 1);
-      const int gpc = min(gp, C::G * 2 - 1);
-      const u32x4 v = ins[(size_t)gpc * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + xc];
+      const int zc = min(max(gz, 0), p.Di - 1), yc = min(max(gy, 0), p.Hi - 1);
+      const u32x4 v = ins[(size_t)(chunk * 2 + min(part, 1)) * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + sxc];
       pre[it] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
     }
-    const u32x4* wg = reinterpret_cast<const u32x4*>(p.wp);
-    for (int i = tid; i < C::WQ; i += 256) wq[i] = wg[i];
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i)
+      wreg[i] = (i * 256 + tid < C::WQ) ? wg[(size_t)chunk * C::WQ + i * 256 + tid] : (u32x4){0u, 0u, 0u, 0u};
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int rr = it * C::RPI + lrow;
-      const int gp = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
-      if (rr < C::NROWS && xok) xs[gp * C::NVOXP + rem * C::IW + lx] = pre[it];
+      const int part = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
+      if (rr < C::NROWS && xok) xs[part * C::NVOXP + rem * C::IW + lx] = pre[it];
     }
-    if (tid < C::G * 2 * 8) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};
-  }
-  PHASE_MARK(0);
-  __syncthreads();
-  PHASE_MARK(1);
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i)
+      if (i * 256 + tid < C::WQ) wq[i * 256 + tid] = wreg[i];
+  };
+  if (tid < 16) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};   // pad slots stay finite
 
-  // ---- MFMA: wave w = output row y = w --------------------------------------------------------------------------
+  // ---- MFMA role: wave w = output rows y = w * NRB + r, lane column jn = (r, x) ----------------------------------
+  const int lr = jn / C::WB, lxo = jn % C::WB;
   f32x4 acc[C::TD];
 #pragma unroll
   for (int z = 0; z < C::TD; ++z) acc[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int lg = C::G == 1 ? 0 : (kq & 1);                           // channel group this lane supplies
-  const int ltap = C::G == 1 ? kq : (kq >> 1);                       // x tap within the K step
   const u32x4* const wf = wq + lane;
+
+  PHASE_DECL;
+  issue(0);
+  PHASE_MARK(0);
 #pragma unroll 1
-  for (int ky = 0; ky < 3; ++ky) {
-    bf16x8 a_hi[3][C::NXS], a_lo[3][C::NXS];
+  for (int chunk = 0; chunk < C::NCH; ++chunk) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    PHASE_MARK(1);
+    if (chunk + 1 < C::NCH) issue(chunk + 1);
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      bf16x8 a_hi[3], a_lo[3];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-      for (int xsi = 0; xsi < C::NXS; ++xsi) {
-        a_hi[kz][xsi] = __builtin_bit_cast(bf16x8, wf[(((kz * 3 + ky) * C::NXS + xsi) * 2) * 64]);
-        a_lo[kz][xsi] = __builtin_bit_cast(bf16x8, wf[(((kz * 3 + ky) * C::NXS + xsi) * 2 + 1) * 64]);
+      for (int kz = 0; kz < 3; ++kz) {
+        a_hi[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2) * 64]);
+        a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
       }
-    const int rowbase = (lg * 2) * C::NVOXP + (C::S * wave + ky) * C::IW + C::S * jn + ltap;
+      const int rowbase = (C::S * (wave * C::NRB + lr) + ky) * C::IW + C::S * lxo + kq;
 #pragma unroll
-    for (int iz = 0; iz < C::ID; ++iz) {
-#pragma unroll
-      for (int xsi = 0; xsi < C::NXS; ++xsi) {
-        const int slot = rowbase + iz * C::IH * C::IW + 2 * xsi;
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[slot]);
-        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[slot + C::NVOXP]);
+      for (int iz = 0; iz < C::ID; ++iz) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW + C::NVOXP]);
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z2 = iz - kz;
           if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz][xsi], b_hi, acc[z2 / C::S], 0, 0, 0);
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
         }
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z2 = iz - kz;
           if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz][xsi], b_lo, acc[z2 / C::S], 0, 0, 0);
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z2 / C::S], 0, 0, 0);
         }
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z2 = iz - kz;
           if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz][xsi], b_hi, acc[z2 / C::S], 0, 0, 0);
+            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
         }
       }
     }
+    PHASE_MARK(2);
   }
-  PHASE_MARK(2);
   __syncthreads();                 // the input tile is dead: its LDS stages the output tile
   PHASE_MARK(3);
 
-  // ---- bias + ReLU, through LDS, out in 16-byte (split layout) or 8-byte (fp32 rows) pieces ---------------------
-  float bias[4];
+  // ---- bias + ReLU, through LDS, out in 16-byte (split layout) and / or 8-byte (fp32 rows) pieces ---------------
+  float vout[C::TD][4];
+  {
+    float bias[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bias[r] = p.bias[4 * kq + r];
-  if constexpr (C::OUT_SPLIT) {
-    u32x2* const sp2 = reinterpret_cast<u32x2*>(smem);            // [2 groups][hi, lo][NVO] slots, halves of 8 bytes
-    if (jn < C::TW) {
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cg * 16 + 4 * kq + r];
 #pragma unroll
-      for (int z = 0; z < C::TD; ++z) {
-        unsigned h[4], l[4];
+    for (int z = 0; z < C::TD; ++z)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[z][r] + bias[r];
-          if (p.relu) v = fmaxf(v, 0.f);
-          h[r] = bf16_rne(v);
-          l[r] = bf16_rne(v - __uint_as_float(h[r] << 16));
-        }
-        const int vox = (z * C::TH + wave) * C::TW + jn;
-        sp2[((((kq >> 1) * 2 + 0) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+      for (int r = 0; r < 4; ++r) vout[z][r] = fmaxf(acc[z][r] + bias[r], 0.f);
+  }
+  const int ly = wave * C::NRB + lr;                                   // this lane's output row inside the tile
+  const bool live = jn < C::NRB * C::WB;                               // lanes 14, 15 of a 14-wide column block idle
+  if constexpr ((C::OUT & kOutSplit) != 0) {
+    u32x2* const sp2 = reinterpret_cast<u32x2*>(smem);               // [2 groups][hi, lo][NVO] slots, 8-byte halves
+#pragma unroll
+    for (int z = 0; z < C::TD; ++z) {
+      if (!live) break;
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h[r] = bf16_rne(vout[z][r]);
+        l[r] = bf16_rne(vout[z][r] - __uint_as_float(h[r] << 16));
       }
+      const int vox = (z * C::TH + ly) * C::TW + lxo;
+      sp2[((((kq >> 1) * 2 + 0) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+      sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
     }
     __syncthreads();
-    u32x4* const outs = reinterpret_cast<u32x4*>(p.out) + (size_t)n * 4 * out_plane;
+    u32x4* const outs = reinterpret_cast<u32x4*>(p.out_split) + ((size_t)n * (C::COUT / 8) + cg * 2) * 2 * out_plane;
     const u32x4* const sq = reinterpret_cast<const u32x4*>(smem);
     for (int i = tid; i < 4 * C::NVO; i += 256) {
       const int gp = i / C::NVO, vox = i % C::NVO;
       const int gz = oz0 + vox / (C::TH * C::TW), gy = oy0 + (vox / C::TW) % C::TH, gx = ox0 + vox % C::TW;
       if (gz < p.Do && gy < p.Ho && gx < p.Wo) outs[(size_t)gp * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx] = sq[i];
     }
-  } else {
+    if constexpr ((C::OUT & kOutF32) != 0) __syncthreads();
+  }
+  if constexpr ((C::OUT & kOutF32) != 0) {
     constexpr int OCS = C::NVO + 2;
-    float* const os = reinterpret_cast<float*>(smem);             // [16 co][NVO (+2)]
-    if (jn < C::TW) {
+    float* const os = reinterpret_cast<float*>(smem);                // [16 co][NVO (+2)]
+    if (live) {
 #pragma unroll
       for (int z = 0; z < C::TD; ++z)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[z][r] + bias[r];
-          if (p.relu) v = fmaxf(v, 0.f);
-          os[(4 * kq + r) * OCS + (z * C::TH + wave) * C::TW + jn] = v;
-        }
+        for (int r = 0; r < 4; ++r) os[(4 * kq + r) * OCS + (z * C::TH + ly) * C::TW + lxo] = vout[z][r];
     }
     __syncthreads();
     constexpr int NR = C::TD * C::TH, QPR = C::TW / 2;
@@ -894,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void convh_bf16x2_kernel(ConvParams p) {
       const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 2 * q;
       if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
       const float2 v = *reinterpret_cast<const float2*>(os + co * OCS + row * C::TW + 2 * q);
-      float* o = p.out + ((size_t)n * 16 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+      float* o = p.out_f32 + ((size_t)n * C::COUT + cg * 16 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
       if (gx + 1 < p.Wo && (p.Wo & 1) == 0) *reinterpret_cast<float2*>(o) = v;
       else { o[0] = v.x; if (gx + 1 < p.Wo) o[1] = v.y; }
     }
@@ -1385,25 +1410,26 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
 
 namespace {
 template <class C>
-int launch_convh(const char* name, const float* in, const float* wbf, const float* bias, float* out, int n, int Di,
-                 int Hi, int Wi, hipStream_t s) {
-  ConvParams p;
-  p.in = in; p.wp = wbf; p.bias = bias; p.skip = nullptr; p.out = out; p.n = n;
+int launch_convg(const char* name, const void* in, const float* wbf, const float* bias, float* out_f32, void* out_split,
+                 int n, int Di, int Hi, int Wi, hipStream_t s) {
+  ConvGParams p;
+  p.in = in; p.wp = wbf; p.bias = bias; p.out_f32 = out_f32; p.out_split = out_split; p.n = n;
   p.Di = Di; p.Hi = Hi; p.Wi = Wi;
   p.Do = (Di - 1) / C::S + 1; p.Ho = (Hi - 1) / C::S + 1; p.Wo = (Wi - 1) / C::S + 1;
   p.ntz = (p.Do + C::TD - 1) / C::TD; p.nty = (p.Ho + C::TH - 1) / C::TH; p.ntx = (p.Wo + C::TW - 1) / C::TW;
-  p.relu = 1;
   const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
+  V3D_REQUIRE(((C::OUT & kOutF32) == 0 || out_f32) && ((C::OUT & kOutSplit) == 0 || out_split), V3D_ERR_BAD_ARG,
+              "%s: missing output buffer", name);
   static bool attr_set = false;
   if (!attr_set) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)convh_bf16x2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)convg_bf16x2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)C::LDS_BYTES));
     attr_set = true;
   }
   {
     v3d::TimedScope ts(name, s);
-    convh_bf16x2_kernel<C><<<(unsigned)blocks, 256, C::LDS_BYTES, s>>>(p);
+    convg_bf16x2_kernel<C><<<dim3((unsigned)blocks, C::NCG), 256, C::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH(name);
   return V3D_OK;
@@ -1413,7 +1439,7 @@ int launch_convh(const char* name, const float* in, const float* wbf, const floa
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c1bf_ofs, c2bf_ofs, c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, cgbf_ofs[7], c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -1524,36 +1550,35 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
         }
       }
   }
-  for (int l = 1; l <= 2; ++l) {
-    // split-bf16 images of conv1 / conv2 for convh_bf16x2_kernel: [K step = (kz, ky, xs)][hi, lo][lane 64][4 words];
-    // rows = output channel, k = 8 * (lane >> 4) + e: CIN 8: x tap = lane >> 4 (tap 3 = 0), ci = e;
-    // CIN 16: x tap = 2 xs + (lane >> 5), ci = 8 * ((lane >> 4) & 1) + e
-    const int cin = l == 1 ? 8 : 16, nxs = l == 1 ? 1 : 2;
-    const size_t words = (size_t)9 * nxs * 2 * 64 * 4;
-    const size_t ofs = reserve(words);
-    (l == 1 ? h->c1bf_ofs : h->c2bf_ofs) = ofs;
-    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + ofs);
+  for (int l = 1; l <= 6; ++l) {
+    // split-bf16 images of conv1..conv6 for convg_bf16x2_kernel: [cout group][8-channel chunk][kz, ky][hi, lo][lane 64]
+    // [4 words]; rows = output channel within the group, k = 8 * x tap + ci (x tap 3 = 0)
+    static const int cins[7] = {0, 8, 16, 16, 32, 32, 64}, couts[7] = {0, 16, 16, 32, 32, 64, 64};
+    const int cin = cins[l], cout = couts[l], nch = cin / 8, ncg = cout / 16;
+    const size_t words = (size_t)ncg * nch * 9 * 2 * 64 * 4;
+    h->cgbf_ofs[l] = reserve(words);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->cgbf_ofs[l]);
     auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
     auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
-    for (int kzy = 0; kzy < 9; ++kzy)
-      for (int xs = 0; xs < nxs; ++xs)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int co = lane & 15, kq = lane >> 4;
-          const int kx = cin == 8 ? kq : 2 * xs + (kq >> 1);
-          const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
-          unsigned hi[8], lo[8];
-          for (int e = 0; e < 8; ++e) {
-            const int ci = cin == 8 ? e : (kq & 1) * 8 + e;
-            const float v = kx > 2 ? 0.f : conv_w[l][((size_t)co * cin + ci) * 27 + kzy * 3 + kx] * sc;
-            hi[e] = rne(v);
-            lo[e] = rne(v - up(hi[e]));
+    for (int g = 0; g < ncg; ++g)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int kzy = 0; kzy < 9; ++kzy)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = g * 16 + (lane & 15), kx = lane >> 4;
+            const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+            unsigned hi[8], lo[8];
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * 8 + e;
+              const float v = kx > 2 ? 0.f : conv_w[l][((size_t)co * cin + ci) * 27 + kzy * 3 + kx] * sc;
+              hi[e] = rne(v);
+              lo[e] = rne(v - up(hi[e]));
+            }
+            for (int part = 0; part < 2; ++part) {
+              const unsigned* src = part ? lo : hi;
+              unsigned* dst = wb + ((((size_t)g * nch + ch) * 9 + kzy) * 2 + part) * 256 + lane * 4;
+              for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+            }
           }
-          for (int part = 0; part < 2; ++part) {
-            const unsigned* src = part ? lo : hi;
-            unsigned* dst = wb + (((size_t)kzy * nxs + xs) * 2 + part) * 256 + lane * 4;
-            for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
-          }
-        }
   }
   {
     // prob weights for the fused kernel, channel pairs interleaved: [4 pairs][27 taps][2]
@@ -1664,25 +1689,44 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
       return rc;
 #ifdef V3D_PHASE_TIMING
     const int stop_after = getenv("V3D_STOP_AFTER") ? atoi(getenv("V3D_STOP_AFTER")) : 99;   // isolate one kernel's counters
-    if (stop_after == 0) return V3D_OK;
+#define V3D_STOP(l) if (stop_after == (l)) return V3D_OK
+#else
+#define V3D_STOP(l)
 #endif
-    if ((rc = launch_convh<CH<8, 2, true>>("costreg_conv1", F(ws.c0), h->dev + h->c1bf_ofs, h->dev + h->bias_ofs[1],
-                                           F(ws.c1), n, D, H, W, s)) != V3D_OK)
-      return rc;
-#ifdef V3D_PHASE_TIMING
-    if (stop_after == 1) return V3D_OK;
-#endif
-    if ((rc = launch_convh<CH<16, 1, false>>("costreg_conv2", F(ws.c1), h->dev + h->c2bf_ofs, h->dev + h->bias_ofs[2],
-                                             F(ws.c2), n, D / 2, H / 2, W / 2, s)) != V3D_OK)
-      return rc;
-#ifdef V3D_PHASE_TIMING
-    if (stop_after == 2) return V3D_OK;
-#endif
+    // conv1..conv6 hand their activations on in the split layout; conv2 and conv4 also leave the fp32 tensors that
+    // the transposed convolutions (per-layer kernels) add as skips.  The split copies live in the u9 slot of the
+    // workspace, which the fused conv9+prob kernel no longer needs.
+    float* const c2s = F(ws.u9);
+    float* const c4s = c2s + (size_t)n * 16 * (D / 2) * (H / 2) * (W / 2);
+    auto W_ = [&](int l) { return h->dev + h->cgbf_ofs[l]; };
+    auto B_ = [&](int l) { return h->dev + h->bias_ofs[l]; };
+    V3D_STOP(0);
+    if ((rc = launch_convg<CG<8, 16, 2, 14, kOutSplit>>("costreg_conv1", F(ws.c0), W_(1), B_(1), nullptr, F(ws.c1), n, D, H, W,
+                                                        s)) != V3D_OK) return rc;
+    V3D_STOP(1);
+    if ((rc = launch_convg<CG<16, 16, 1, 14, kOutF32 | kOutSplit>>("costreg_conv2", F(ws.c1), W_(2), B_(2), F(ws.c2), c2s, n,
+                                                                   D / 2, H / 2, W / 2, s)) != V3D_OK) return rc;
+    V3D_STOP(2);
+    if ((rc = launch_convg<CG<16, 32, 2, 14, kOutSplit>>("costreg_conv3", c2s, W_(3), B_(3), nullptr, F(ws.c3), n, D / 2, H / 2,
+                                                         W / 2, s)) != V3D_OK) return rc;
+    V3D_STOP(3);
+    if ((rc = launch_convg<CG<32, 32, 1, 14, kOutF32 | kOutSplit>>("costreg_conv4", F(ws.c3), W_(4), B_(4), F(ws.c4), c4s, n,
+                                                                   D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
+    V3D_STOP(4);
+    if ((rc = launch_convg<CG<32, 64, 2, 8, kOutSplit>>("costreg_conv5", c4s, W_(5), B_(5), nullptr, F(ws.c5), n, D / 4, H / 4,
+                                                        W / 4, s)) != V3D_OK) return rc;
+    V3D_STOP(5);
+    if ((rc = launch_convg<CG<64, 64, 1, 8, kOutF32>>("costreg_conv6", F(ws.c5), W_(6), B_(6), F(ws.c6), nullptr, n, D / 8,
+                                                      H / 8, W / 8, s)) != V3D_OK) return rc;
+    V3D_STOP(6);
+#undef V3D_STOP
   }
-  RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
-  RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
-  RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
-  RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
+  if (generic) {
+    RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
+    RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
+    RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
+    RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
+  }
   RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
   RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   if (!generic) {
