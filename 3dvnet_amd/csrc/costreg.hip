@@ -928,6 +928,175 @@ __global__ __launch_bounds__(256, 2) void convg_bf16x2_kernel(ConvGParams p) {
   PHASE_FLUSH;
 }
 
+// ---- conv7 / conv8 (transposed convolutions + skip) on split-bf16 matrix cores -------------------------------------
+// ConvTranspose3d(k 3, stride 2, pad 1, output_padding 1): per axis out[2j] = in[j] w[1], out[2j+1] = in[j] w[2] +
+// in[j+1] w[0].  Cell j = outputs (2j, 2j+1) from inputs (j, j+1).  GEMM per chunk of 8 input channels: columns = the
+// cells of an x row, rows = 16 output channels of one of the 8 output parities, K = 32 = (dy, dx) x 8 channels; the
+// (pz, dz) combinations (0,0), (1,0), (1,1) x 4 (py, px) parities = 12 blocks of weights (zero where a parity does not
+// see an input).  A wave keeps the B fragments of its two cell rows in registers and walks the 12 blocks.
+// Input: split channel-last layout; output = ReLU(BN(deconv)) + skip (fp32 [n, COUT, D, H, W]) as fp32 or split.
+template <int CIN_, int COUT_, int WB_, int OUT_>
+struct DG {
+  static constexpr int CIN = CIN_, COUT = COUT_, WB = WB_, OUT = OUT_;
+  static constexpr int NCH = CIN / 8, NCG = COUT / 16;
+  static constexpr int NRB = 16 / WB;                         // cell rows per MFMA column block
+  static constexpr int CZ = 2, CY = 4 * NRB, CX = WB;         // cells per tile; wave w = cell rows w*NRB .. of both cz
+  static constexpr int VZ = CZ + 1, VY = CY + 1, VX = CX + 2; // input voxels (+1 idle column)
+  static constexpr int NVOX = VZ * VY * VX, NVOXP = NVOX + 8;
+  static constexpr int WQ = 12 * 2 * 64;                      // 16-byte words of one chunk's weight image
+  static constexpr int NSLOT = 2 * NVOX;
+  static constexpr int NIT = (NSLOT + 255) / 256, NWIT = (WQ + 255) / 256;
+  static constexpr int LDS_BYTES = (2 * NVOXP + WQ) * 16;
+  static_assert(CIN % 8 == 0 && COUT % 16 == 0 && (WB == 14 || WB == 8), "shape");
+  static_assert(LDS_BYTES <= 64 * 1024, "static LDS");
+};
+
+struct DeconvGParams {
+  const void* in;      // split layout [n][CIN/8][hi, lo][Di][Hi][Wi]
+  const void* wp;      // [NCG][NCH][12][hi, lo][64 lanes][4 words]
+  const float* bias;   // [COUT]
+  const float* skip;   // [n, COUT, 2Di, 2Hi, 2Wi] fp32
+  float* out_f32;      // same shape, or null
+  void* out_split;     // split layout, or null
+  int n, Di, Hi, Wi, ntz, nty, ntx;
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void deconvg_bf16x2_kernel(DeconvGParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [hi, lo][NVOXP]
+  u32x4* const wq = xs + 2 * C::NVOXP;                              // [12][hi, lo][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  const int cg = blockIdx.y;
+  int b = v3d::xcd_contiguous_block();
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int cz0 = tz * C::CZ, cy0 = ty * C::CY, cx0 = tx * C::CX;   // first cell = first input voxel of the tile
+  const int Do = 2 * p.Di, Ho = 2 * p.Hi, Wo = 2 * p.Wi;
+  const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
+  const size_t out_plane = (size_t)Do * Ho * Wo;
+
+  const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::NCH * 2 * in_plane;
+  const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)cg * C::NCH * C::WQ;
+  u32x4 pre[C::NIT], wreg[C::NWIT];
+  auto issue = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int i = it * 256 + tid;
+      const int part = i / C::NVOX, v = i % C::NVOX;
+      const int gz = cz0 + v / (C::VY * C::VX), gy = cy0 + (v / C::VX) % C::VY, gx = cx0 + v % C::VX;
+      const bool ok = i < C::NSLOT && gz < p.Di && gy < p.Hi && gx < p.Wi;       // inputs past the volume do not exist
+      const int zc = min(gz, p.Di - 1), yc = min(gy, p.Hi - 1), xc = min(gx, p.Wi - 1);
+      const u32x4 val = ins[(size_t)(chunk * 2 + min(part, 1)) * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + xc];
+      pre[it] = ok ? val : (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i)
+      wreg[i] = (i * 256 + tid < C::WQ) ? wg[(size_t)chunk * C::WQ + i * 256 + tid] : (u32x4){0u, 0u, 0u, 0u};
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int i = it * 256 + tid;
+      if (i < C::NSLOT) xs[(i / C::NVOX) * C::NVOXP + i % C::NVOX] = pre[it];
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWIT; ++i)
+      if (i * 256 + tid < C::WQ) wq[i * 256 + tid] = wreg[i];
+  };
+  if (tid < 16) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};
+
+  // column jn = (cell row r within the wave's pair, cell x); K lane group kq = (dy, dx)
+  const int lr = jn / C::WB, lxo = jn % C::WB;
+  const int lcy = wave * C::NRB + lr;
+  f32x4 acc[C::CZ][8];
+#pragma unroll
+  for (int z = 0; z < C::CZ; ++z)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[z][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u32x4* const wf = wq + lane;
+
+  issue(0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < C::NCH; ++chunk) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (chunk + 1 < C::NCH) issue(chunk + 1);
+    // B fragments of this wave's cell rows: input planes cz .. cz + 1 for cz = 0 .. CZ-1 => VZ planes
+    bf16x8 b_hi[C::VZ], b_lo[C::VZ];
+#pragma unroll
+    for (int vz = 0; vz < C::VZ; ++vz) {
+      const int slot = (vz * C::VY + lcy + (kq >> 1)) * C::VX + lxo + (kq & 1);
+      b_hi[vz] = __builtin_bit_cast(bf16x8, xs[slot]);
+      b_lo[vz] = __builtin_bit_cast(bf16x8, xs[slot + C::NVOXP]);
+    }
+#pragma unroll
+    for (int pyx = 0; pyx < 4; ++pyx) {
+#pragma unroll
+      for (int zb = 0; zb < 3; ++zb) {                        // (pz, dz) = (0,0), (1,0), (1,1)
+        const int pz = zb == 0 ? 0 : 1, dz = zb == 2 ? 1 : 0;
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, wf[((zb * 4 + pyx) * 2) * 64]);
+        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, wf[((zb * 4 + pyx) * 2 + 1) * 64]);
+#pragma unroll
+        for (int cz = 0; cz < C::CZ; ++cz) {
+          f32x4& c = acc[cz][pz * 4 + pyx];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi[cz + dz], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo[cz + dz], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi[cz + dz], c, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- BN bias + ReLU + skip; the two x parities of a cell are one float2 / adjacent slots ----------------------------
+  const bool live = jn < C::NRB * C::WB;
+  const int gcy = cy0 + lcy, gcx = cx0 + lxo;
+  if (live && gcy < p.Hi && gcx < p.Wi) {
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cg * 16 + 4 * kq + r];
+#pragma unroll
+    for (int cz = 0; cz < C::CZ; ++cz) {
+      const int gcz = cz0 + cz;
+      if (gcz >= p.Di) break;
+#pragma unroll
+      for (int pzy = 0; pzy < 4; ++pzy) {
+        const int pz = pzy >> 1, py = pzy & 1;
+        const size_t sp = ((size_t)(2 * gcz + pz) * Ho + (2 * gcy + py)) * Wo + 2 * gcx;
+        float v0[4], v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t o = ((size_t)n * C::COUT + cg * 16 + 4 * kq + r) * out_plane + sp;
+          const float2 sk = *reinterpret_cast<const float2*>(p.skip + o);
+          v0[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 0][r] + bias[r], 0.f) + sk.x;
+          v1[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 1][r] + bias[r], 0.f) + sk.y;
+          if constexpr ((C::OUT & kOutF32) != 0) *reinterpret_cast<float2*>(p.out_f32 + o) = make_float2(v0[r], v1[r]);
+        }
+        if constexpr ((C::OUT & kOutSplit) != 0) {
+          // this lane holds channels 4 kq .. 4 kq + 3 of group cg * 2 + (kq >> 1): one 8-byte half of the hi / lo slot
+          u32x2* const os = reinterpret_cast<u32x2*>(p.out_split) +
+                            (((size_t)n * (C::COUT / 8) + cg * 2 + (kq >> 1)) * 2 * out_plane) * 2 + (kq & 1);
+          unsigned h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h0[r] = bf16_rne(v0[r]); l0[r] = bf16_rne(v0[r] - __uint_as_float(h0[r] << 16));
+            h1[r] = bf16_rne(v1[r]); l1[r] = bf16_rne(v1[r] - __uint_as_float(h1[r] << 16));
+          }
+          os[sp * 2] = (u32x2){h0[0] | (h0[1] << 16), h0[2] | (h0[3] << 16)};
+          os[(sp + 1) * 2] = (u32x2){h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16)};
+          os[(out_plane + sp) * 2] = (u32x2){l0[0] | (l0[1] << 16), l0[2] | (l0[3] << 16)};
+          os[(out_plane + sp + 1) * 2] = (u32x2){l1[0] | (l1[1] << 16), l1[2] | (l1[3] << 16)};
+        }
+      }
+    }
+  }
+}
+
 // ---- prob conv (base -> 1 channel, bias, no BN/ReLU; mvsnet.py:152,162) ---------------------------
 // A 1-channel output would waste 15/16 of an MFMA, so this layer is register-blocked VALU work:
 // a workgroup owns a PT_D x PT_H x (PT_XG*PT_RX) output tile; CK input channels of the halo'd tile
@@ -1436,10 +1605,31 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
 }
 }  // namespace
 
+namespace {
+template <class C>
+int launch_deconvg(const char* name, const void* in, const float* wbf, const float* bias, const float* skip, float* out_f32,
+                   void* out_split, int n, int Di, int Hi, int Wi, hipStream_t s) {
+  DeconvGParams p;
+  p.in = in; p.wp = wbf; p.bias = bias; p.skip = skip; p.out_f32 = out_f32; p.out_split = out_split; p.n = n;
+  p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+  p.ntz = (Di + C::CZ - 1) / C::CZ; p.nty = (Hi + C::CY - 1) / C::CY; p.ntx = (Wi + C::CX - 1) / C::CX;
+  const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
+  V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
+  V3D_REQUIRE(skip && ((C::OUT & kOutF32) == 0 || out_f32) && ((C::OUT & kOutSplit) == 0 || out_split), V3D_ERR_BAD_ARG,
+              "%s: missing buffer", name);
+  {
+    v3d::TimedScope ts(name, s);
+    deconvg_bf16x2_kernel<C><<<dim3((unsigned)blocks, C::NCG), 256, 0, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH(name);
+  return V3D_OK;
+}
+}  // namespace
+
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, cgbf_ofs[7], c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, cgbf_ofs[7], dgbf_ofs[2], c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -1580,6 +1770,41 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
             }
           }
   }
+  for (int l = 7; l <= 8; ++l) {
+    // split-bf16 images of conv7 / conv8 for deconvg_bf16x2_kernel: [cout group][8-channel chunk][block 12][hi, lo]
+    // [lane 64][4 words]; block = zb * 4 + (py, px), zb = {(pz 0, dz 0), (1, 0), (1, 1)}; rows = output channel,
+    // k = 8 * (dy, dx) + ci.  Kernel tap of (parity p, input d): p 0: d 0 -> 1; p 1: d 0 -> 2, d 1 -> 0.
+    const int cin = l == 7 ? 64 : 32, cout = l == 7 ? 32 : 16, nch = cin / 8, ncg = cout / 16;
+    h->dgbf_ofs[l - 7] = reserve((size_t)ncg * nch * 12 * 2 * 64 * 4);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->dgbf_ofs[l - 7]);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto tap = [](int par, int d) { return par == 0 ? (d == 0 ? 1 : -1) : (d == 0 ? 2 : 0); };
+    for (int g = 0; g < ncg; ++g)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int blk = 0; blk < 12; ++blk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int zb = blk / 4, py = (blk >> 1) & 1, px = blk & 1;
+            const int pz = zb == 0 ? 0 : 1, dz = zb == 2 ? 1 : 0;
+            const int co = g * 16 + (lane & 15), dy = lane >> 5, dx = (lane >> 4) & 1;
+            const int kz = tap(pz, dz), ky = tap(py, dy), kx = tap(px, dx);
+            const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+            unsigned hi[8], lo[8];
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * 8 + e;
+              const float v = (kz < 0 || ky < 0 || kx < 0)
+                                  ? 0.f
+                                  : conv_w[l][((size_t)ci * cout + co) * 27 + kz * 9 + ky * 3 + kx] * sc;
+              hi[e] = rne(v);
+              lo[e] = rne(v - up(hi[e]));
+            }
+            for (int part = 0; part < 2; ++part) {
+              const unsigned* src = part ? lo : hi;
+              unsigned* dst = wb + ((((size_t)g * nch + ch) * 12 + blk) * 2 + part) * 256 + lane * 4;
+              for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+            }
+          }
+  }
   {
     // prob weights for the fused kernel, channel pairs interleaved: [4 pairs][27 taps][2]
     h->prob_w2_ofs = reserve((size_t)base * 27);
@@ -1716,9 +1941,16 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     if ((rc = launch_convg<CG<32, 64, 2, 8, kOutSplit>>("costreg_conv5", c4s, W_(5), B_(5), nullptr, F(ws.c5), n, D / 4, H / 4,
                                                         W / 4, s)) != V3D_OK) return rc;
     V3D_STOP(5);
-    if ((rc = launch_convg<CG<64, 64, 1, 8, kOutF32>>("costreg_conv6", F(ws.c5), W_(6), B_(6), F(ws.c6), nullptr, n, D / 8,
-                                                      H / 8, W / 8, s)) != V3D_OK) return rc;
+    if ((rc = launch_convg<CG<64, 64, 1, 8, kOutSplit>>("costreg_conv6", F(ws.c5), W_(6), B_(6), nullptr, F(ws.c6), n, D / 8,
+                                                        H / 8, W / 8, s)) != V3D_OK) return rc;
     V3D_STOP(6);
+    // conv4 + conv7(x) (mvsnet.py:159), conv2 + conv8(x) (:160)
+    if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit>>("costreg_conv7", F(ws.c6), h->dev + h->dgbf_ofs[0], B_(7), F(ws.c4),
+                                                       nullptr, F(ws.u7), n, D / 8, H / 8, W / 8, s)) != V3D_OK) return rc;
+    V3D_STOP(7);
+    if ((rc = launch_deconvg<DG<32, 16, 14, kOutF32>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8), F(ws.c2),
+                                                      F(ws.u8), nullptr, n, D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
+    V3D_STOP(8);
 #undef V3D_STOP
   }
   if (generic) {
@@ -1726,9 +1958,9 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
     RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
     RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
+    RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
+    RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   }
-  RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
-  RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   if (!generic) {
     C9Params q;
     q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
