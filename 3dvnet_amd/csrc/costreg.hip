@@ -1229,7 +1229,7 @@ struct C9 {
 };
 
 struct C9Params {
-  const float* u8;     // [n, 16, D/2, H/2, W/2]
+  const float* u8;     // conv8 output in the split layout [n][2 groups][hi, lo][D/2][H/2][W/2][8 bf16]
   const float* c0;     // conv0 output (skip) in the split channel-last layout [n][hi, lo][D][H][W][8 bf16]
   const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)
   const float* bias9;  // [8] folded BN bias
@@ -1262,19 +1262,22 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
   PHASE_DECL;
   // ---- global reads are requested in batches with clamped addresses (no branches): (a) the 4 x 6 x 16 x 16ch
   // input tile and the weight fragments now; vmcnt can track 63 loads, so the skip values follow after staging
-  float v[3][8];
-  bool vok[3];
+  // u8 arrives in the split channel-last layout ([n][2 groups][hi, lo][D/2][H/2][W/2] slots): 2 x 2 x 384 slots, six
+  // 16-byte copies per thread
+  u32x4 pre[6];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.u8) + (size_t)n * 4 * in_plane;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int it = tid + 256 * i;
-    const int half = it / 384, vox = it % 384;
-    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-    const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
-    vok[i] = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-    const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1), xc = min(max(gx, 0), W2 - 1);
-    const float* src = p.u8 + ((size_t)n * 16 + half * 8) * in_plane + ((size_t)zc * H2 + yc) * W2 + xc;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[i][e] = src[(size_t)e * in_plane];
+    for (int i = 0; i < 6; ++i) {
+      const int it = tid + 256 * i;
+      const int gp = it / 384, vox = it % 384;                       // gp = group * 2 + part
+      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
+      const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+      const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1), xc = min(max(gx, 0), W2 - 1);
+      const u32x4 val = src[(size_t)gp * in_plane + ((size_t)zc * H2 + yc) * W2 + xc];
+      pre[i] = ok ? val : (u32x4){0u, 0u, 0u, 0u};
+    }
   }
   // weight fragments stay in registers: block (tz3, ty3), tz3 = {(pz 0, dz 0), (0, 1), (1, 1)} likewise ty3
   bf16x8 a_hi[9], a_lo[9];
@@ -1289,22 +1292,14 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
 
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- stage the input tile as split bf16, channel-last ------------------------------------------------------
+  // ---- stage the input tile: slot = voxel * 2 + channel half (group), hi and lo arrays -----------------------------
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 6; ++i) {
     const int it = tid + 256 * i;
-    const int half = it / 384, vox = it % 384;
+    const int gp = it / 384, vox = it % 384;
     const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = vok[i] ? v[i][e] : 0.f;
-      h[e] = bf16_rne(x);
-      l[e] = bf16_rne(x - __uint_as_float(h[e] << 16));
-    }
-    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + half;
-    xh[slot] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    xl[slot] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + (gp >> 1);
+    ((gp & 1) ? xl : xh)[slot] = pre[i];
   }
   if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
     const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
@@ -1948,8 +1943,8 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit>>("costreg_conv7", F(ws.c6), h->dev + h->dgbf_ofs[0], B_(7), F(ws.c4),
                                                        nullptr, F(ws.u7), n, D / 8, H / 8, W / 8, s)) != V3D_OK) return rc;
     V3D_STOP(7);
-    if ((rc = launch_deconvg<DG<32, 16, 14, kOutF32>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8), F(ws.c2),
-                                                      F(ws.u8), nullptr, n, D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
+    if ((rc = launch_deconvg<DG<32, 16, 14, kOutSplit>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8), F(ws.c2),
+                                                        nullptr, F(ws.u8), n, D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
     V3D_STOP(8);
 #undef V3D_STOP
   }
