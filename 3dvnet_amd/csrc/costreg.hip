@@ -1452,6 +1452,24 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
   PHASE_FLUSH;
 }
 
+// ---- fp32 [n, C, D, H, W] -> split channel-last layout (per-layer entry point of the split kernels) ----------------
+__global__ __launch_bounds__(256) void encode_split_kernel(const float* __restrict__ in, u32x4* __restrict__ out, int C,
+                                                           size_t plane, size_t total) {   // total = n * (C / 8) * plane
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t sp = i % plane, ng = i / plane;                 // ng = n * (C / 8) + group
+  const float* src = in + (ng * 8) * plane + sp;               // channels of a group are consecutive planes
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float v = src[(size_t)c * plane];
+    h[c] = bf16_rne(v);
+    l[c] = bf16_rne(v - __uint_as_float(h[c] << 16));
+  }
+  out[(ng * 2) * plane + sp] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  out[(ng * 2 + 1) * plane + sp] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+}
+
 // ---- soft-argmin over D (mvsnet.py:219-227): p = softmax(-x), depth = sum_d vals[d] p[d] ----------
 __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restrict__ reg,
                                                           const float* __restrict__ vals,
@@ -1855,6 +1873,40 @@ extern "C" int v3d_costreg_layer_f32(const v3d_costreg_weights* h, int layer, co
   V3D_REQUIRE(h && in && out, V3D_ERR_BAD_ARG, "v3d_costreg_layer_f32: null argument");
   V3D_REQUIRE(n > 0 && Di > 0 && Hi > 0 && Wi > 0, V3D_ERR_BAD_SHAPE, "v3d_costreg_layer_f32: bad shape");
   return run_layer(h, layer, in, skip, out, n, Di, Hi, Wi, (hipStream_t)stream);
+}
+
+extern "C" size_t v3d_costreg_layer_split_workspace_bytes(int n, int cin, int Di, int Hi, int Wi) {
+  if (n <= 0 || cin <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  return v3d::align_up((size_t)n * cin * Di * Hi * Wi * sizeof(float), 256);
+}
+
+extern "C" int v3d_costreg_layer_split_f32(const v3d_costreg_weights* h, int layer, const float* in, const float* skip,
+                                           int n, int Di, int Hi, int Wi, float* out, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  static const int cins[9] = {32, 8, 16, 16, 32, 32, 64, 64, 32};
+  V3D_REQUIRE(h && in && out && workspace, V3D_ERR_BAD_ARG, "v3d_costreg_layer_split_f32: null argument");
+  V3D_REQUIRE(layer >= 1 && layer <= 8, V3D_ERR_BAD_ARG, "v3d_costreg_layer_split_f32: layer %d (1..8: conv1..conv8)", layer);
+  V3D_REQUIRE(n > 0 && Di > 0 && Hi > 0 && Wi > 0, V3D_ERR_BAD_SHAPE, "v3d_costreg_layer_split_f32: bad shape");
+  V3D_REQUIRE(layer < 7 || skip, V3D_ERR_BAD_ARG, "v3d_costreg_layer_split_f32: conv7 / conv8 need the skip tensor");
+  const int cin = cins[layer];
+  V3D_REQUIRE(workspace_bytes >= v3d_costreg_layer_split_workspace_bytes(n, cin, Di, Hi, Wi), V3D_ERR_WORKSPACE_TOO_SMALL,
+              "v3d_costreg_layer_split_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t plane = (size_t)Di * Hi * Wi, total = (size_t)n * (cin / 8) * plane;
+  encode_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(in, (u32x4*)workspace, cin, plane, total);
+  V3D_CHECK_LAUNCH("encode_split_kernel");
+  const float* w = h->dev + (layer <= 6 ? h->cgbf_ofs[layer] : h->dgbf_ofs[layer - 7]);
+  const float* bias = h->dev + h->bias_ofs[layer];
+  switch (layer) {
+    case 1: return launch_convg<CG<8, 16, 2, 14, kOutF32>>("costreg_conv1", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 2: return launch_convg<CG<16, 16, 1, 14, kOutF32>>("costreg_conv2", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 3: return launch_convg<CG<16, 32, 2, 14, kOutF32>>("costreg_conv3", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 4: return launch_convg<CG<32, 32, 1, 14, kOutF32>>("costreg_conv4", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 5: return launch_convg<CG<32, 64, 2, 8, kOutF32>>("costreg_conv5", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 6: return launch_convg<CG<64, 64, 1, 8, kOutF32>>("costreg_conv6", workspace, w, bias, out, nullptr, n, Di, Hi, Wi, s);
+    case 7: return launch_deconvg<DG<64, 32, 8, kOutF32>>("costreg_conv7", workspace, w, bias, skip, out, nullptr, n, Di, Hi, Wi, s);
+    default: return launch_deconvg<DG<32, 16, 14, kOutF32>>("costreg_conv8", workspace, w, bias, skip, out, nullptr, n, Di, Hi, Wi, s);
+  }
 }
 
 namespace {

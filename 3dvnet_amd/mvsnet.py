@@ -157,8 +157,10 @@ class CostRegNet(nn.Module):
         _lib.check(rc, 'v3d_costreg_depth_split' if split else 'v3d_costreg_depth_f32')
         return (depth, reg) if return_reg else depth
 
-    def run_layer(self, layer, x, skip=None):
-        """One conv/deconv + folded BN + ReLU (+ skip) layer, for per-layer parity tests."""
+    def run_layer(self, layer, x, skip=None, split=False):
+        """One conv/deconv + folded BN + ReLU (+ skip) layer, for per-layer parity tests.
+        `split=True` (layers 1..8): the kernel the fused path uses for that layer (split-bf16 matrix
+        cores); default: the exact-fp32 per-layer kernel (layer 0: always its product kernel)."""
         _require_cuda(x, 'CostRegNet')
         lib = _lib.load()
         x = x.contiguous().float()
@@ -173,6 +175,14 @@ class CostRegNet(nn.Module):
         if skip is not None:
             skip = skip.contiguous().float()
             assert skip.shape == out.shape
+        if split:
+            nbytes = lib.v3d_costreg_layer_split_workspace_bytes(n, x.shape[1], Di, Hi, Wi)
+            ws = self._ws.get('layer_split', nbytes, x.device)
+            rc = lib.v3d_costreg_layer_split_f32(self.packed_handle(), layer, _lib.ptr(x), _lib.ptr(skip), n,
+                                                 Di, Hi, Wi, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr(x.device))
+            _lib.check(rc, 'v3d_costreg_layer_split_f32')
+            return out
         rc = lib.v3d_costreg_layer_f32(self.packed_handle(), layer, _lib.ptr(x), _lib.ptr(skip), n,
                                        Di, Hi, Wi, _lib.ptr(out), _lib.stream_ptr(x.device))
         _lib.check(rc, 'v3d_costreg_layer_f32')

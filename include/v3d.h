@@ -122,6 +122,15 @@ int v3d_costreg_depth_split(const v3d_costreg_weights* handle, const void* var_s
 int v3d_costreg_layer_f32(const v3d_costreg_weights* handle, int layer, const float* in,
                           const float* skip, int n, int Di, int Hi, int Wi, float* out, void* stream);
 
+/* The same layers 1..8 (conv1..conv8) on the kernels the fused path uses: split-bf16 matrix cores reading the split
+ * channel-last activation layout.  `in`, `skip` (conv7 / conv8, required) and `out` are fp32 [n, C, D, H, W]; the
+ * input is re-encoded into `workspace` (>= v3d_costreg_layer_split_workspace_bytes).  Layer 0 already runs its
+ * product kernel through v3d_costreg_layer_f32; conv9 only exists fused with the prob conv (v3d_costreg_depth_*). */
+size_t v3d_costreg_layer_split_workspace_bytes(int n, int cin, int Di, int Hi, int Wi);
+int v3d_costreg_layer_split_f32(const v3d_costreg_weights* handle, int layer, const float* in, const float* skip,
+                                int n, int Di, int Hi, int Wi, float* out, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rows B1-B2 and C1: back-project depth pixels / depth hypotheses to world points and compute their
  * multi-view variance feature.  Replaces mv3d/utils.py:67-83 (build_img_pts),

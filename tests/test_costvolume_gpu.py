@@ -233,6 +233,34 @@ def test_costreg_single_layers(layer, cuda):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5 if layer else 0, atol=tol)
 
 
+@pytest.mark.parametrize('layer', list(range(1, 9)))
+def test_costreg_single_layers_split_kernels(layer, cuda):
+    """conv1..conv8 on the kernels of the fused path (split-bf16 matrix cores, split channel-last activations) vs
+    torch CPU, on volumes that are not multiples of their tiles.  Operands carry 16 mantissa bits and K reaches 1728:
+    tolerance 4e-5 of max|out| (measured <= 1e-5)."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    sd = syn.costregnet_weights(seed=6)
+    net = mvs.CostRegNet(32, 8).eval()
+    net.load_state_dict(sd, strict=False)
+    net = net.to(cuda)
+    cin = [32, 8, 16, 16, 32, 32, 64, 64, 32, 16][layer]
+    g = torch.Generator().manual_seed(100 + layer)
+    shape = (2, cin, 6, 10, 18) if layer < 7 else (2, cin, 3, 5, 9)
+    x = torch.randn(shape, generator=g)
+    name = 'conv%d' % layer
+    if layer < 7:
+        ref = ocv.conv_bn_relu3d(x, sd, name, stride=2 if layer in (1, 3, 5) else 1)
+        skip = None
+    else:
+        ref = ocv.deconv_bn_relu3d(x, sd, name)
+        skip = torch.randn(ref.shape, generator=g)
+        ref = skip + ref
+    out = net.run_layer(layer, x.to(cuda), None if skip is None else skip.to(cuda), split=True)
+    torch.cuda.synchronize()
+    err = float((out.cpu() - ref).abs().max())
+    assert err <= 4e-5 * max(1.0, float(ref.abs().max())), err
+
+
 def test_full_size_properties_cfg2_batch(cuda):
     """BASELINE config-2 size, several references per launch: size-independent properties.
     (1) a reference whose sources are all the reference itself has zero variance everywhere the
