@@ -51,12 +51,21 @@ def kernel_roofline(name, avg_ms, shape):
     elif name.startswith('costreg_conv'):
         layer = int(name[len('costreg_conv'):])
         ci, co, div = COSTREG_LAYERS[layer]
-        flops = 2.0 * 27 * ci * co * (vox // div) * n_ref
-        a = flops / (avg_ms * 1e-3) / 1e12
-        # conv0, conv1, conv2 run on bf16 MFMAs with every fp32 product split into 3 bf16 products (hi*hi + hi*lo + lo*hi):
-        # its ceiling in algorithmic FLOPs is the dense bf16 peak / 3; the other layers use fp32 MFMAs
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if layer in (0, 1, 2) else PEAK_F32_MFMA_TFLOPS
-        return dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak)
+        work_vox = vox // div                      # output voxels (conv) / input voxels (transposed conv)
+        if layer == 0:
+            # conv0 runs on bf16 MFMAs with each fp32 product split into 3 bf16 products (hi*hi + hi*lo + lo*hi):
+            # the ceiling in algorithmic FLOPs is the dense bf16 peak / 3
+            flops = 2.0 * 27 * ci * co * work_vox * n_ref
+            a = flops / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            return dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak)
+        # conv1..conv8: a few hundred MFMAs per workgroup -- bound by moving their activations (4 bytes per value in the
+        # split layout as in fp32): input + output (+ the fp32 copy conv2 / conv4 keep for the skips, + the skip read)
+        if layer in (7, 8):
+            nbytes = 4.0 * n_ref * (ci * work_vox + 2 * co * 8 * work_vox)
+        else:
+            vox_in = work_vox * (8 if layer in (1, 3, 5) else 1)
+            nbytes = 4.0 * n_ref * (ci * vox_in + co * work_vox * (2 if layer in (2, 4) else 1))
     elif name == 'costreg_prob':
         nbytes = 4.0 * n_ref * vox * (8 + 1)
     elif name == 'soft_argmin':

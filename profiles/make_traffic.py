@@ -9,9 +9,10 @@ import json
 import sys
 
 # substring of the (shortened) kernel symbol -> the name bench.py / the library's timing log uses
-NAMES = [('psv_variance_reuse_kernel', 'psv_variance'), ('psv_variance_kernel', 'psv_variance'), ('conv0_bf16x2_kernel', 'costreg_conv0'),
-         ('conv9_prob_kernel', 'costreg_conv9_prob'), ('ConvCfg<1, 8, 16', 'costreg_conv1'),
-         ('ConvCfg<0, 16, 16', 'costreg_conv2'), ('soft_argmin_kernel', 'soft_argmin')]
+NAMES = [('psv_variance_reuse_kernel', 'psv_variance'), ('psv_variance_kernel', 'psv_variance'),
+         ('conv0_bf16x2_kernel', 'costreg_conv0'), ('conv9_prob_kernel', 'costreg_conv9_prob'),
+         ('convg_bf16x2_kernel<CG<8, 16', 'costreg_conv1'), ('convg_bf16x2_kernel<CG<16, 16', 'costreg_conv2'),
+         ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin')]
 
 
 def read(path):
