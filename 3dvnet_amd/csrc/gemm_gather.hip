@@ -75,6 +75,30 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // depth gate is 1e-4).  The activation tile is then [row][32 k] bf16 (64 B rows, hi and lo
 // arrays) with the 16-B k-group slot XOR-swizzled by the row so that every ds_read_b128 lane group hits 16
 // distinct slots; weight fragments are split and packed on the host.
+#ifdef V3D_PHASE_TIMING
+// developer build only: per-phase cycle counters (wave 0 of every workgroup), see costreg.hip
+constexpr int kPhaseSlots = 1 << 16;
+__device__ unsigned long long g_gg_phase[8 * kPhaseSlots];
+#define PHASE_DECL                                  \
+  long long ph_t = __builtin_readcyclecounter();    \
+  long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i)                                   \
+  do {                                                  \
+    long long t_ = __builtin_readcyclecounter();        \
+    ph_acc[i] += t_ - ph_t;                             \
+    ph_t = t_;                                          \
+  } while (0)
+#define PHASE_FLUSH                                                                                      \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < kPhaseSlots)                                                    \
+      for (int i_ = 0; i_ < 8; ++i_) g_gg_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_];   \
+  } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_FLUSH
+#endif
+
 template <int MBW, int NB, bool BF16>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   constexpr int kTM = 16 * NB;
@@ -198,17 +222,22 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
     for (int i = 0; i < WPT; ++i) reinterpret_cast<f32x4*>(ws)[tid + i * 256] = wr[i];
   };
 
+  PHASE_DECL;
   int rcur[NPASS], rnxt[NPASS];
   if (nact > 0) {
     rows_of(s_list[0], rcur);
     issue(s_list[0], 0, rcur);
     if (nact > 1) rows_of(s_list[1], rnxt);
   }
+  PHASE_MARK(0);
   for (int a = 0; a < nact; ++a) {
     for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();
+      PHASE_MARK(1);
       commit();
+      PHASE_MARK(2);
       __syncthreads();
+      PHASE_MARK(3);
       if (kc + 1 < nkc) {
         issue(s_list[a], kc + 1, rcur);
       } else if (a + 1 < nact) {
@@ -217,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
         issue(s_list[a + 1], 0, rcur);
         if (a + 2 < nact) rows_of(s_list[a + 2], rnxt);       // one whole segment ahead of its first use
       }
+      PHASE_MARK(4);
       // ---- MFMA ------------------------------------------------------------------------------------------
       if constexpr (BF16) {
         const u32x4* wq = reinterpret_cast<const u32x4*>(ws);
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
     }
   }
 
+  PHASE_MARK(5);
   // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -310,6 +341,8 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
       }
     }
   }
+  PHASE_MARK(6);
+  PHASE_FLUSH;
 }
 
 __global__ void fill_kernel(float* p, size_t n, float v) {
@@ -463,3 +496,15 @@ extern "C" int v3d_fill_f32(float* ptr, size_t n, float value, void* stream) {
   V3D_CHECK_LAUNCH("fill_kernel");
   return V3D_OK;
 }
+
+#ifdef V3D_PHASE_TIMING
+extern "C" int v3d_debug_gemm_phase_read(unsigned long long* out8_host, int n_blocks) {
+  V3D_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)8 * kPhaseSlots);
+  V3D_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gg_phase), h.size() * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) out8_host[i] = 0;
+  for (int b = 0; b < n_blocks && b < kPhaseSlots; ++b)
+    for (int i = 0; i < 8; ++i) out8_host[i] += h[(size_t)b * 8 + i];
+  return V3D_OK;
+}
+#endif
