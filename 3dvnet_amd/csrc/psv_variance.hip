@@ -846,6 +846,9 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
               V3D_ERR_BAD_ARG, "v3d_psv_variance_f32: null pointer argument");
   V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED,
               "v3d_psv_variance_f32: C=%d unsupported (16 or 32)", C);
+  // the reuse kernel divides by W - 1 and H - 1 through their correctly rounded reciprocals (exact unless the divisor's
+  // significand is all ones, i.e. >= 2^24 - 1)
+  V3D_REQUIRE(W <= (1 << 20) && H <= (1 << 20), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: image size out of range");
   V3D_REQUIRE(!split || C == 32, V3D_ERR_UNSUPPORTED,
               "v3d_psv_variance_split: C=%d unsupported (the split layout is defined for 32 channels)", C);
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 &&
