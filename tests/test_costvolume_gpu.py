@@ -193,6 +193,27 @@ def test_psv_kernel_variants_bit_identical(cuda):
     assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
 
 
+def test_generic_fp32_chain_agrees_with_split_bf16_chain(cuda, tmp_path):
+    """V3D_COSTREG_GENERIC=1 runs the regulariser on the exact-fp32 per-layer kernels (conv9 and the prob conv
+    unfused); the default chain runs on split-bf16 matrix cores.  Both are within 1e-4 of the oracle, hence within
+    2e-4 of each other; the regularised volumes agree to 4e-4 of their range."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for i, extra in enumerate(({}, {'V3D_COSTREG_GENERIC': '1'})):
+        path = str(tmp_path / ('d%d.npz' % i))
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'costreg_depth_dump.py'), path],
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(path))
+    np.testing.assert_allclose(res[0]['depth'], res[1]['depth'], rtol=2e-4, atol=0)
+    scale = float(np.abs(res[1]['reg']).max())
+    np.testing.assert_allclose(res[0]['reg'], res[1]['reg'], rtol=0, atol=4e-4 * scale)
+    assert not np.array_equal(res[0]['depth'], res[1]['depth'])      # the switch really selected another chain
+
+
 def test_psv_feat_dim_16(cuda):
     syn, mvs = v3d('synthetic'), v3d('mvsnet')
     img_size, plane_size = (64, 80), (8, 8)
