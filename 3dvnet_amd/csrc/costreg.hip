@@ -1,9 +1,23 @@
 // Rows A5-A6 of SURVEY.md §8a: CostRegNet (dense 3D-conv U-Net, eval-mode BatchNorm folded) and the
 // soft-argmin depth.  Reference semantics: mv3d/subnetworks/mvsnet.py:18-36,133-163,219-227.
 //
-// All ten conv / transposed-conv layers run through ONE templated implicit-GEMM kernel on the
-// exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain, so the 1e-4 depth parity
-// gate is met with fp32 operands and fp32 accumulation):
+// Two families of kernels live here.
+//
+// (1) The fused path (v3d_costreg_depth_f32 / _split): every layer on split-bf16 matrix cores.  Each fp32 operand
+//     x = hi + lo (hi = RNE_bf16(x), lo = RNE_bf16(x - hi), 16 mantissa bits), each product hi*hi + hi*lo + lo*hi on
+//     v_mfma_f32_16x16x32_bf16 with fp32 accumulation; activations travel between layers in the split channel-last
+//     layout [n][C/8 groups][hi, lo][D][H][W][8 bf16] (4 bytes per value, every staging loop a 16-byte copy):
+//       conv0_bf16x2_kernel      32 -> 8 at full resolution (68 % of the MACs), pair mode, 4 chunks of 8 channels
+//       convg_bf16x2_kernel      conv1..conv6 (stride 1 / 2), 8 input channels per chunk, 16 output channels per workgroup
+//       deconvg_bf16x2_kernel    conv7, conv8 (transposed conv as a GEMM over 2x2x2 output cells) + fp32 skip
+//       conv9_prob_kernel        conv9 + conv0 skip + the 8 -> 1 prob conv, the 8-channel tensor stays in LDS
+//       soft_argmin_kernel       softmax(-x) expectation over the depth planes
+//     Final depth vs the fp32 CPU oracle: 5e-5 relative (gate 1e-4).
+//
+// (2) The exact-fp32 per-layer kernels (v3d_costreg_layer_f32, and the whole chain under V3D_COSTREG_GENERIC=1):
+//     one templated implicit-GEMM kernel on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), described below, plus
+//     prob_conv_kernel.  They were the round's first correct path and remain the reference point for the split
+//     kernels' per-layer parity tests.
 //
 //   D[co, voxel] += W'[co, k] * X[k, voxel],  k = (input channel, kernel tap)
 //
@@ -22,7 +36,7 @@
 //     output_padding 1) is decomposed into its 8 output-parity classes, each a dense gather with
 //     1..8 taps (out[o] = sum_k in[(o+1-k)/2] W[k] for (o+1-k) even).
 //
-// The final `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
+// The unfused `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
 // and the depth softmax + expectation is a per-pixel streaming reduction.
 #include <cstdlib>
 #include <type_traits>
