@@ -659,9 +659,42 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
     PHASE_MARK(5);
   }
 
-  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1.  The tile goes through LDS ([co][z][y][28 x], co stride
-  // padded by 4 floats against bank conflicts) so that it leaves as 16-byte row segments instead of 32 4-byte
-  // stores per lane.
+  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1: lane (kq, jn) holds channels 4 (kq & 1) .. +3 of voxel
+  // x = 2 jn + (kq >> 1).
+  if constexpr (SPLIT_OUT) {
+    // split layout: those 4 channels are one 8-byte half of the voxel's hi slot and of its lo slot; the 4 lane
+    // quarters of a wave instruction cover 16 x 2 consecutive slots completely -> direct stores, no LDS round trip
+    const size_t out_plane_s = (size_t)p.Do * p.Ho * p.Wo;
+    const int sx = kq >> 1, cbase = 4 * (kq & 1);
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
+    u32x2* const outs = reinterpret_cast<u32x2*>(p.out) + ((size_t)n * 2 * out_plane_s) * 2 + (kq & 1);
+    const int gx = ox0 + 2 * jn + sx;
+    if (jn < C0::TW / 2 && gx < p.Wo) {
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        const int gz = oz0 + (j >> 1), gy = oy0 + wave * 2 + (j & 1);
+        if (gz >= p.Do || gy >= p.Ho) continue;
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float val = acc[j][r] + bias[r];
+          if (p.relu) val = fmaxf(val, 0.f);
+          h[r] = bf16_rne(val);
+          l[r] = bf16_rne(val - __uint_as_float(h[r] << 16));
+        }
+        const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+        outs[sp * 2] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        outs[(out_plane_s + sp) * 2] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+      }
+    }
+    PHASE_MARK(6);
+    PHASE_FLUSH;
+    return;
+  }
+  // fp32 output: the tile goes through LDS ([co][z][y][28 x], co stride padded by 4 floats against bank conflicts)
+  // so that it leaves as 16-byte row segments instead of 32 4-byte stores per lane.
   constexpr int OCS = C0::TD * C0::TH * C0::TW + 4;
   float* const os = reinterpret_cast<float*>(smem);
   __syncthreads();                 // every wave is done reading the input tile
@@ -685,28 +718,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   }
   __syncthreads();
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
-  if constexpr (SPLIT_OUT) {
-    constexpr int NV = C0::TD * C0::TH * C0::TW;
-    u32x4* const outs = reinterpret_cast<u32x4*>(p.out) + (size_t)n * 2 * out_plane;
-#pragma unroll
-    for (int k = 0; k < (NV + 255) / 256; ++k) {
-      const int i = k * 256 + tid;
-      if (i >= NV) break;
-      const int row = i / C0::TW, x = i % C0::TW;
-      const int gz = oz0 + row / C0::TH, gy = oy0 + row % C0::TH, gx = ox0 + x;
-      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
-      unsigned h[8], l[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float v = os[c * OCS + row * C0::TW + x];
-        h[c] = bf16_rne(v);
-        l[c] = bf16_rne(v - __uint_as_float(h[c] << 16));
-      }
-      const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-      outs[sp] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-      outs[out_plane + sp] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-    }
-  } else {
+  {
   constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
 #pragma unroll
   for (int k = 0; k < (NQ + 255) / 256; ++k) {
