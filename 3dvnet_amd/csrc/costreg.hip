@@ -489,8 +489,11 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 // ([n][4 chunks][hi, lo][D][H][W] 16-byte slots): staging is then 16-byte copies, no conversion.
 // SPLIT_OUT: the 8 output channels of a voxel leave as one hi slot and one lo slot of the split channel-last layout
 // ([n][hi, lo][D][H][W] 16-byte slots) consumed by convh_bf16x2_kernel (conv1) and conv9_prob_kernel (skip).
-template <bool SPLIT_IN, bool SPLIT_OUT>
-__global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
+// NW = waves per workgroup (4 or 8): with 8, a wave owns one output row of the 4 planes and a CU holds 4 waves per SIMD
+// (2 workgroups), so one wave's LDS / barrier waits are covered by another's MFMAs.
+template <bool SPLIT_IN, bool SPLIT_OUT, int NW>
+__global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvParams p) {
+  constexpr int NT = 64 * NW, RPI = NT / 32, RPW = C0::TH / NW;      // threads, staging rows per iteration, rows per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);                           // [NVOXI] hi slots
   u32x4* const xl = xh + C0::NVOXI;                                           // [NVOXI] lo slots
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   // MFMA role: wave w owns output rows y = 2w, 2w+1 for all TD planes; one column block = the 14 x pairs of a row
   // (lanes 14, 15 idle), so an input row fetched from LDS feeds up to 3 output planes (z reuse).
   static_assert(C0::TH == 8 && C0::TW == 28, "wave -> row mapping");
-  constexpr int NACC = C0::TD * 2;
+  constexpr int NACC = C0::TD * RPW;
   f32x4 acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -534,9 +537,10 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   const int sgx = ix0 + lx;
   const bool xok = lx < C0::IW;
   const bool xin = xok && sgx >= 0 && sgx < p.Wi;
-  constexpr int NITS_S = (2 * C0::SROWS + 7) / 8;               // split input: 60 hi rows then 60 lo rows
-  constexpr int NWQ = (C0::WU32 / 4 + 255) / 256;               // 16-byte weight loads per thread (4.5 -> 5)
-  float pre[SPLIT_IN ? 1 : C0::NITS][C0::CG];
+  constexpr int NITS_S = (2 * C0::SROWS + RPI - 1) / RPI;       // split input: 60 hi rows then 60 lo rows
+  constexpr int NITS_F = (C0::SROWS + RPI - 1) / RPI;           // fp32 input: 60 rows x 8 channels
+  constexpr int NWQ = (C0::WU32 / 4 + NT - 1) / NT;             // 16-byte weight loads per thread
+  float pre[SPLIT_IN ? 1 : NITS_F][C0::CG];
   u32x4 pres[SPLIT_IN ? NITS_S : 1];
   u32x4 wreg[NWQ];
   const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * 8 * in_plane + lx;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
       constexpr int per = (NITS_S + 2) / 3;
 #pragma unroll
       for (int it = part * per; it < (part + 1) * per && it < NITS_S; ++it) {
-        const int rr = it * 8 + grp;
+        const int rr = it * RPI + grp;
         const int hl = rr >= C0::SROWS ? 1 : 0;
         const int g = rowg[rr - hl * C0::SROWS];               // rows 60..63 of the table are out of range
         pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin)
@@ -557,11 +561,11 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
                        : (u32x4){0u, 0u, 0u, 0u};
       }
     } else {
-      constexpr int per = (C0::NITS + 2) / 3;
+      constexpr int per = (NITS_F + 2) / 3;
       const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
 #pragma unroll
-      for (int it = part * per; it < (part + 1) * per && it < C0::NITS; ++it) {
-        const int g = rowg[it * 8 + grp];
+      for (int it = part * per; it < (part + 1) * per && it < NITS_F; ++it) {
+        const int g = rowg[min(it * RPI + grp, 63)];
 #pragma unroll
         for (int c = 0; c < C0::CG; ++c) pre[it][c] = (g != kRowOob && xin) ? inc[(size_t)c * in_plane + g] : 0.f;
       }
@@ -570,20 +574,20 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
     constexpr int wper = (NWQ + 2) / 3;
 #pragma unroll
     for (int i = part * wper; i < (part + 1) * wper && i < NWQ; ++i)
-      wreg[i] = (i * 256 + tid < C0::WU32 / 4) ? wc[i * 256] : (u32x4){0u, 0u, 0u, 0u};
+      wreg[i] = (i * NT + tid < C0::WU32 / 4) ? wc[i * NT] : (u32x4){0u, 0u, 0u, 0u};
   };
   auto commit = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT_IN) {
 #pragma unroll
       for (int it = 0; it < NITS_S; ++it) {
-        const int rr = it * 8 + grp;
+        const int rr = it * RPI + grp;
         const int hl = rr >= C0::SROWS ? 1 : 0;
         if (rr < 2 * C0::SROWS && xok) (hl ? xl : xh)[rowd[rr - hl * C0::SROWS] + lx] = pres[it];
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < C0::NITS; ++it) {
-        const int d = rowd[it * 8 + grp];
+      for (int it = 0; it < NITS_F; ++it) {
+        const int d = rowd[min(it * RPI + grp, 63)];
         if (d >= 0 && xok) {
           unsigned h[8], l[8];
 #pragma unroll
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NWQ; ++i)
-      if (i * 256 + tid < C0::WU32 / 4) reinterpret_cast<u32x4*>(wsu)[i * 256 + tid] = wreg[i];
+      if (i * NT + tid < C0::WU32 / 4) reinterpret_cast<u32x4*>(wsu)[i * NT + tid] = wreg[i];
   };
   // one ky slice of the 27 taps: the 3 kz weight fragments stay in registers, every input row read from LDS feeds
   // up to 3 output planes
@@ -611,8 +615,8 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
       a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
     }
 #pragma unroll
-    for (int yy = 0; yy < 2; ++yy) {
-      const int rowbase = (wave * 2 + yy + ky) * C0::IW + 2 * jn + kq;
+    for (int yy = 0; yy < RPW; ++yy) {
+      const int rowbase = (wave * RPW + yy + ky) * C0::IW + 2 * jn + kq;
 #pragma unroll
       for (int iz = 0; iz < C0::ID; ++iz) {
         const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[rowbase + iz * C0::IH * C0::IW]);
@@ -620,17 +624,17 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z = iz - kz;
-          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z * 2 + yy], 0, 0, 0);
+          if (z >= 0 && z < C0::TD) acc[z * RPW + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z * RPW + yy], 0, 0, 0);
         }
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z = iz - kz;
-          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z * 2 + yy], 0, 0, 0);
+          if (z >= 0 && z < C0::TD) acc[z * RPW + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z * RPW + yy], 0, 0, 0);
         }
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           const int z = iz - kz;
-          if (z >= 0 && z < C0::TD) acc[z * 2 + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z * 2 + yy], 0, 0, 0);
+          if (z >= 0 && z < C0::TD) acc[z * RPW + yy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z * RPW + yy], 0, 0, 0);
         }
       }
     }
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
     if (jn < C0::TW / 2 && gx < p.Wo) {
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
-        const int gz = oz0 + (j >> 1), gy = oy0 + wave * 2 + (j & 1);
+        const int gz = oz0 + j / RPW, gy = oy0 + wave * RPW + j % RPW;
         if (gz >= p.Do || gy >= p.Ho) continue;
         unsigned h[4], l[4];
 #pragma unroll
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
     if (jn < C0::TW / 2) {
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
-        const int row = (j >> 1) * C0::TH + wave * 2 + (j & 1);
+        const int row = (j / RPW) * C0::TH + wave * RPW + j % RPW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float val = acc[j][r] + bias[r];
@@ -721,8 +725,8 @@ __global__ __launch_bounds__(256, 2) void conv0_bf16x2_kernel(ConvParams p) {
   {
   constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
 #pragma unroll
-  for (int k = 0; k < (NQ + 255) / 256; ++k) {
-    const int i = k * 256 + tid;
+  for (int k = 0; k < (NQ + NT - 1) / NT; ++k) {
+    const int i = k * NT + tid;
     if (i >= NQ) break;
     const int co = i / (C0::TD * C0::TH * QPR), rem = i % (C0::TD * C0::TH * QPR);
     const int row = rem / QPR, q = rem % QPR;
@@ -1582,6 +1586,10 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
 }  // namespace
 
 namespace {
+#ifndef V3D_C0_WAVES
+#define V3D_C0_WAVES 8
+#endif
+constexpr int kC0Waves = V3D_C0_WAVES;      // waves per workgroup of the fused path's conv0 (4 or 8)
 int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const float* wbf, const float* bias, const float* skip, float* out, int n,
                       int Di, int Hi, int Wi, hipStream_t s) {
   ConvParams p;
@@ -1594,22 +1602,22 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
   V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
   static bool attr_set = false;
   if (!attr_set) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, false>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, false>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, true>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, true, kC0Waves>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, true>,
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, true, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
     attr_set = true;
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-    if (split_in && split_out) conv0_bf16x2_kernel<true, true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else if (split_in) conv0_bf16x2_kernel<true, false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else if (split_out) conv0_bf16x2_kernel<false, true><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else conv0_bf16x2_kernel<false, false><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    if (split_in && split_out) conv0_bf16x2_kernel<true, true, kC0Waves><<<(unsigned)blocks, 64 * kC0Waves, C0::LDS_BYTES, s>>>(p);
+    else if (split_in) conv0_bf16x2_kernel<true, false, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else if (split_out) conv0_bf16x2_kernel<false, true, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+    else conv0_bf16x2_kernel<false, false, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH("conv0_bf16x2_kernel");
   return V3D_OK;
