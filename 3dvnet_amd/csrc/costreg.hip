@@ -1511,16 +1511,26 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
   const float* col = reg + (size_t)b * D * HW + pix;
   // one pass over D with a running maximum: num = sum vals_d e^{-x_d - m}, den = sum e^{-x_d - m}
   float m = -INFINITY, num = 0.f, den = 0.f;
-  for (int d = 0; d < D; ++d) {
-    const float x = -col[(size_t)d * HW];
+  auto step = [&](float xin, float val) __attribute__((always_inline)) {
+    const float x = -xin;
     if (x > m) {
       const float sc = expf(m - x);          // exp(-inf) = 0 on the first plane
       num *= sc; den *= sc; m = x;
     }
     const float ex = expf(x - m);
-    num += vals[d] * ex;
+    num += val * ex;
     den += ex;
+  };
+  // 8 planes are requested before the first is consumed (the running-maximum chain is sequential, the loads are not)
+  int d = 0;
+  for (; d + 8 <= D; d += 8) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(col + (size_t)(d + i) * HW);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) step(x[i], vals[d + i]);
   }
+  for (; d < D; ++d) step(col[(size_t)d * HW], vals[d]);
   const float e = num / den;
   depth[gid] = e;
 }
