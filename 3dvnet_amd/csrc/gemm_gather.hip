@@ -75,6 +75,64 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // depth gate is 1e-4).  The activation tile is then [row][32 k] bf16 (64 B rows, hi and lo
 // arrays) with the 16-B k-group slot XOR-swizzled by the row so that every ds_read_b128 lane group hits 16
 // distinct slots; weight fragments are split and packed on the host.
+// ---- epilogue shared by the GEMM kernels: bias -> GroupNorm(16) -> residual -> ReLU -> scatter-max -> store -----------
+template <int MBW, int NB>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NB][MBW], int m0, int wave, int kq, int jn) {
+  // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int m = m0 + nb * 16 + jn;
+#pragma unroll
+    for (int mw = 0; mw < MBW; ++mw) {
+      const int co0 = (wave * MBW + mw) * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[nb][mw][r] + ((p.bias && co0 + r < p.N) ? p.bias[co0 + r] : 0.f);
+      if (p.gn_w) {
+        // GroupNorm over the 16 channels of this block for row m: 4 registers x 4 lane quarters
+        float sum = v[0] + v[1] + v[2] + v[3];
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.f / 16.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq += (v[r] - mean) * (v[r] - mean);
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        const float rstd = 1.f / sqrtf(sq * (1.f / 16.f) + p.gn_eps);      // biased variance (torch GN)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co0 + r < p.N) v[r] = (v[r] - mean) * rstd * p.gn_w[co0 + r] + p.gn_b[co0 + r];
+      }
+      if (m < p.M && co0 < p.N) {
+        if (p.residual) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < p.N) v[r] += p.residual[(size_t)m * p.ld_res + co0 + r];
+        }
+        if (p.relu_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.pool) {
+          float* pr = p.pool + (size_t)p.pool_idx[m] * p.ld_pool + co0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < p.N) atomic_max_float(pr + r, v[r]);
+        }
+        if (p.out) {
+          float* o = p.out + (size_t)m * p.ld_out + co0;
+          if (co0 + 3 < p.N && (p.ld_out % 4 == 0)) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co0 + r < p.N) o[r] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
 #ifdef V3D_PHASE_TIMING
 // developer build only: per-phase cycle counters (wave 0 of every workgroup), see costreg.hip
 constexpr int kPhaseSlots = 1 << 16;
@@ -288,62 +346,122 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   }
 
   PHASE_MARK(5);
-  // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int m = m0 + nb * 16 + jn;
-#pragma unroll
-    for (int mw = 0; mw < MBW; ++mw) {
-      const int co0 = (wave * MBW + mw) * 16 + kq * 4;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[nb][mw][r] + ((p.bias && co0 + r < p.N) ? p.bias[co0 + r] : 0.f);
-      if (p.gn_w) {
-        // GroupNorm over the 16 channels of this block for row m: 4 registers x 4 lane quarters
-        float sum = v[0] + v[1] + v[2] + v[3];
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.f / 16.f);
-        float sq = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sq += (v[r] - mean) * (v[r] - mean);
-        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-        const float rstd = 1.f / sqrtf(sq * (1.f / 16.f) + p.gn_eps);      // biased variance (torch GN)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co0 + r < p.N) v[r] = (v[r] - mean) * rstd * p.gn_w[co0 + r] + p.gn_b[co0 + r];
-      }
-      if (m < p.M && co0 < p.N) {
-        if (p.residual) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co0 + r < p.N) v[r] += p.residual[(size_t)m * p.ld_res + co0 + r];
-        }
-        if (p.relu_out) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.pool) {
-          float* pr = p.pool + (size_t)p.pool_idx[m] * p.ld_pool + co0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co0 + r < p.N) atomic_max_float(pr + r, v[r]);
-        }
-        if (p.out) {
-          float* o = p.out + (size_t)m * p.ld_out + co0;
-          if (co0 + 3 < p.N && (p.ld_out % 4 == 0)) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (co0 + r < p.N) o[r] = v[r];
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<MBW, NB>(p, acc, m0, wave, kq, jn);
   PHASE_MARK(6);
   PHASE_FLUSH;
 }
+
+// ---- Conv1d(k = 3, pad 1) over groups of `group_len` consecutive rows (the hypothesis decoder, refinement.py:29-30) ----
+// The three taps read the same activation rows shifted by -1 / 0 / +1, so the tile (+ one halo row on either side) is
+// gathered, split and committed to LDS once per K chunk and used by all three taps; only the 16 KB weight slab changes
+// between taps.  A tap that would cross a group boundary reads a zero row instead (the conv's padding).  The generic
+// kernel stages every (tap, chunk) separately: three times the gather + split work, which is the larger half of its time.
+template <int MBW, int NB>
+__global__ __launch_bounds__(256) void conv1d_gemm_kernel(GemmParams p) {
+  constexpr int kTM = 16 * NB, kZRow = kTM + 2, kRT = kTM + 3;      // rows in LDS: halo + tile + halo + zero row
+  constexpr int NPASS = (kTM + 2 + 31) / 32;
+  constexpr int kWslab = 4 * MBW * 16 * kKC, MB = 4 * MBW;
+  __shared__ __attribute__((aligned(16))) u32x4 xq[2 * kRT * 4];     // [hi, lo][row][4 k groups of 8 bf16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  const int m0 = blockIdx.x * kTM;
+  const int nkc = p.KP / kKC;
+  const float* const src = p.seg[0].src;
+  const int ld = p.seg[0].ld;
+
+  f32x4 acc[NB][MBW];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // per column block: does tap 0 / tap 2 of this lane's output row stay inside its group?  (bit 2 nb / 2 nb + 1; a tap
+  // that leaves the group reads the zero row = the conv's padding)
+  unsigned tapmask = 0;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int hh = (m0 + nb * 16 + jn) % p.group_len;
+    tapmask |= (hh >= 1 ? 1u : 0u) << (2 * nb);
+    tapmask |= (hh + 1 < p.group_len ? 1u : 0u) << (2 * nb + 1);
+  }
+  if (tid < 8) xq[(tid >> 2) * kRT * 4 + kZRow * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
+
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  f32x4 xr[NPASS];
+  auto issue_x = [&](int kc) __attribute__((always_inline)) {
+    const int col = kc * kKC + sc4;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int lr = srow + 32 * i, m = m0 - 1 + lr;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (lr < kTM + 2 && m >= 0 && m < p.M && col < p.K) v = *reinterpret_cast<const f32x4*>(src + (size_t)m * ld + col);
+      xr[i] = v;
+    }
+  };
+  auto commit_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = srow + 32 * i;
+      if (row < kTM + 2) {
+        f32x4 v = xr[i];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+        const int slot = kg ^ (((row >> 3) & 1) * 3);
+        const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
+        const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
+        const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+        u32x2* xh2 = reinterpret_cast<u32x2*>(xq);
+        xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
+        xh2[((kRT + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+      }
+    }
+  };
+  // A fragments: every wave owns its MBW channel blocks, nothing is shared between waves, so the fragments go from the
+  // packed image (L2-resident) straight into registers, one tap ahead -- no LDS copy, no barrier between taps
+  u32x4 a_cur[2 * MBW], a_nxt[2 * MBW];
+  auto load_a = [&](u32x4 (&a)[2 * MBW], int t, int kc) __attribute__((always_inline)) {
+    const u32x4* w = reinterpret_cast<const u32x4*>(p.wp + (size_t)(t * nkc + kc) * kWslab) + lane;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) {
+      a[m] = w[(wave * MBW + m) * 64];
+      a[MBW + m] = w[(MB + wave * MBW + m) * 64];
+    }
+  };
+
+  issue_x(0);
+  load_a(a_cur, 0, 0);
+#pragma unroll 1
+  for (int kc = 0; kc < nkc; ++kc) {
+    __syncthreads();                 // the previous chunk's MFMAs are done with the tile
+    commit_x();
+    __syncthreads();
+    if (kc + 1 < nkc) issue_x(kc + 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < 2) load_a(a_nxt, t + 1, kc);
+      else if (kc + 1 < nkc) load_a(a_nxt, 0, kc + 1);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
+        const int R = inside ? nb * 16 + jn + t : kZRow;
+        const int slot = R * 4 + (kq ^ (((R >> 3) & 1) * 3));
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xq[slot]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xq[kRT * 4 + slot]);
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+          const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a_cur[m]), a_lo = __builtin_bit_cast(bf16x8, a_cur[MBW + m]);
+          acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[nb][m], 0, 0, 0);
+          acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[nb][m], 0, 0, 0);
+          acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2 * MBW; ++m) a_cur[m] = a_nxt[m];
+    }
+  }
+  gemm_epilogue<MBW, NB>(p, acc, m0, wave, kq, jn);
+}
+
 
 __global__ void fill_kernel(float* p, size_t n, float v) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -474,7 +592,18 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   const unsigned blocks = (unsigned)((M + tm - 1) / tm);
   static const bool fp32_path = getenv("V3D_GEMM_FP32") != nullptr;    // exact-fp32 MFMA instead of split bf16
   if (!fp32_path) p.wp = h->dev + h->bf_ofs;
-  {
+  // conv1d over row groups (3 taps of the same source): the tile is staged once per K chunk for all three taps
+  bool conv1d = !fp32_path && group_len > 0 && h->n_seg == 3 && h->K % 4 == 0;
+  for (int t = 0; conv1d && t < 3; ++t)
+    conv1d = p.seg[t].src == p.seg[0].src && p.seg[t].ld == p.seg[0].ld && !p.seg[t].idx && p.seg[t].ld % 4 == 0 &&
+             (reinterpret_cast<size_t>(p.seg[t].src) & 15) == 0;
+  if (conv1d) {
+    v3d::TimedScope ts("conv1d_gemm", s);
+    // one kernel family for every M (32-row tiles when M is small): chunked and unchunked calls of the decoder then
+    // accumulate in the same order and agree bit for bit
+    if (h->MBW == 2) { if (small) conv1d_gemm_kernel<2, 2><<<blocks, 256, 0, s>>>(p); else conv1d_gemm_kernel<2, 8><<<blocks, 256, 0, s>>>(p); }
+    else { if (small) conv1d_gemm_kernel<1, 2><<<blocks, 256, 0, s>>>(p); else conv1d_gemm_kernel<1, 8><<<blocks, 256, 0, s>>>(p); }
+  } else {
     v3d::TimedScope ts(h->n_seg == 27 ? "sparse_conv_gemm" : h->n_seg == 3 ? "conv1d_gemm" : "linear_gemm", s);
 #define V3D_GG(MBW_, NB_)                                                                  \
   do {                                                                                     \
