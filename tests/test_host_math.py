@@ -44,3 +44,56 @@ def test_bf16_split_carries_sixteen_mantissa_bits():
     rec = (hi.astype(np.float64) + lo.astype(np.float64))
     assert np.array_equal(rec.astype(np.float32).astype(np.float64), rec)
     assert np.all(np.abs(rec - x.astype(np.float64)) <= 2.0 ** -17 * np.abs(x.astype(np.float64)) + 1e-45)
+
+
+def _deconv_cells_1d(x, w, shifted):
+    """ConvTranspose1d(k=3, stride 2, pad 1, output_padding 1) written as the cell decomposition the HIP kernels use.
+    Aligned cells (deconvg_bf16x2_kernel): cell j = outputs (2j, 2j+1) from inputs (j, j+1):
+        out[2j] = in[j] w[1];  out[2j+1] = in[j] w[2] + in[j+1] w[0]
+    Shifted cells (conv9_prob_kernel, whose halo'd tile starts at an odd output): cell j = outputs (2j+1, 2j+2):
+        out[2j+1] = in[j] w[2] + in[j+1] w[0];  out[2j+2] = in[j+1] w[1]"""
+    n = x.shape[0]
+    out = np.zeros(2 * n, dtype=np.float64)
+    xin = lambda i: x[i] if 0 <= i < n else 0.0
+    if not shifted:
+        for j in range(n):
+            out[2 * j] = xin(j) * w[1]
+            out[2 * j + 1] = xin(j) * w[2] + xin(j + 1) * w[0]
+    else:
+        for j in range(-1, n):
+            if 0 <= 2 * j + 1 < 2 * n:
+                out[2 * j + 1] = xin(j) * w[2] + xin(j + 1) * w[0]
+            if 0 <= 2 * j + 2 < 2 * n:
+                out[2 * j + 2] = xin(j + 1) * w[1]
+    return out
+
+
+def test_transposed_conv_cell_decomposition_matches_torch():
+    """The tap tables packed by v3d_costreg_pack for conv7 / conv8 / conv9 (kernel tap of (output parity, input offset))
+    restate torch's ConvTranspose(k 3, s 2, p 1, output_padding 1); the 3D layers are the tensor product of this 1D map."""
+    import torch
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 8):
+        x = rng.standard_normal(n)
+        w = rng.standard_normal(3)
+        ref = torch.nn.functional.conv_transpose1d(torch.tensor(x).view(1, 1, n), torch.tensor(w).view(1, 1, 3), stride=2,
+                                                   padding=1, output_padding=1).view(-1).numpy()
+        for shifted in (False, True):
+            np.testing.assert_allclose(_deconv_cells_1d(x, w, shifted), ref, rtol=0, atol=1e-12)
+
+
+def test_stride_two_conv_as_four_tap_k_steps():
+    """convg_bf16x2_kernel evaluates a k=3 conv with K steps of 4 x taps x 8 channels, the 4th tap carrying zero weights,
+    reading input x = S * out_x + tap - 1 (S = 1 or 2): check the index map against torch conv1d."""
+    import torch
+    rng = np.random.default_rng(4)
+    for stride in (1, 2):
+        n = 11
+        x = rng.standard_normal(n)
+        w = rng.standard_normal(3)
+        ref = torch.nn.functional.conv1d(torch.tensor(x).view(1, 1, n), torch.tensor(w).view(1, 1, 3), stride=stride,
+                                         padding=1).view(-1).numpy()
+        w4 = np.concatenate([w, [0.0]])
+        xin = lambda i: x[i] if 0 <= i < n else 0.0
+        out = np.array([sum(w4[t] * xin(stride * o + t - 1) for t in range(4)) for o in range(len(ref))])
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
