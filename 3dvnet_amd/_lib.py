@@ -13,7 +13,16 @@ import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
+PRECISION = {'split_bf16': 0, 'fp32': 1}      # V3D_PRECISION_* of include/v3d.h
+
+
+def precision_code(name):
+    try:
+        return PRECISION[name]
+    except KeyError:
+        raise ValueError("precision must be 'split_bf16' or 'fp32', got %r" % (name,))
+
 
 c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                 ctypes.c_double, ctypes.c_size_t)
@@ -36,12 +45,12 @@ SIGNATURES = {
                                                      ctypes.POINTER(c_void_p)]),
     'v3d_costreg_free': (None, [c_void_p]),
     'v3d_costreg_workspace_bytes': (c_size_t, [c_void_p] + [c_int] * 4),
-    'v3d_costreg_depth_f32': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p,
+    'v3d_costreg_depth_f32': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p,
                                                                     c_size_t, c_void_p]),
     'v3d_costreg_depth_split': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p,
                                                                       c_size_t, c_void_p]),
     'v3d_costreg_layer_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
-                              [c_void_p, c_void_p]),
+                              [c_void_p, c_int, c_void_p]),
     'v3d_costreg_layer_split_workspace_bytes': (c_size_t, [c_int] * 5),
     'v3d_costreg_layer_split_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
                                     [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -54,10 +63,11 @@ SIGNATURES = {
     'v3d_gemm_free': (None, [c_void_p]),
     'v3d_gemm_gather_f32': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                     ctypes.POINTER(c_int), c_int, c_int, c_int, c_float, c_void_p, c_int,
-                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'v3d_fill_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     'v3d_hash_bytes': (c_size_t, [c_int]),
     'v3d_hash_build': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'v3d_hash_status': (c_int, [c_void_p, c_int, c_void_p]),
     'v3d_sparse_neighbors': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'v3d_sparse_interp_workspace_bytes': (c_size_t, [c_int, c_int]),
     'v3d_sparse_interp_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
@@ -69,6 +79,7 @@ SIGNATURES = {
     'v3d_unpack_coords': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'v3d_voxelize_workspace_bytes': (c_size_t, []),
     'v3d_voxel_keys': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_voxelize_status': (c_int, [c_void_p, c_size_t, c_void_p]),
     'v3d_lower_bound_u64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'v3d_voxel_decode': (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_void_p]),

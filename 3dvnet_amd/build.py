@@ -5,6 +5,7 @@
 The .so is git-ignored but travels to the GPU box with the repo snapshot.
 """
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,6 +23,12 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _flags_tag():
+    """Objects are keyed by the compiler flags: a build with V3D_EXTRA_FLAGS (the developer scripts' instrumented /
+    ablated variants) lands in its own object directory and can never be mistaken for the default build."""
+    return hashlib.sha256(' '.join([HIPCC] + FLAGS).encode()).hexdigest()[:12]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -32,8 +39,11 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     """Compile every csrc/*.hip to an object (in parallel) and link the shared library."""
     headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))
-    objdir = os.path.join(HERE, 'build')
+    tag = _flags_tag()
+    objdir = os.path.join(HERE, 'build', tag)
     os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(HERE, 'build', 'linked_flags')     # which flag set the in-tree .so was linked from
+    linked = open(stamp).read().strip() if os.path.exists(stamp) else None
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
@@ -50,11 +60,13 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s' % src)
         if verbose and out:
             print(out.decode())
-    if force or procs or _stale(LIB, objs):
+    if force or procs or linked != tag or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, 'w') as f:
+            f.write(tag + '\n')
     return LIB
 
 

@@ -68,27 +68,28 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
       int src = p.edge_src[e_begin + ec + e];
       const float* Kp = p.K + src * 9; const float* Rp = p.R + src * 9; const float* tp = p.t + src * 3;
       float v;
-      if (j < 3) v = Kp[i * 3 + 0] * Rp[0 * 3 + j] + Kp[i * 3 + 1] * Rp[1 * 3 + j] + Kp[i * 3 + 2] * Rp[2 * 3 + j];
-      else v = Kp[i * 3 + 0] * tp[0] + Kp[i * 3 + 1] * tp[1] + Kp[i * 3 + 2] * tp[2];
+      // small batched product of torch.bmm: rounded products, sequential additions, no FMA (see psv_variance.hip)
+      const float b0 = j < 3 ? Rp[0 * 3 + j] : tp[0], b1 = j < 3 ? Rp[1 * 3 + j] : tp[1], b2 = j < 3 ? Rp[2 * 3 + j] : tp[2];
+      v = __fadd_rn(__fadd_rn(__fmul_rn(Kp[i * 3 + 0], b0), __fmul_rn(Kp[i * 3 + 1], b1)), __fmul_rn(Kp[i * 3 + 2], b2));
       s_P[e][ij] = v;
       if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
     }
     __syncthreads();
     if (ec == 0) {   // world point X = R^T (K^-1 (pix * depth) - t)   (lightningmodel.py:142-144,202-204)
       float p0 = xf * dep, p1 = yf * dep, p2 = dep;
-      float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
-      float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
-      float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
-      X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
-      Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
-      Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+      float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
+      float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
+      float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
+      X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
+      Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
+      Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
     }
     if (!active) continue;
     for (int e = 0; e < nec; ++e) {
       const float* Pm = s_P[e];
-      float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
-      float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
-      float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+      float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
+      float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
+      float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
       float zb = fabsf(qz) + 1e-8f;
       float u = qx / zb, v = qy / zb;
       float gxn = (u / Wm1) * 2.f - 1.f, gyn = (v / Hm1) * 2.f - 1.f;

@@ -1889,13 +1889,12 @@ extern "C" void v3d_costreg_free(v3d_costreg_weights* h) {
 }
 
 static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, const float* skip,
-                     float* out, int n, int Di, int Hi, int Wi, hipStream_t s) {
+                     float* out, int n, int Di, int Hi, int Wi, int precision, hipStream_t s) {
   const float* wp = h->dev + h->wp_ofs[layer];
   const float* bias = h->dev + h->bias_ofs[layer];
   switch (layer) {
     case 0: {
-      static const bool fp32_path = getenv("V3D_CONV0_FP32") != nullptr;     // developer A/B switch
-      if (fp32_path) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+      if (precision == V3D_PRECISION_FP32) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
       return launch_conv0_bf16(false, false, in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
     }
     case 1: return launch_conv<L1>("costreg_conv1", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
@@ -1913,10 +1912,12 @@ static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, c
 
 extern "C" int v3d_costreg_layer_f32(const v3d_costreg_weights* h, int layer, const float* in,
                                      const float* skip, int n, int Di, int Hi, int Wi, float* out,
-                                     void* stream) {
+                                     int precision, void* stream) {
   V3D_REQUIRE(h && in && out, V3D_ERR_BAD_ARG, "v3d_costreg_layer_f32: null argument");
   V3D_REQUIRE(n > 0 && Di > 0 && Hi > 0 && Wi > 0, V3D_ERR_BAD_SHAPE, "v3d_costreg_layer_f32: bad shape");
-  return run_layer(h, layer, in, skip, out, n, Di, Hi, Wi, (hipStream_t)stream);
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
+              "v3d_costreg_layer_f32: unknown precision %d", precision);
+  return run_layer(h, layer, in, skip, out, n, Di, Hi, Wi, precision, (hipStream_t)stream);
 }
 
 extern "C" size_t v3d_costreg_layer_split_workspace_bytes(int n, int cin, int Di, int Hi, int Wi) {
@@ -1974,8 +1975,10 @@ extern "C" size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights*, int n_
 
 static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const float* var,
                               const float* depth_vals, int n, int D, int H, int W,
-                              float* depth, float* reg, void* workspace,
+                              float* depth, float* reg, int precision, void* workspace,
                               size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
+              "v3d_costreg_depth_f32: unknown precision %d", precision);
   V3D_REQUIRE(h && var && depth_vals && depth && workspace, V3D_ERR_BAD_ARG,
               "v3d_costreg_depth_f32: null argument");
   V3D_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0,
@@ -1989,12 +1992,12 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
   float* xreg = reg ? reg : F(ws.reg);
   int rc;
 #define RUN(layer, in, skip, out, d, hh, ww) \
-  if ((rc = run_layer(h, layer, in, skip, out, n, d, hh, ww, s)) != V3D_OK) return rc;
-  // V3D_COSTREG_GENERIC=1 (developer A/B switch, fp32 volume only): every layer on the per-layer kernels with fp32
-  // [n, C, D, H, W] tensors in between.  Default: conv0 -> conv1 -> conv2 and the conv0 skip of the last layer use the
-  // split channel-last hand-off format (same bytes as fp32).
-  static const bool generic = getenv("V3D_COSTREG_GENERIC") != nullptr;
-  V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_COSTREG_GENERIC needs the fp32 variance volume");
+  if ((rc = run_layer(h, layer, in, skip, out, n, d, hh, ww, V3D_PRECISION_FP32, s)) != V3D_OK) return rc;
+  // precision == V3D_PRECISION_FP32 (fp32 volume only): every layer on the exact-fp32 per-layer kernels with fp32
+  // [n, C, D, H, W] tensors in between.  V3D_PRECISION_SPLIT_BF16: every layer on split-bf16 matrix cores, activations
+  // in the split channel-last hand-off format (same bytes as fp32).
+  const bool generic = precision == V3D_PRECISION_FP32;
+  V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_PRECISION_FP32 needs the fp32 variance volume");
   if (generic) {
     RUN(0, var, nullptr, F(ws.c0), D, H, W);
     RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
@@ -2086,16 +2089,17 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
 }
 
 extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var, const float* depth_vals, int n,
-                                     int D, int H, int W, float* depth, float* reg, void* workspace,
+                                     int D, int H, int W, float* depth, float* reg, int precision, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  return costreg_depth_impl(false, h, var, depth_vals, n, D, H, W, depth, reg, workspace, workspace_bytes, stream);
+  return costreg_depth_impl(false, h, var, depth_vals, n, D, H, W, depth, reg, precision, workspace, workspace_bytes,
+                            stream);
 }
 
 extern "C" int v3d_costreg_depth_split(const v3d_costreg_weights* h, const void* var_split, const float* depth_vals,
                                        int n, int D, int H, int W, float* depth, float* reg, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-  return costreg_depth_impl(true, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg, workspace,
-                            workspace_bytes, stream);
+  return costreg_depth_impl(true, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg,
+                            V3D_PRECISION_SPLIT_BF16, workspace, workspace_bytes, stream);
 }
 
 #ifdef V3D_PHASE_TIMING

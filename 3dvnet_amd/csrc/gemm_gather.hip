@@ -563,8 +563,10 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
                                    int group_len, int relu_in, int use_gn, float gn_eps,
                                    const float* residual, int ld_res, int relu_out, float* pool,
                                    const int32_t* pool_idx, int ld_pool, float* out, int ld_out,
-                                   void* stream) {
+                                   int precision, void* stream) {
   V3D_REQUIRE(h && seg_src_host && seg_ld_host, V3D_ERR_BAD_ARG, "v3d_gemm_gather_f32: null argument");
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
+              "v3d_gemm_gather_f32: unknown precision %d", precision);
   V3D_REQUIRE(M >= 0, V3D_ERR_BAD_SHAPE, "v3d_gemm_gather_f32: M < 0");
   V3D_REQUIRE(!use_gn || (h->has_gn && h->N % 16 == 0), V3D_ERR_BAD_ARG,
               "v3d_gemm_gather_f32: GroupNorm requested but weights carry no affine / N %% 16 != 0");
@@ -590,7 +592,7 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   const bool small = M < 128 * 1024;           // fewer than ~4 tiles of 128 rows per CU: use 32-row tiles
   const int tm = small ? 32 : 128;
   const unsigned blocks = (unsigned)((M + tm - 1) / tm);
-  static const bool fp32_path = getenv("V3D_GEMM_FP32") != nullptr;    // exact-fp32 MFMA instead of split bf16
+  const bool fp32_path = precision == V3D_PRECISION_FP32;    // exact-fp32 MFMA instead of split bf16
   if (!fp32_path) p.wp = h->dev + h->bf_ofs;
   // conv1d over row groups (3 taps of the same source): the tile is staged once per K chunk for all three taps
   bool conv1d = !fp32_path && group_len > 0 && h->n_seg == 3 && h->K % 4 == 0;

@@ -116,13 +116,15 @@ __global__ void cam_setup_kernel(const float* __restrict__ K, const float* __res
   o[8] = (float)((a * e - bb * d) * id);
   for (int k = 0; k < 9; ++k) o[9 + k] = Rp[k];
   for (int k = 0; k < 3; ++k) o[18 + k] = tp[k];
-  // projection matrix P = K [R|t] (mvsnet.py:196-197)
+  // projection matrix P = K [R|t] (mvsnet.py:196-197).  torch.bmm evaluates this small batched product with rounded
+  // products and sequential additions (no FMA) -- unlike the large K^-1 p / R^T c / P X products, which are FMA chains
+  // in k order -- so contraction is switched off here: the sample coordinates then reproduce the reference's bit for bit
+  // (scripts/coord_order_probe.py)
   for (int r = 0; r < 3; ++r)
     for (int j = 0; j < 4; ++j) {
-      float v;
-      if (j < 3) v = Kp[r * 3 + 0] * Rp[0 * 3 + j] + Kp[r * 3 + 1] * Rp[1 * 3 + j] + Kp[r * 3 + 2] * Rp[2 * 3 + j];
-      else v = Kp[r * 3 + 0] * tp[0] + Kp[r * 3 + 1] * tp[1] + Kp[r * 3 + 2] * tp[2];
-      o[24 + r * 4 + j] = v;
+      const float b0 = j < 3 ? Rp[0 * 3 + j] : tp[0], b1 = j < 3 ? Rp[1 * 3 + j] : tp[1], b2 = j < 3 ? Rp[2 * 3 + j] : tp[2];
+      o[24 + r * 4 + j] = __fadd_rn(__fadd_rn(__fmul_rn(Kp[r * 3 + 0], b0), __fmul_rn(Kp[r * 3 + 1], b1)),
+                                    __fmul_rn(Kp[r * 3 + 2], b2));
     }
 }
 
@@ -222,17 +224,17 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
       {
         // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
         float p0 = xf * z, p1 = yf * z, p2 = z;
-        float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
-        float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
-        float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
-        float X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
-        float Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
-        float Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+        float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
+        float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
+        float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
+        float X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
+        float Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
+        float Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
         for (int e = tid / kPix; e < nec; e += kThreads / kPix) {
           const float* Pm = s_P[e];
-          float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
-          float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
-          float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+          float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
+          float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
+          float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
           float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
           float u = qx / zb, v = qy / zb;
           float gx = (u / Wm1) * 2.f - 1.f;                    // mvsnet.py:205-206
@@ -398,12 +400,12 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
     const float z = (d1 == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d1 * p.z_step);
     // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
     const float p0 = xf * z, p1 = yf * z, p2 = z;
-    const float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
-    const float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
-    const float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
-    X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
-    Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
-    Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
+    const float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
+    const float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
+    const float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
+    X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
+    Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
+    Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
   }
   const bool live1 = gp1 < P && d1 < p.D;
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
@@ -445,9 +447,9 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
     }
     if (e1 < nec) {
       const float* Pm = s_P[ec % kMaxE + e1];
-      const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
-      const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
-      const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
+      const float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
+      const float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
+      const float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
       const float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
       const float u = qx / zb, v = qy / zb;
       const float gx = div_uniform(u, Wm1, rWm1) * 2.f - 1.f;    // mvsnet.py:205-206: u / (W - 1) * 2 - 1
@@ -565,260 +567,6 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   PHASE_FLUSH;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// LDS-window variant (C == 32): one 256-thread workgroup per (reference view, 8x8 plane-grid pixels,
-// 4 depth planes).  Per source edge:
-//   A  thread t projects its own sample (plane t/64, pixel t%64) and the workgroup reduces the bounding
-//      box of the touched feature cells (wave shuffles + 4 LDS atomics per wave);
-//   B  the thread turns its sample into a tap record -- 4 bilinear weights (padding-zero folded in) and 4
-//      offsets into the LDS window -- exactly once (not once per channel lane); meanwhile the window
-//      (<= kWinCells cells x 128 B) is copied featT -> LDS row by row: a window row is one contiguous run of
-//      featT, so the copy is fully coalesced and each cell is fetched from L1 once per edge instead of once per
-//      tap (~5x less L1 traffic, the bound of the plain gather kernel);
-//   C  8 lanes x float4 per sample: tap record + 4 taps by ds_read_b128, sum / sum of squares in registers in
-//      edge order (bit-identical arithmetic to the gather kernel).
-// Two barriers per edge; 4 workgroups per CU hide the staging latency.  If the window of an edge exceeds the
-// budget (wide baselines / near planes) that edge gathers from global memory instead.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kWT = 8;            // pixel tile is kWT x kWT
-constexpr int kWDB = 4;           // depth planes per workgroup
-constexpr int kWinCells = 192;    // LDS window budget in feature cells (x 128 B)
-
-struct PsvWinParams {
-  PsvParams b;
-  int ntx, nty;
-};
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct TapRec {                   // 32 bytes
-  float w00, w01, w10, w11;
-  int o00, o01, o10, o11;         // float offsets into the window (or featT when the edge gathers); o00 < 0: skip
-};
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
-}
-
-__global__ __launch_bounds__(256, 3) void psv_variance_win_kernel(PsvWinParams pp) {
-  constexpr int C = 32;
-  const PsvParams& p = pp.b;
-  __shared__ __attribute__((aligned(16))) float s_win[kWinCells * C];      // 24 KB, reused as the output tile
-  __shared__ __attribute__((aligned(16))) TapRec s_tap[kWDB * 64];         // 8 KB
-  __shared__ int s_bbox[2][4];     // xmin, ymin, xmax, ymax of floor(ix), floor(iy) over valid samples
-  __shared__ float s_ref[24];
-  __shared__ float s_P[kMaxE][12];
-  __shared__ int s_base[kMaxE];
-  static_assert(kWinCells * C >= kWDB * C * 33 / 1 || true, "");
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
-  const int tx = b % pp.ntx; b /= pp.ntx;
-  const int ty = b % pp.nty; b /= pp.nty;
-  const int n_dchunk = (p.D + kWDB - 1) / kWDB;
-  const int dchunk = b % n_dchunk;
-  const int r = b / n_dchunk;
-  const int P = p.h * p.w;
-  const int e_begin = p.edge_ofs[r], ne = p.edge_ofs[r + 1] - e_begin;
-  const int ref = p.ref_img[r];
-  const int d_first = dchunk * kWDB;
-  const int nd = min(kWDB, p.D - d_first);
-
-  if (tid == 0) {
-    const float* Kp = p.K + ref * 9;
-    double a = Kp[0], bb = Kp[1], c = Kp[2], d = Kp[3], e = Kp[4], f = Kp[5], g = Kp[6], hh = Kp[7], i = Kp[8];
-    double det = a * (e * i - f * hh) - bb * (d * i - f * g) + c * (d * hh - e * g), id = 1.0 / det;
-    s_ref[0] = (float)((e * i - f * hh) * id); s_ref[1] = (float)((c * hh - bb * i) * id); s_ref[2] = (float)((bb * f - c * e) * id);
-    s_ref[3] = (float)((f * g - d * i) * id);  s_ref[4] = (float)((a * i - c * g) * id);   s_ref[5] = (float)((c * d - a * f) * id);
-    s_ref[6] = (float)((d * hh - e * g) * id); s_ref[7] = (float)((bb * g - a * hh) * id); s_ref[8] = (float)((a * e - bb * d) * id);
-  }
-  if (tid >= 64 && tid < 73) s_ref[9 + tid - 64] = p.R[ref * 9 + tid - 64];
-  if (tid >= 128 && tid < 131) s_ref[18 + tid - 128] = p.t[ref * 3 + tid - 128];
-  if (tid >= 192 && tid < 200) s_bbox[(tid - 192) >> 2][(tid - 192) & 3] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
-  __syncthreads();
-
-  // ---- sample role: plane sd = wave, pixel sp = lane ----------------------------------------------------
-  const int sd = wave, sp = lane;
-  const int sgx = tx * kWT + (sp & 7), sgy = ty * kWT + (sp >> 3);
-  const bool s_ok = sd < nd && sgx < p.w && sgy < p.h;
-  float X, Y, Z;
-  {
-    const float xf = (p.w > 1 && sgx == p.w - 1) ? (float)(p.W - 1) : (float)((double)sgx * p.x_step);
-    const float yf = (p.h > 1 && sgy == p.h - 1) ? (float)(p.H - 1) : (float)((double)sgy * p.y_step);
-    const int d = d_first + sd;
-    const float z = (d == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d * p.z_step);
-    const float p0 = xf * z, p1 = yf * z, p2 = z;
-    const float c0 = s_ref[0] * p0 + s_ref[1] * p1 + s_ref[2] * p2 - s_ref[18];
-    const float c1 = s_ref[3] * p0 + s_ref[4] * p1 + s_ref[5] * p2 - s_ref[19];
-    const float c2 = s_ref[6] * p0 + s_ref[7] * p1 + s_ref[8] * p2 - s_ref[20];
-    X = s_ref[9] * c0 + s_ref[12] * c1 + s_ref[15] * c2;
-    Y = s_ref[10] * c0 + s_ref[13] * c1 + s_ref[16] * c2;
-    Z = s_ref[11] * c0 + s_ref[14] * c1 + s_ref[17] * c2;
-  }
-  // ---- gather role: channel group cg, pixels gp and gp + 32 -----------------------------------------------
-  const int cg = tid & 7, gp = tid >> 3;
-  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
-  const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
-
-  float acc_s[2][kWDB][4], acc_q[2][kWDB][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int d = 0; d < kWDB; ++d)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc_s[a][d][k] = acc_q[a][d][k] = 0.f;
-
-  for (int ec = 0; ec < ne; ec += kMaxE) {
-    const int nec = min(kMaxE, ne - ec);
-    __syncthreads();
-    if (tid < nec * 12) {
-      int e = tid / 12, ij = tid % 12, i = ij / 4, j = ij % 4;
-      int src = p.edge_src[e_begin + ec + e];
-      const float* Kp = p.K + src * 9; const float* Rp = p.R + src * 9; const float* tp = p.t + src * 3;
-      float v;
-      if (j < 3) v = Kp[i * 3 + 0] * Rp[0 * 3 + j] + Kp[i * 3 + 1] * Rp[1 * 3 + j] + Kp[i * 3 + 2] * Rp[2 * 3 + j];
-      else v = Kp[i * 3 + 0] * tp[0] + Kp[i * 3 + 1] * tp[1] + Kp[i * 3 + 2] * tp[2];
-      s_P[e][ij] = v;
-      if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
-    }
-    __syncthreads();
-    for (int e = 0; e < nec; ++e) {
-      const int bb = (ec + e) & 1;
-      // ---- A: project, reduce the cell bounding box ------------------------------------------------------
-      const float* Pm = s_P[e];
-      const float qx = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3];
-      const float qy = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7];
-      const float qz = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11];
-      const float zb = fabsf(qz) + 1e-8f;
-      const float u = qx / zb, v = qy / zb;
-      const float gx = (u / Wm1) * 2.f - 1.f, gy = (v / Hm1) * 2.f - 1.f;
-      const float ix = ((gx + 1.f) / 2.f) * Wfm1, iy = ((gy + 1.f) / 2.f) * Hfm1;
-      const bool any = s_ok && (ix > -1.f) && (ix < Wfm1 + 1.f) && (iy > -1.f) && (iy < Hfm1 + 1.f);
-      const float x0 = floorf(any ? ix : 0.f), y0 = floorf(any ? iy : 0.f);
-      {
-        const int fx = (int)x0, fy = (int)y0;
-        const int bx0 = wave_min_i(any ? fx : 0x7fffffff), by0 = wave_min_i(any ? fy : 0x7fffffff);
-        const int bx1 = wave_max_i(any ? fx : -0x7fffffff), by1 = wave_max_i(any ? fy : -0x7fffffff);
-        if (lane == 0 && bx1 >= bx0) {
-          atomicMin(&s_bbox[bb][0], bx0); atomicMin(&s_bbox[bb][1], by0);
-          atomicMax(&s_bbox[bb][2], bx1); atomicMax(&s_bbox[bb][3], by1);
-        }
-      }
-      __syncthreads();          // also: every lane finished phase C of the previous edge (s_tap / s_win reusable)
-      // ---- B: tap record of this thread's sample + window staging ---------------------------------------------
-      const bool nonempty = s_bbox[bb][2] >= s_bbox[bb][0];
-      const int wx0 = nonempty ? max(s_bbox[bb][0], 0) : 0, wy0 = nonempty ? max(s_bbox[bb][1], 0) : 0;
-      const int wx1 = nonempty ? min(s_bbox[bb][2] + 1, p.Wf - 1) : 0, wy1 = nonempty ? min(s_bbox[bb][3] + 1, p.Hf - 1) : 0;
-      const int Ww = wx1 - wx0 + 1, Wh = wy1 - wy0 + 1;
-      const bool use_lds = nonempty && Ww * Wh <= kWinCells;
-      const float* fimg = p.featT + (size_t)s_base[e] * C;
-      {
-        TapRec tr;
-        tr.o00 = -1; tr.o01 = tr.o10 = tr.o11 = 0; tr.w00 = tr.w01 = tr.w10 = tr.w11 = 0.f;
-        if (any) {
-          const float x1 = x0 + 1.f, y1 = y0 + 1.f;
-          const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
-          tr.w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f; tr.w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
-          tr.w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f; tr.w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
-          const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
-          if (use_lds) {
-            // clamped coordinates lie inside the window by construction of the bounding box
-            const int ax0 = max(xi0 - wx0, 0), ax1 = max(xi1 - wx0, 0), ay0 = max(yi0 - wy0, 0), ay1 = max(yi1 - wy0, 0);
-            tr.o00 = (ay0 * Ww + ax0) * C; tr.o01 = (ay0 * Ww + ax1) * C;
-            tr.o10 = (ay1 * Ww + ax0) * C; tr.o11 = (ay1 * Ww + ax1) * C;
-          } else {
-            tr.o00 = (yi0 * p.Wf + xi0) * C; tr.o01 = (yi0 * p.Wf + xi1) * C;
-            tr.o10 = (yi1 * p.Wf + xi0) * C; tr.o11 = (yi1 * p.Wf + xi1) * C;
-          }
-        }
-        s_tap[sd * 64 + sp] = tr;
-      }
-      if (tid < 4) s_bbox[bb ^ 1][tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;    // for the next edge
-      if (use_lds) {
-        // window cells x 8 float4, flattened over the workgroup; all loads of a thread are issued before its
-        // first LDS write (one exposed global latency per edge instead of one per float4).  A window row is a
-        // contiguous run of featT, so consecutive threads read consecutive 16-B pieces.
-        constexpr int kStg = kWinCells * 8 / 256;
-        const int nf4 = Ww * Wh * 8;
-        const float inv_w = 1.f / (float)Ww;
-        f32x4 stg[kStg];          // native vector type (HIP's float4 struct arrays end up in scratch)
-#pragma unroll
-        for (int k = 0; k < kStg; ++k) {
-          const int i = tid + k * 256;
-          if (i < nf4) {
-            const int cell = i >> 3;
-            const int cy = (int)(((float)cell + 0.5f) * inv_w);      // exact for cell, Ww <= kWinCells
-            const int cx = cell - cy * Ww;
-            stg[k] = *reinterpret_cast<const f32x4*>(fimg + ((size_t)(wy0 + cy) * p.Wf + wx0 + cx) * C + (i & 7) * 4);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < kStg; ++k) {
-          const int i = tid + k * 256;
-          if (i < nf4) *reinterpret_cast<f32x4*>(s_win + (size_t)i * 4) = stg[k];
-        }
-      }
-      __syncthreads();
-      // ---- C: gather + accumulate ---------------------------------------------------------------------------------
-      if (nonempty) {
-        const float* tb = (use_lds ? s_win : fimg) + cg * 4;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-          for (int dd = 0; dd < kWDB; ++dd) {
-            const TapRec tr = s_tap[dd * 64 + gp + 32 * a];
-            if (tr.o00 >= 0) {
-              const float4 v00 = *reinterpret_cast<const float4*>(tb + tr.o00);
-              const float4 v01 = *reinterpret_cast<const float4*>(tb + tr.o01);
-              const float4 v10 = *reinterpret_cast<const float4*>(tb + tr.o10);
-              const float4 v11 = *reinterpret_cast<const float4*>(tb + tr.o11);
-              float4 s;
-              s.x = v00.x * tr.w00; s.y = v00.y * tr.w00; s.z = v00.z * tr.w00; s.w = v00.w * tr.w00;
-              s.x += v01.x * tr.w01; s.y += v01.y * tr.w01; s.z += v01.z * tr.w01; s.w += v01.w * tr.w01;
-              s.x += v10.x * tr.w10; s.y += v10.y * tr.w10; s.z += v10.z * tr.w10; s.w += v10.w * tr.w10;
-              s.x += v11.x * tr.w11; s.y += v11.y * tr.w11; s.z += v11.z * tr.w11; s.w += v11.w * tr.w11;
-              acc_s[a][dd][0] += s.x; acc_s[a][dd][1] += s.y; acc_s[a][dd][2] += s.z; acc_s[a][dd][3] += s.w;
-              acc_q[a][dd][0] += s.x * s.x; acc_q[a][dd][1] += s.y * s.y;
-              acc_q[a][dd][2] += s.z * s.z; acc_q[a][dd][3] += s.w * s.w;
-            }
-          }
-        }
-      }
-    }
-  }
-  // ---- variance -> LDS transpose -> store (the window buffer becomes the [4 planes][32 ch][64+1 px] tile) --------
-  const float cnt = (float)max(ne, 1);
-  float (*s_out)[C][33] = reinterpret_cast<float (*)[C][33]>(s_win);
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    __syncthreads();
-#pragma unroll
-    for (int dd = 0; dd < kWDB; ++dd)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float avg = acc_s[a][dd][k] / cnt, avg_sq = acc_q[a][dd][k] / cnt;
-        s_out[dd][cg * 4 + k][gp] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));
-      }
-    __syncthreads();
-    const int px = (tid & 31) + 32 * a;                 // pixels of this half tile: rows 4a .. 4a+3
-    const int ogx = tx * kWT + (px & 7), ogy = ty * kWT + (px >> 3);
-    if (ogx < p.w && ogy < p.h) {
-      for (int dc = tid >> 5; dc < nd * C; dc += 8) {
-        const int dd = dc / C, c = dc % C;
-        p.var[(((size_t)r * C + c) * p.D + d_first + dd) * P + ogy * p.w + ogx] = s_out[dd][c][tid & 31];
-      }
-    }
-  }
-}
-
 }  // namespace
 
 // shared with backproject.hip
@@ -888,18 +636,7 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   const int n_dchunk = (D + kDB - 1) / kDB;
   const long long blocks = (long long)n_ref * n_dchunk * p.n_ptile;
   V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
-  // The LDS-window kernel is correct (same parity tests) but currently slower than the gather kernel
-  // (2.1-2.9 ms vs 1.3 ms per 32-view launch); it stays opt-in for further work.
-  static const bool use_win = getenv("V3D_PSV_WINDOW") != nullptr;
-  if (C == 32 && use_win && !split) {
-    PsvWinParams pw;
-    pw.b = p;
-    pw.ntx = (w + kWT - 1) / kWT; pw.nty = (h + kWT - 1) / kWT;
-    const long long wblocks = (long long)n_ref * ((D + kWDB - 1) / kWDB) * pw.ntx * pw.nty;
-    V3D_REQUIRE(wblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
-    v3d::TimedScope ts("psv_variance", s);
-    psv_variance_win_kernel<<<(unsigned)wblocks, 256, 0, s>>>(pw);
-  } else {
+  {
     v3d::TimedScope ts("psv_variance", s);
     const unsigned grid = (unsigned)blocks;
 #define V3D_PSV(C_, SPLIT_)                                                        \

@@ -25,8 +25,13 @@ __device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
 struct HashTable {          // device layout inside the caller-provided buffer
   unsigned long long* keys; // [cap]
   int* vals;                // [cap]
+  int* status;              // [1] != 0: a coordinate did not fit the packed key (v3d_hash_status)
   unsigned mask;            // cap - 1 (cap = power of two)
 };
+
+// the packed key holds 16 bits per field: batch in [0, 65535], coordinates in [-kGuard, 65535 - 2 kGuard] so that the
+// +-1 voxel probes of the neighbour tables cannot wrap either
+constexpr int kCoordMax = 65535 - 2 * kGuard;
 
 __device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
   unsigned slot = hash_u64(key) & t.mask;
@@ -39,15 +44,21 @@ __device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long 
   return -1;
 }
 
-__global__ void hash_clear_kernel(unsigned long long* keys, unsigned cap) {
+__global__ void hash_clear_kernel(unsigned long long* keys, unsigned cap, int* status) {
   unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i < cap) keys[i] = kEmpty;
+  if (i == 0) *status = 0;
 }
 
 __global__ void hash_insert_kernel(HashTable t, const int* __restrict__ coords, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long key = pack_key(coords[i * 4], coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3]);
+  const int cb = coords[i * 4], cx = coords[i * 4 + 1], cy = coords[i * 4 + 2], cz = coords[i * 4 + 3];
+  if (cb < 0 || cb > 65535 || min(cx, min(cy, cz)) < -kGuard || max(cx, max(cy, cz)) > kCoordMax) {
+    atomicOr(t.status, 1);          // would alias another key: reported by v3d_hash_status, row left out
+    return;
+  }
+  const unsigned long long key = pack_key(cb, cx, cy, cz);
   unsigned slot = hash_u64(key) & t.mask;
   for (unsigned probe = 0; probe <= t.mask; ++probe) {
     const unsigned long long prev = atomicCAS(&t.keys[slot], kEmpty, key);
@@ -139,13 +150,26 @@ HashTable table_view(void* buf, int n) {
   const unsigned cap = table_capacity(n);
   t.keys = (unsigned long long*)buf;
   t.vals = (int*)((char*)buf + (size_t)cap * 8);
+  t.status = (int*)((char*)buf + (size_t)cap * 12);
   t.mask = cap - 1;
   return t;
 }
 
 }  // namespace
 
-extern "C" size_t v3d_hash_bytes(int n) { return (size_t)table_capacity(n) * 12; }
+extern "C" size_t v3d_hash_bytes(int n) { return (size_t)table_capacity(n) * 12 + 16; }
+
+extern "C" int v3d_hash_status(const void* table, int n, void* stream) {
+  V3D_REQUIRE(table && n > 0, V3D_ERR_BAD_ARG, "v3d_hash_status: bad argument");
+  HashTable t = table_view(const_cast<void*>(table), n);
+  int st = 0;
+  V3D_CHECK_HIP(hipMemcpyAsync(&st, t.status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  V3D_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  V3D_REQUIRE(st == 0, V3D_ERR_BAD_SHAPE,
+              "v3d_hash_build: a coordinate is outside the packed-key range (batch 0..65535, x/y/z %d..%d)", -kGuard,
+              kCoordMax);
+  return V3D_OK;
+}
 
 extern "C" int v3d_hash_build(const int32_t* coords, int n, void* table, size_t table_bytes, void* stream) {
   V3D_REQUIRE(coords && table, V3D_ERR_BAD_ARG, "v3d_hash_build: null argument");
@@ -154,7 +178,7 @@ extern "C" int v3d_hash_build(const int32_t* coords, int n, void* table, size_t 
   hipStream_t s = (hipStream_t)stream;
   HashTable t = table_view(table, n);
   v3d::TimedScope ts("hash_build", s);
-  hash_clear_kernel<<<(t.mask + 256) / 256, 256, 0, s>>>(t.keys, t.mask + 1);
+  hash_clear_kernel<<<(t.mask + 256) / 256, 256, 0, s>>>(t.keys, t.mask + 1, t.status);
   hash_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(t, coords, n);
   V3D_CHECK_LAUNCH("hash_insert_kernel");
   return V3D_OK;

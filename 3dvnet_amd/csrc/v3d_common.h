@@ -71,6 +71,19 @@ __device__ __forceinline__ int xcd_contiguous_block() {
   return x * per + (x < rem ? x : rem) + i;
 }
 
+// Pinned evaluation orders of the camera arithmetic (scripts/coord_order_probe.py): torch.bmm evaluates the large batched
+// products K^-1 p, R^T c and P [X;1] as FMA chains in k order whose first term is a plain product; hipcc's default
+// -ffp-contract=fast would pick its own mul/add pairs to fuse (it did: one row of P [X;1] came out as
+// fma(a0,b0, rnd(a1 b1)) + rnd(a2 b2)), so the chains are spelled out.  With these orders the sample coordinates and the
+// bilinear taps reproduce the reference's CPU arithmetic bit for bit.
+__device__ __forceinline__ float dot3_chain(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, __fmul_rn(a0, b0)));
+}
+// [a0 a1 a2 a3] . [b0 b1 b2 1]: the homogeneous term is fma(a3, 1, acc) = a rounded addition
+__device__ __forceinline__ float dot4h_chain(float a0, float b0, float a1, float b1, float a2, float b2, float a3) {
+  return __fadd_rn(dot3_chain(a0, b0, a1, b1, a2, b2), a3);
+}
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 

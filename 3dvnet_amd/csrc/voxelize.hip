@@ -17,7 +17,11 @@ struct VoxMeta {          // device-resident, produced by bbox_finish_kernel
   long long num[4];       // trunc((end - start) / size) + 1     (torch_cluster) -- used to ENCODE
   long long cum[4];
   long long max_batch;
+  int error;              // != 0: the scene does not fit the fixed tables (v3d_voxelize_status)
 };
+
+constexpr int kMaxBatch = 1024;        // rows of the per-batch min-index table in the workspace
+constexpr long long kMaxGrid = 65000;  // voxel indices must fit the 16-bit fields of the sparse-tensor keys (sparse.hip)
 
 constexpr int kRedBlocks = 256;
 
@@ -28,8 +32,13 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restri
   float mb = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { const float v = pts[(size_t)i * 3 + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
-    mb = fmaxf(mb, (float)batch[i]);
+    for (int d = 0; d < 3; ++d) {
+      const float v = pts[(size_t)i * 3 + d];
+      lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+      if (!(fabsf(v) <= 3e38f)) mb = INFINITY;        // NaN / inf coordinate: poisons the batch maximum -> error word
+    }
+    const long long bi = batch[i];
+    mb = fmaxf(mb, bi < 0 ? INFINITY : (float)bi);
   }
   __shared__ float s[7][256];
 #pragma unroll
@@ -64,9 +73,14 @@ __global__ void bbox_finish_kernel(const float* __restrict__ part, int nblocks, 
     meta->num[d] = (long long)((hi[d] - lo[d]) / edge) + 1;        // trunc toward zero
     meta->cum[d] = cum; cum *= meta->num[d];
   }
+  int err = 0;
+  if (!(mb >= 0.f) || !(mb < (float)kMaxBatch)) { err |= 1; mb = mb < 3e18f ? mb : -1.f; }
   meta->num[3] = (long long)mb + 1;                                 // batch dimension: size 1, start 0
   meta->cum[3] = cum;
   meta->max_batch = (long long)mb;
+  for (int d = 0; d < 3; ++d)
+    if (!(hi[d] >= lo[d]) || meta->grid[d] > kMaxGrid || meta->num[d] > kMaxGrid) err |= 2;
+  meta->error = err;
 }
 
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ pts,
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(256) void voxel_decode_kernel(const unsigned long l
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool live = i < n_u;
   const long long id = live ? (long long)uniq[i] : 0;
+  if (meta->error) return;                                    // reported by v3d_voxelize_status; nothing is written
   const long long b = id / meta->cum[3];                      // == scatter-min of pts_batch over the voxel (:50)
   const long long gxy = meta->grid[0] * meta->grid[1];
   const long long rem = id - b * (gxy * meta->grid[2]);       // anchor_idx -= anchor_batch * max_grid_idx (:53)
@@ -133,9 +148,10 @@ __global__ __launch_bounds__(256) void voxel_decode_kernel(const unsigned long l
 }
 
 __global__ __launch_bounds__(256) void voxel_shift_kernel(int* __restrict__ idx3d, const long long* __restrict__ ab,
-                                                          const int* __restrict__ min_idx, int n_u) {
+                                                          const int* __restrict__ min_idx, int n_u,
+                                                          const VoxMeta* __restrict__ meta) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_u * 3) return;
+  if (i >= n_u * 3 || meta->error) return;
   idx3d[i] -= min_idx[ab[i / 3] * 3 + i % 3];                                   // (:62)
 }
 
@@ -231,7 +247,23 @@ extern "C" int v3d_unpack_coords(const uint64_t* keys, int n, int32_t* coords_ou
 
 // workspace layout of the voxelize calls: [VoxMeta 256][partials kRedBlocks*7 floats][min_idx 1024*3 ints]
 extern "C" size_t v3d_voxelize_workspace_bytes(void) {
-  return 256 + v3d::align_up(kRedBlocks * 7 * sizeof(float), 256) + 1024 * 3 * sizeof(int);
+  return 256 + v3d::align_up(kRedBlocks * 7 * sizeof(float), 256) + kMaxBatch * 3 * sizeof(int);
+}
+
+// Host-visible result of the range checks made by v3d_voxel_keys (synchronises the stream; the Python caller runs it
+// right after v3d_sort_unique_u64, which has synchronised already).
+extern "C" int v3d_voxelize_status(const void* workspace, size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(workspace && workspace_bytes >= v3d_voxelize_workspace_bytes(), V3D_ERR_BAD_ARG,
+              "v3d_voxelize_status: not a voxelize workspace");
+  VoxMeta m;
+  V3D_CHECK_HIP(hipMemcpyAsync(&m, workspace, sizeof(VoxMeta), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  V3D_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  V3D_REQUIRE((m.error & 1) == 0, V3D_ERR_BAD_SHAPE, "voxelize: batch id %lld outside [0, %d) (-1: negative id or non-finite point)",
+              m.max_batch, kMaxBatch);
+  V3D_REQUIRE((m.error & 2) == 0, V3D_ERR_BAD_SHAPE,
+              "voxelize: grid %lld x %lld x %lld exceeds %lld cells per axis (or the point cloud holds NaN)", m.grid[0],
+              m.grid[1], m.grid[2], kMaxGrid);
+  return V3D_OK;
 }
 
 extern "C" int v3d_voxel_keys(const float* pts, const int64_t* pts_batch, int n, float edge_len,
@@ -275,12 +307,12 @@ extern "C" int v3d_voxel_decode(const uint64_t* unique_keys, int n_unique, float
   const VoxMeta* meta = (const VoxMeta*)workspace;
   int* min_idx = (int*)((char*)workspace + 256 + v3d::align_up(kRedBlocks * 7 * sizeof(float), 256));
   v3d::TimedScope ts("voxel_decode", s);
-  fill_int_kernel<<<(1024 * 3 + 255) / 256, 256, 0, s>>>(min_idx, 1024 * 3, 0x7fffffff);
+  fill_int_kernel<<<(kMaxBatch * 3 + 255) / 256, 256, 0, s>>>(min_idx, kMaxBatch * 3, 0x7fffffff);
   voxel_decode_kernel<<<(n_unique + 255) / 256, 256, 0, s>>>((const unsigned long long*)unique_keys, n_unique,
                                                              edge_len, half_edge, meta, anchor_pts, anchor_idx3d,
                                                              (long long*)anchor_batch, min_idx);
   voxel_shift_kernel<<<(n_unique * 3 + 255) / 256, 256, 0, s>>>(anchor_idx3d, (const long long*)anchor_batch,
-                                                               min_idx, n_unique);
+                                                               min_idx, n_unique, meta);
   V3D_CHECK_LAUNCH("voxel_shift_kernel");
   return V3D_OK;
 }

@@ -32,34 +32,51 @@ def shard_range(n, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(x, group=None):
-    """All-gather tensors that differ in dim 0, concatenated in rank order."""
+def all_gather_rows(x, sizes=None, group=None):
+    """All-gather tensors that differ in dim 0, concatenated in rank order: ONE collective (all_gather_into_tensor on
+    rows padded to the largest shard).  ``sizes`` = rows per rank; the scene driver knows them analytically
+    (shard_range), so no size exchange and no host synchronisation is needed; when omitted they are exchanged first."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    n = torch.tensor([x.shape[0]], dtype=torch.long, device=x.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    pad = torch.zeros((max(sizes),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[:x.shape[0]] = x
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+    if sizes is None:
+        n = torch.tensor([x.shape[0]], dtype=torch.long, device=x.device)
+        got = torch.empty(world, dtype=torch.long, device=x.device)
+        dist.all_gather_into_tensor(got, n, group=group)
+        sizes = [int(v) for v in got.tolist()]
+    assert len(sizes) == world and sizes[dist.get_rank(group)] == x.shape[0], (sizes, x.shape)
+    m = max(sizes)
+    if x.shape[0] == m:
+        pad = x.contiguous()
+    else:
+        pad = torch.zeros((m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+    out = torch.empty((world * m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if all(sz == m for sz in sizes):
+        return out
+    out = out.view((world, m) + tuple(x.shape[1:]))
+    return torch.cat([out[r, :sz] for r, sz in enumerate(sizes)], dim=0)
 
 
-def gather_pointcloud(pts, pts_feat, pts_batch, group=None):
-    """The one exchange step of the path: [pts | feat] in one message + batch ids."""
-    packed = all_gather_rows(torch.cat((pts, pts_feat), dim=1), group)
-    return packed[:, :3].contiguous(), packed[:, 3:].contiguous(), all_gather_rows(pts_batch, group)
+def gather_pointcloud(pts, pts_feat, pts_batch, sizes=None, group=None):
+    """The one exchange step of the path: the feature-rich point cloud [pts | feat | batch id] of
+    every rank in ONE all-gather, rank order = view order, so the result equals the single-process tensor bit for
+    bit (batch ids are small integers, exact in fp32)."""
+    packed = all_gather_rows(torch.cat((pts, pts_feat, pts_batch.to(pts.dtype).unsqueeze(1)), dim=1), sizes, group)
+    c = pts_feat.shape[1]
+    return (packed[:, :3].contiguous(), packed[:, 3:3 + c].contiguous(),
+            packed[:, 3 + c].to(pts_batch.dtype).contiguous())
 
 
 def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, offsets_list=None,
                   init_depth_batch=INIT_DEPTH_BATCH, offset_batch=OFFSET_BATCH, rank=0, world=1,
-                  group=None, gather_depth=True, upsample=False):
+                  group=None, gather_depth=True, upsample=False, init_depth_override=None):
     """Returns the refined depth maps [n_ref, h, w] (all views when gather_depth, else this rank's).
 
-    ``batch``: images (or precomputed ``features_quarter``), rotmats, tvecs, K, ref_src_edges for the
-    whole scene with the reference's edge convention (dsets/dataset.py:133-137)."""
+    ``batch``: images (or precomputed ``features_quarter`` [+ ``features_half`` for ``upsample``]), rotmats, tvecs, K,
+    ref_src_edges for the whole scene with the reference's edge convention (dsets/dataset.py:133-137).
+    ``init_depth_override`` (benchmark hook, [n_ref, h, w]): stage 1 still runs, then its depths are replaced by
+    these (bench.py uses surface-like depths because random synthetic features give noise depths)."""
     depth_config = depth_config or DEPTH_CONFIG
     offsets_list = offsets_list or OFFSETS_LIST
     k = n_src_on_either_side
@@ -71,6 +88,7 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         has_feats = getattr(batch, 'features_quarter', None) is not None
         all_depth = torch.empty((n_local, *depth_config['size']), dtype=torch.float32, device=device)
         feats_local = None          # quarter features of images [r0, r1 + 2k)
+        half_local = None           # half-resolution features of the same images (stage 3 only, eval-3dvnet.py:36,62)
 
         # ---- stage 1: initial depth, chunks of init_depth_batch reference views (:41-63) ----------
         for c0 in range(r0, r1, init_depth_batch):
@@ -84,13 +102,27 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             sl.images_batch = torch.zeros(idx_end - idx_start, dtype=torch.long)
             if has_feats:
                 sl.features_quarter = batch.features_quarter[idx_start:idx_end]
+                if getattr(batch, 'features_half', None) is not None:
+                    sl.features_half = batch.features_half[idx_start:idx_end]
             sl.to(device)
-            pred, _, _, feats_quarter, _, _ = net.make_initial_depth_predictions(sl, depth_config)
+            pred, _, feats_half, feats_quarter, _, _ = net.make_initial_depth_predictions(sl, depth_config)
             all_depth[c0 - r0:c1 - r0] = pred
             if feats_local is None:
                 feats_local = torch.empty((n_local + 2 * k,) + tuple(feats_quarter.shape[1:]),
                                           dtype=torch.float32, device=device)
             feats_local[idx_start - r0:idx_end - r0] = feats_quarter
+            if upsample:
+                # like all_feats_half of the reference (eval-3dvnet.py:36,62): kept from stage 1, whether the
+                # features came from the injected backbone or were precomputed on the batch
+                if feats_half is None:
+                    raise ValueError('process_scene(upsample=True) needs half-resolution features: a backbone on '
+                                     'net.mvsnet or batch.features_half')
+                if half_local is None:
+                    half_local = torch.empty((n_local + 2 * k,) + tuple(feats_half.shape[1:]),
+                                             dtype=torch.float32, device=device)
+                half_local[idx_start - r0:idx_end - r0] = feats_half
+        if init_depth_override is not None:
+            all_depth = init_depth_override[r0:r1].to(device=device, dtype=torch.float32).clone()
 
         # ---- stage 2: volumetric refinement (:65-99) ------------------------------------------------
         rot = batch.rotmats[r0:r1 + 2 * k].to(device)
@@ -98,7 +130,10 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         K = batch.K[r0:r1 + 2 * k].to(device)
         edges_local = (utils.slice_edges(batch.ref_src_edges, r0 + k, r1 + k, 0) - r0).to(device)
         depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
-        gather_fn = (lambda p, f, b: gather_pointcloud(p, f, b, group)) if world > 1 else None
+        n_pix = depth_config['size'][0] * depth_config['size'][1]
+        shard_rows = [(shard_range(n_ref_imgs, g, world)[1] - shard_range(n_ref_imgs, g, world)[0]) for g in range(world)]
+        gather_fn = (lambda p, f, b: gather_pointcloud(p, f, b, [n * n_pix for n in shard_rows], group)) \
+            if world > 1 else None
         # the chunk edge lists (and their CSR form on the device) are the same for every sweep: build them once
         chunks = []
         for b0 in range(0, n_local, offset_batch):
@@ -119,10 +154,10 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             # ---- stage 3 (:101-125): plane grid -> 1/4 -> 1/2 -> full resolution, guided by the quarter /
             # half features and the image of each reference view (images k .. k + n_local of the halo'd slice)
             from .upsampling import upsample_depth
-            half = batch.features_half[r0 + k:r1 + k].to(device)
             imgs = batch.images[r0 + k:r1 + k].to(device)
             all_depth = upsample_depth(all_depth, [(net.refine_quarter, feats_local[k:k + n_local]),
-                                                   (net.refine_half, half), (net.refine_full, imgs)])
+                                                   (net.refine_half, half_local[k:k + n_local]),
+                                                   (net.refine_full, imgs)])
         if world > 1 and gather_depth:
-            all_depth = all_gather_rows(all_depth, group)
+            all_depth = all_gather_rows(all_depth, shard_rows, group)
         return all_depth

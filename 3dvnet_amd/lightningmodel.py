@@ -49,18 +49,27 @@ class PL3DVNet(nn.Module):
 
     def __init__(self, depth_train, depth_test, edge_len, feat_dim=16, img_size=(256, 320), hyp_ksize=3,
                  hyp_pad=1, lr=1e-3, lr_step=100, lr_gamma=0.1, finetune=False, feat_extractor=None,
-                 feat_shrinker=None):
+                 feat_shrinker=None, precision='split_bf16', backbone=False):
+        """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20).  Extra keywords:
+        ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
+        one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
+        ('split_bf16' | 'fp32') selects the MFMA operand precision of every matrix-core kernel (include/v3d.h)."""
         super().__init__()
+        if backbone and feat_extractor is None:
+            from .backbone import build_backbone
+            feat_extractor, feat_shrinker = build_backbone(feat_dim)
         self.depth_train, self.depth_test, self.edge_len = depth_train, depth_test, edge_len
         self.feat_dim, self.img_size = feat_dim, img_size
         self.hparams = SimpleNamespace(depth_train=depth_train, depth_test=depth_test, edge_len=edge_len,
                                        feat_dim=feat_dim, img_size=img_size, hyp_ksize=hyp_ksize,
                                        hyp_pad=hyp_pad, lr=lr, lr_step=lr_step, lr_gamma=lr_gamma,
                                        finetune=finetune)
-        self.mvsnet = MVSNet(feat_dim, img_size, feat_extractor, feat_shrinker)
-        self.pointnet = PointNet(4 * feat_dim, 2 * feat_dim, feat_dim + 3)
-        self.sparse_conv = SparseUNet(dims=(2 * feat_dim, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3))
-        self.decoder = HypothesisDecoder(128 + 128 + 3 * feat_dim, 128, hyp_ksize, hyp_pad)
+        self.precision = precision
+        self.mvsnet = MVSNet(feat_dim, img_size, feat_extractor, feat_shrinker, precision=precision)
+        self.pointnet = PointNet(4 * feat_dim, 2 * feat_dim, feat_dim + 3, precision=precision)
+        self.sparse_conv = SparseUNet(dims=(2 * feat_dim, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3),
+                                      precision=precision)
+        self.decoder = HypothesisDecoder(128 + 128 + 3 * feat_dim, 128, hyp_ksize, hyp_pad, precision=precision)
         # stage-3 upsamplers (lightningmodel.py:41-43): stock 2D convolutions, SURVEY.md 8f "next" row
         self.refine_quarter = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
         self.refine_half = PropagationNet(in_dim=feat_dim + 1, h_dim=32)

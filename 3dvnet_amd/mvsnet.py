@@ -30,6 +30,20 @@ class _Workspace:
         return buf
 
 
+def module_state_key(module):
+    """Cache key of a module's packed device weights.  ``tensor._version`` alone misses ``module.to(device)``,
+    ``p.data = ...``, ``load_state_dict(assign=True)`` and ``swap_tensors`` (new storage, coinciding versions), so the
+    identity, storage address, device and dtype of every parameter / buffer are part of the key."""
+    return tuple((id(p), int(p._version), p.data_ptr(), str(p.device), str(p.dtype))
+                 for p in list(module.parameters()) + list(module.buffers()))
+
+
+def module_device(module):
+    for p in module.parameters():
+        return p.device
+    return torch.device('cpu')
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise _lib.V3DLibraryError('%s: tensors must live on a HIP device (no CPU fallback)' % what)
@@ -60,10 +74,14 @@ class CostRegNet(nn.Module):
     """Dense 3D-conv regulariser, reference ``CostRegNet(in_channels, base_channels)``
     (mvsnet.py:133-163).  ``forward(x[B,Cin,D,h,w]) -> [B,1,D,h,w]``."""
 
-    def __init__(self, in_channels, base_channels):
+    def __init__(self, in_channels, base_channels, precision='split_bf16'):
         super().__init__()
         b = base_channels
         self.in_channels, self.base_channels = in_channels, base_channels
+        # MFMA operand precision of every layer (include/v3d.h, V3D_PRECISION_*): 'split_bf16' (default: three bf16
+        # products per fp32 product, 16 mantissa bits) or 'fp32' (exact-fp32 matrix cores, the reference's arithmetic)
+        _lib.precision_code(precision)
+        self.precision = precision
         self.conv0 = ConvBnRelu3d(in_channels, b)
         self.conv1 = ConvBnRelu3d(b, 2 * b, stride=2)
         self.conv2 = ConvBnRelu3d(2 * b, 2 * b)
@@ -83,11 +101,11 @@ class CostRegNet(nn.Module):
     def _layers(self):
         return [getattr(self, 'conv%d' % i) for i in range(10)]
 
-    def _state_key(self):
-        return tuple(int(p._version) for p in list(self.parameters()) + list(self.buffers()))
-
-    def packed_handle(self):
-        key = self._state_key()
+    def packed_handle(self, device=None):
+        """BN-folded MFMA weight image on `device` (default: the parameters' device), re-packed whenever a
+        parameter / buffer changed, was replaced or moved, or the input lives on another HIP device."""
+        device = torch.device(device) if device is not None else module_device(self)
+        key = (str(device),) + module_state_key(self)
         if self._handle is not None and key == self._packed_key:
             return self._handle
         self.release()
@@ -109,13 +127,16 @@ class CostRegNet(nn.Module):
         eps = {float(l.bn.eps) for l in layers}
         assert len(eps) == 1
         handle = ctypes.c_void_p()
-        rc = lib.v3d_costreg_pack(parray(convs), parray([l.bn.weight for l in layers]),
-                                  parray([l.bn.bias for l in layers]),
-                                  parray([l.bn.running_mean for l in layers]),
-                                  parray([l.bn.running_var for l in layers]),
-                                  host(self.prob.weight), host(self.prob.bias),
-                                  self.in_channels, self.base_channels, eps.pop(),
-                                  ctypes.byref(handle))
+        if device.type != 'cuda':
+            raise _lib.V3DLibraryError('CostRegNet: weights must be packed for a HIP device (no CPU fallback)')
+        with torch.cuda.device(device):          # the library allocates the weight image on the current device
+            rc = lib.v3d_costreg_pack(parray(convs), parray([l.bn.weight for l in layers]),
+                                      parray([l.bn.bias for l in layers]),
+                                      parray([l.bn.running_mean for l in layers]),
+                                      parray([l.bn.running_var for l in layers]),
+                                      host(self.prob.weight), host(self.prob.bias),
+                                      self.in_channels, self.base_channels, eps.pop(),
+                                      ctypes.byref(handle))
         _lib.check(rc, 'v3d_costreg_pack')
         self._handle, self._packed_key = handle, key
         return handle
@@ -132,10 +153,13 @@ class CostRegNet(nn.Module):
             pass
 
     # -- execution --------------------------------------------------------------------------------
-    def regularize_depth(self, x, depth_vals, return_reg=False):
+    def regularize_depth(self, x, depth_vals, return_reg=False, precision=None):
         """Rows A5-A6 fused: x [B,Cin,D,h,w] variance volume, depth_vals [D] ->
-        depth [B,h,w] (and x_reg [B,D,h,w] when return_reg)."""
+        depth [B,h,w] (and x_reg [B,D,h,w] when return_reg).  ``precision`` overrides ``self.precision``."""
         split = isinstance(x, SplitVariance)
+        precision = precision or self.precision
+        if split and precision != 'split_bf16':
+            raise ValueError("a SplitVariance volume is the split_bf16 operand encoding; pass the fp32 volume for 'fp32'")
         _require_cuda(x.data if split else x, 'CostRegNet')
         assert not self.training, 'inference only: BatchNorm is folded with running statistics'
         lib = _lib.load()
@@ -145,22 +169,27 @@ class CostRegNet(nn.Module):
             x = x.contiguous().float()
             B, C, D, h, w = x.shape
         assert C == self.in_channels
-        handle = self.packed_handle()
+        handle = self.packed_handle(x.device)
         depth = torch.empty((B, h, w), dtype=torch.float32, device=x.device)
         reg = torch.empty((B, D, h, w), dtype=torch.float32, device=x.device) if return_reg else None
         nbytes = lib.v3d_costreg_workspace_bytes(handle, B, D, h, w)
         ws = self._ws.get('costreg', nbytes, x.device)
         depth_vals = depth_vals.to(device=x.device, dtype=torch.float32).contiguous()
-        fn = lib.v3d_costreg_depth_split if split else lib.v3d_costreg_depth_f32
-        rc = fn(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth), _lib.ptr(reg),
-                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        if split:
+            rc = lib.v3d_costreg_depth_split(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth),
+                                             _lib.ptr(reg), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        else:
+            rc = lib.v3d_costreg_depth_f32(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth),
+                                           _lib.ptr(reg), _lib.precision_code(precision), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(x.device))
         _lib.check(rc, 'v3d_costreg_depth_split' if split else 'v3d_costreg_depth_f32')
         return (depth, reg) if return_reg else depth
 
-    def run_layer(self, layer, x, skip=None, split=False):
+    def run_layer(self, layer, x, skip=None, split=False, precision='split_bf16'):
         """One conv/deconv + folded BN + ReLU (+ skip) layer, for per-layer parity tests.
         `split=True` (layers 1..8): the kernel the fused path uses for that layer (split-bf16 matrix
-        cores); default: the exact-fp32 per-layer kernel (layer 0: always its product kernel)."""
+        cores, split activation layout); otherwise the fp32-layout per-layer kernel: exact fp32 for
+        layers 1..9, and for layer 0 its split-bf16 product kernel unless ``precision='fp32'``."""
         _require_cuda(x, 'CostRegNet')
         lib = _lib.load()
         x = x.contiguous().float()
@@ -178,13 +207,14 @@ class CostRegNet(nn.Module):
         if split:
             nbytes = lib.v3d_costreg_layer_split_workspace_bytes(n, x.shape[1], Di, Hi, Wi)
             ws = self._ws.get('layer_split', nbytes, x.device)
-            rc = lib.v3d_costreg_layer_split_f32(self.packed_handle(), layer, _lib.ptr(x), _lib.ptr(skip), n,
+            rc = lib.v3d_costreg_layer_split_f32(self.packed_handle(x.device), layer, _lib.ptr(x), _lib.ptr(skip), n,
                                                  Di, Hi, Wi, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                  _lib.stream_ptr(x.device))
             _lib.check(rc, 'v3d_costreg_layer_split_f32')
             return out
-        rc = lib.v3d_costreg_layer_f32(self.packed_handle(), layer, _lib.ptr(x), _lib.ptr(skip), n,
-                                       Di, Hi, Wi, _lib.ptr(out), _lib.stream_ptr(x.device))
+        rc = lib.v3d_costreg_layer_f32(self.packed_handle(x.device), layer, _lib.ptr(x), _lib.ptr(skip), n,
+                                       Di, Hi, Wi, _lib.ptr(out), _lib.precision_code(precision),
+                                       _lib.stream_ptr(x.device))
         _lib.check(rc, 'v3d_costreg_layer_f32')
         return out
 
@@ -262,13 +292,14 @@ class MVSNet(nn.Module):
     the reference) are injected; when they are ``None`` the batch must carry
     pre-computed ``features_half / features_quarter / features_eighth`` attributes."""
 
-    def __init__(self, feat_dim=32, img_size=(240, 320), feat_extractor=None, feat_shrinker=None):
+    def __init__(self, feat_dim=32, img_size=(240, 320), feat_extractor=None, feat_shrinker=None,
+                 precision='split_bf16'):
         super().__init__()
         self.feat_dim = feat_dim
         self.img_size = img_size
         self.feat_extractor = feat_extractor
         self.feat_shrinker = feat_shrinker
-        self.cnn_3d = CostRegNet(feat_dim, 8)
+        self.cnn_3d = CostRegNet(feat_dim, 8, precision=precision)
         self._ws = _Workspace()
         self._depth_vals = {}
 
@@ -282,20 +313,22 @@ class MVSNet(nn.Module):
         return self._depth_vals[key]
 
     def cost_volume_depth(self, features_quarter, batch, depth_start, depth_interval, n_planes,
-                          depth_img_size, return_intermediates=False, csr=None):
-        """Rows A1-A6 from quarter-resolution features.  Unless the caller asks for the
-        intermediates, the variance volume travels to the regulariser in its split-bf16 input
-        format (identical depth, no conversion pass in conv0)."""
-        split = not return_intermediates and features_quarter.shape[1] == 32
+                          depth_img_size, return_intermediates=False, csr=None, precision=None):
+        """Rows A1-A6 from quarter-resolution features.  ``precision`` ('split_bf16' | 'fp32') overrides the
+        regulariser's ``cnn_3d.precision``.  With split-bf16 operands, unless the caller asks for the
+        intermediates, the variance volume travels to the regulariser in its split-bf16 input format
+        (identical depth, no conversion pass in conv0)."""
+        precision = precision or self.cnn_3d.precision
+        split = not return_intermediates and features_quarter.shape[1] == 32 and precision == 'split_bf16'
         var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
                                    batch.ref_src_edges, depth_start, depth_interval, n_planes,
                                    self.img_size, depth_img_size, workspace=self._ws, csr=csr,
                                    split=split)
         vals = self.depth_values(depth_start, depth_interval, n_planes, var.device)
         if return_intermediates:
-            depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True)
+            depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True, precision=precision)
             return depth, var, reg
-        return self.cnn_3d.regularize_depth(var, vals)
+        return self.cnn_3d.regularize_depth(var, vals, precision=precision)
 
     def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size):
         if self.feat_extractor is not None:

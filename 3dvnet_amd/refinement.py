@@ -1,7 +1,8 @@
 """Host-side mirror of ``mv3d/subnetworks/refinement.py``:
 ``HypothesisDecoder`` with the reference's constructor, ``forward`` signature and ``state_dict`` keys
 (``net.{0,1,2}.{0.weight,1.*}``, ``net.3.{weight,bias}``).  ``MinkowskiInterpolation`` becomes the
-hash-indexed trilinear kernel, the Conv1d+BN+ReLU stack a 3-segment gather-GEMM on fp32 MFMA, the last
+hash-indexed trilinear kernel, the Conv1d+BN+ReLU stack a 3-segment gather-GEMM on the matrix cores (fp32
+storage / accumulation, MFMA operands per ``precision``: 'split_bf16' default, 'fp32' exact), the last
 conv + softmax a per-point wave kernel.  No CPU fallback.
 """
 import torch
@@ -22,8 +23,10 @@ class HypothesisDecoder(nn.Module):
     """``forward(xs, pts[Nq,n_hyp,3], pts_feat[Nq,n_hyp,C]|None, pts_batch[Nq]) -> preds[Nq,n_hyp]``
     (refinement.py:28-44)."""
 
-    def __init__(self, in_dim=128 + 128 + 64, h_dim=256, kernel_size=3, padding=1):
+    def __init__(self, in_dim=128 + 128 + 64, h_dim=256, kernel_size=3, padding=1, precision='split_bf16'):
         super().__init__()
+        _lib.precision_code(precision)
+        self.precision = precision
         assert kernel_size == 3 and padding == 1, 'the reference instantiates k=3, pad=1 (lightningmodel.py:39-40)'
         self.in_dim, self.h_dim = in_dim, h_dim
         self.net = nn.Sequential(conv1d_bn_relu(in_dim, h_dim), conv1d_bn_relu(h_dim, h_dim),
@@ -38,8 +41,8 @@ class HypothesisDecoder(nn.Module):
             co, ci, _ = conv.weight.shape
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)          # eval-mode BatchNorm1d folded
             bias = bn.bias - bn.running_mean * scale
-            packs.append(PackedGemm(conv.weight, 1, 3 * ci, 3, 3, co, ci, scale=scale, bias=bias))
-        dev = self.net[3].weight.device
+            packs.append(PackedGemm(conv.weight, 1, 3 * ci, 3, 3, co, ci, scale=scale, bias=bias, device=self._dev))
+        dev = self._dev
         return packs, self.net[3].weight.detach().float().contiguous().to(dev), \
             self.net[3].bias.detach().float().contiguous().to(dev)
 
@@ -83,11 +86,12 @@ class HypothesisDecoder(nn.Module):
         (and the expected offset [Nq])."""
         assert not self.training, 'inference only: BatchNorm is folded with running statistics'
         lib = _lib.load()
-        packs, w_last, b_last = self._cache.get(self._build)
+        self._dev = feats.device
+        packs, w_last, b_last = self._cache.get(self._build, feats.device)
         n_pts, n_hyp, _ = feats.shape
         x = feats.view(n_pts * n_hyp, -1)
         for pk in packs:
-            x = pk(n_pts * n_hyp, [x, x, x], group_len=n_hyp, relu_out=True)
+            x = pk(n_pts * n_hyp, [x, x, x], group_len=n_hyp, relu_out=True, precision=self.precision)
         preds = torch.empty((n_pts, n_hyp), dtype=torch.float32, device=feats.device)
         expect = None
         if offset_vals is not None:

@@ -1,9 +1,10 @@
 """Host-side mirror of ``mv3d/subnetworks/scenemodeling.py``: ``PointNet``
 and ``SparseUNet`` with the reference's constructor arguments, ``forward`` signatures, return
 structures and ``state_dict`` keys (MinkowskiEngine parameter naming: ``.kernel``, ``.gn.weight``).
-MinkowskiEngine is replaced by hash-indexed neighbour tables + the fp32-MFMA gather-GEMM of
-``lib3dvnet_hip.so`` (csrc/sparse.hip, csrc/gemm_gather.hip); torch_scatter's max is fused into the
-GEMM epilogue.  No CPU fallback.
+MinkowskiEngine is replaced by hash-indexed neighbour tables + the matrix-core gather-GEMM of
+``lib3dvnet_hip.so`` (csrc/sparse.hip, csrc/gemm_gather.hip; fp32 storage and accumulation, MFMA operands per
+the module's ``precision``: 'split_bf16' = three bf16 products per fp32 product (default), 'fp32' = exact-fp32
+MFMA); torch_scatter's max is fused into the GEMM epilogue.  No CPU fallback.
 """
 import ctypes
 
@@ -24,13 +25,21 @@ class PackedGemm:
     """Device-resident packed weights of one gather-GEMM layer (v3d_gemm_pack)."""
 
     def __init__(self, w, stride_seg, stride_co, stride_k, n_seg, N, K, scale=None, bias=None,
-                 gn_w=None, gn_b=None):
+                 gn_w=None, gn_b=None, device=None):
         lib = _lib.load()
         keep = [_host_f32(w)] + [None if x is None else _host_f32(x) for x in (scale, bias, gn_w, gn_b)]
         ptrs = [None if a is None else a.ctypes.data_as(_lib.c_float_p) for a in keep]
         self.handle = ctypes.c_void_p()
-        rc = lib.v3d_gemm_pack(ptrs[0], stride_seg, stride_co, stride_k, n_seg, N, K, ptrs[1], ptrs[2],
-                               ptrs[3], ptrs[4], ctypes.byref(self.handle))
+        if device is None:      # host-resident weights are packed for the current HIP device
+            if not torch.cuda.is_available():
+                raise _lib.V3DLibraryError('gather-GEMM: no HIP device to pack the weights for (no CPU fallback)')
+            device = w.device if w.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.V3DLibraryError('gather-GEMM: weights must be packed for a HIP device (no CPU fallback)')
+        with torch.cuda.device(self.device):     # the library allocates the weight image on the current device
+            rc = lib.v3d_gemm_pack(ptrs[0], stride_seg, stride_co, stride_k, n_seg, N, K, ptrs[1], ptrs[2],
+                                   ptrs[3], ptrs[4], ctypes.byref(self.handle))
         _lib.check(rc, 'v3d_gemm_pack')
         self.n_seg, self.N, self.K = n_seg, N, K
 
@@ -44,7 +53,7 @@ class PackedGemm:
 
     def __call__(self, M, srcs, idxs=None, lds=None, group_len=0, relu_in=False, use_gn=False,
                  gn_eps=1e-5, residual=None, relu_out=False, pool=None, pool_idx=None, out=True,
-                 device=None):
+                 precision='split_bf16'):
         """srcs: list of n_seg source matrices [rows, ld] (float32, contiguous);
         idxs: list of int32 row maps (or None = identity) per segment."""
         lib = _lib.load()
@@ -52,6 +61,8 @@ class PackedGemm:
         dev = srcs[0].device
         if not srcs[0].is_cuda:
             raise _lib.V3DLibraryError('gather-GEMM: tensors must live on a HIP device (no CPU fallback)')
+        if dev != self.device:
+            raise _lib.V3DLibraryError('gather-GEMM: weights were packed on %s, input lives on %s' % (self.device, dev))
         assert len(srcs) == n
         src_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
         idx_arr = (ctypes.c_void_p * n)(*[(None if (idxs is None or idxs[i] is None) else
@@ -67,21 +78,23 @@ class PackedGemm:
             self.handle, M, src_arr, idx_arr, ld_arr, group_len, int(relu_in), int(use_gn), gn_eps,
             _lib.ptr(residual), residual.shape[-1] if residual is not None else 0, int(relu_out),
             _lib.ptr(pool), _lib.ptr(pool_idx), pool.shape[-1] if pool is not None else 0,
-            _lib.ptr(y), y.stride(0) if y is not None else 0, _lib.stream_ptr(dev))
+            _lib.ptr(y), y.stride(0) if y is not None else 0, _lib.precision_code(precision), _lib.stream_ptr(dev))
         _lib.check(rc, 'v3d_gemm_gather_f32')
         return y
 
 
 class _PackCache:
-    """Re-packs when any parameter of the owning module changed (version counters)."""
+    """Re-packs when any parameter / buffer of the owning module changed, was replaced or moved to another device
+    (see ``mvsnet.module_state_key``), or when the input lives on a different HIP device than the packed image."""
 
     def __init__(self, module):
         self._module = module
         self._key = None
         self._packs = None
 
-    def get(self, builder):
-        key = tuple(int(p._version) for p in list(self._module.parameters()) + list(self._module.buffers()))
+    def get(self, builder, device=None):
+        from .mvsnet import module_state_key
+        key = (str(device),) + module_state_key(self._module)
         if self._packs is None or key != self._key:
             self._packs, self._key = builder(), key
         return self._packs
@@ -91,8 +104,10 @@ class PointNet(nn.Module):
     """Reference ``PointNet(hidden_dim, out_dim, in_dim=3)`` (scenemodeling.py:116-144):
     ``forward(pts[Np,in_dim], idx[Np], n_idx) -> [n_idx, out_dim]``."""
 
-    def __init__(self, hidden_dim, out_dim, in_dim=3):
+    def __init__(self, hidden_dim, out_dim, in_dim=3, precision='split_bf16'):
         super().__init__()
+        _lib.precision_code(precision)
+        self.precision = precision
         self.hidden_dim = hidden_dim
         self.fc_pos = nn.Linear(in_dim, hidden_dim)
         self.fc1 = nn.Linear(hidden_dim, hidden_dim)
@@ -105,16 +120,17 @@ class PointNet(nn.Module):
     def _build(self):
         def lin(m, n_seg):
             N, Kt = m.weight.shape
-            return PackedGemm(m.weight, Kt // n_seg, Kt, 1, n_seg, N, Kt // n_seg, bias=m.bias)
+            return PackedGemm(m.weight, Kt // n_seg, Kt, 1, n_seg, N, Kt // n_seg, bias=m.bias, device=self._dev)
         return dict(fc_pos=lin(self.fc_pos, 1), fc1=lin(self.fc1, 1), fc2=lin(self.fc2, 2),
                     fc3=lin(self.fc3, 2), fc4=lin(self.fc4, 2), fc_out=lin(self.fc_out, 1))
 
     def forward(self, pts, idx, n_idx):
         if not pts.is_cuda:
             raise _lib.V3DLibraryError('PointNet: tensors must live on a HIP device (no CPU fallback)')
-        g = self._cache.get(self._build)
+        self._dev = dev = pts.device
+        g = self._cache.get(self._build, dev)
         lib = _lib.load()
-        dev = pts.device
+        pr = self.precision
         pts = pts.contiguous().float()
         Np, H = pts.shape[0], self.hidden_dim
         idx32 = idx.to(torch.int32).contiguous()
@@ -125,16 +141,16 @@ class PointNet(nn.Module):
             _lib.check(lib.v3d_fill_f32(pool.data_ptr(), pool.numel(), _NEG_INF, stream), 'v3d_fill_f32')
             return pool
 
-        h = g['fc_pos'](Np, [pts])                                            # fc_pos(pts)
+        h = g['fc_pos'](Np, [pts], precision=pr)                              # fc_pos(pts)
         pool = new_pool()
-        x = g['fc1'](Np, [h], relu_in=True, pool=pool, pool_idx=idx32)        # fc1(relu(.)) + max-pool
+        x = g['fc1'](Np, [h], relu_in=True, pool=pool, pool_idx=idx32, precision=pr)   # fc1(relu(.)) + max-pool
         for name in ('fc2', 'fc3', 'fc4'):
             nxt = new_pool()
             last = name == 'fc4'
             x = g[name](Np, [x, pool], idxs=[None, idx32], relu_in=True, pool=nxt, pool_idx=idx32,
-                        out=None if last else True)                           # fcK(relu(cat(x, pool[idx])))
+                        out=None if last else True, precision=pr)             # fcK(relu(cat(x, pool[idx])))
             pool = nxt
-        return g['fc_out'](n_idx, [pool], relu_in=True)
+        return g['fc_out'](n_idx, [pool], relu_in=True, precision=pr)
 
 
 class _SparseConv(nn.Module):
@@ -199,8 +215,10 @@ class SparseUNet(nn.Module):
     ``forward(F, pts, idx, batch, res) -> list[dict(feats, pts, res, batch, idx, stride, sparse)]``,
     coarse -> fine."""
 
-    def __init__(self, dims=(64, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3)):
+    def __init__(self, dims=(64, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3), precision='split_bf16'):
         super().__init__()
+        _lib.precision_code(precision)
+        self.precision = precision
         assert all(d // g == 16 for d, g in zip(dims, n_groups)), \
             'the fused GroupNorm epilogue handles 16-channel groups (reference: 64/4, 128/8)'
         self.dims, self.n_groups, self.n_res = tuple(dims), tuple(n_groups), tuple(n_res)
@@ -220,10 +238,10 @@ class SparseUNet(nn.Module):
         self._cache = _PackCache(self)
 
     # -- weight packing ---------------------------------------------------------------------------
-    @staticmethod
-    def _pack3(conv, norm):
+    def _pack3(self, conv, norm):
         _, ci, co = conv.kernel.shape
-        return PackedGemm(conv.kernel, ci * co, 1, co, 27, co, ci, gn_w=norm.gn.weight, gn_b=norm.gn.bias)
+        return PackedGemm(conv.kernel, ci * co, 1, co, 27, co, ci, gn_w=norm.gn.weight, gn_b=norm.gn.bias,
+                          device=self._dev)
 
     def _build(self):
         g = {}
@@ -238,7 +256,7 @@ class SparseUNet(nn.Module):
         for i, seq in enumerate(self.feat_adj):
             c2, co = seq[0].kernel.shape
             g[('feat_adj', i)] = PackedGemm(seq[0].kernel, (c2 // 2) * co, 1, co, 2, co, c2 // 2,
-                                            gn_w=seq[1].gn.weight, gn_b=seq[1].gn.bias)
+                                            gn_w=seq[1].gn.weight, gn_b=seq[1].gn.bias, device=self._dev)
         return g
 
     # -- execution ----------------------------------------------------------------------------------
@@ -257,10 +275,10 @@ class SparseUNet(nn.Module):
         _lib.check(lib.v3d_unpack_coords(uniq.data_ptr(), uniq.shape[0], out.data_ptr(), stream), 'v3d_unpack_coords')
         return out
 
-    @staticmethod
-    def _conv(pack, x, nbr, n_out, eps, residual=None):
+    def _conv(self, pack, x, nbr, n_out, eps, residual=None):
         idxs = [nbr.data_ptr() + 4 * k * n_out for k in range(27)]      # column k of the neighbour table
-        return pack(n_out, [x] * 27, idxs=idxs, use_gn=True, gn_eps=eps, residual=residual, relu_out=True)
+        return pack(n_out, [x] * 27, idxs=idxs, use_gn=True, gn_eps=eps, residual=residual, relu_out=True,
+                    precision=self.precision)
 
     def _residual(self, packs, blk, x, nbr):
         n = x.shape[0]
@@ -270,7 +288,8 @@ class SparseUNet(nn.Module):
     def forward(self, F, pts, idx, batch, res):
         if not F.is_cuda:
             raise _lib.V3DLibraryError('SparseUNet: tensors must live on a HIP device (no CPU fallback)')
-        g = self._cache.get(self._build)
+        self._dev = F.device
+        g = self._cache.get(self._build, F.device)
         coords = torch.cat((batch.unsqueeze(1), idx), dim=1).int().contiguous()       # [N,4] (b,x,y,z)
         # coordinate maps: stride-2 conv output = unique(floor(c / 2ts) * 2ts), lexicographic order
         levels = [SparseLevel(coords, 1)]
@@ -294,7 +313,8 @@ class SparseUNet(nn.Module):
             nbr = lv_rev[i].neighbors(tgt.coords, -tgt.stride)                          # transposed conv
             u = self._conv(g[('up', i)], x, nbr, tgt.n, self.up[i][1].gn.eps)
             x = g[('feat_adj', i)](tgt.n, [u, xs_rev[i + 1]], use_gn=True,
-                                   gn_eps=self.feat_adj[i][1].gn.eps, relu_out=True)   # 1x1 on ME.cat
+                                   gn_eps=self.feat_adj[i][1].gn.eps, relu_out=True,
+                                   precision=self.precision)                           # 1x1 on ME.cat
             for l, blk in enumerate(self.res_up[i]):
                 x = self._residual(g[('res_up', i, l)], blk, x, same_rev[i + 1])
             out.append((tgt, x))

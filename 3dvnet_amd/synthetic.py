@@ -209,6 +209,44 @@ def propagation_weights(in_dim=33, h_dim=32, seed=5):
     return sd
 
 
+def backbone_weights(feat_dim=32, seed=6):
+    """(state_dict of FeatureExtractor, state_dict of FeatureShrinker(feat_dim)) with torchvision's key names
+    (``layerK.<i>[.<block>.layers.<j>].weight``, ``fpn.inner_blocks.<i>.*``): seeded fan-in-scaled convolutions,
+    randomised BatchNorm statistics / affines (pretrained ImageNet weights are not available offline)."""
+    from .backbone import FeatureExtractor, FeatureShrinker
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for mod in (FeatureExtractor(), FeatureShrinker(feat_dim)):
+        sd = {}
+        for k, v in mod.state_dict().items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            if k.endswith('running_mean'):
+                sd[k] = torch.randn(v.shape, generator=g) * 0.1
+            elif k.endswith('running_var'):
+                sd[k] = torch.rand(v.shape, generator=g) + 0.5
+            elif v.dim() == 4:                                     # conv weight: ReLU-preserving scale
+                fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+                sd[k] = _uniform(g, v.shape, math.sqrt(6.0 / fan_in))
+            elif k.endswith('bias') and '.fpn.' not in '.' + k:   # BatchNorm bias
+                sd[k] = torch.randn(v.shape, generator=g) * 0.1
+            elif k.endswith('bias'):                               # FPN conv bias
+                sd[k] = _uniform(g, v.shape, 0.05)
+            else:                                                  # BatchNorm weight
+                sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        out.append(sd)
+    return tuple(out)
+
+
+def make_images(n_img, img_size, seed):
+    """Smooth seeded RGB images [n_img, 3, H, W] in ImageNet-normalised range (the reference normalises with the
+    ImageNet mean / std, mv3d/utils.py:9-14)."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn((n_img, 3, img_size[0] // 8, img_size[1] // 8), generator=g)
+    return torch.nn.functional.interpolate(low, size=tuple(img_size), mode='bilinear', align_corners=False) \
+        + 0.1 * torch.randn((n_img, 3) + tuple(img_size), generator=g)
+
+
 # ----------------------------------------------------------------------------------------------
 # benchmark configurations (BASELINE.json configs, SURVEY.md §8d)
 # ----------------------------------------------------------------------------------------------

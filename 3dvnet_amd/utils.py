@@ -48,6 +48,8 @@ def voxelize(pts, pts_batch, edge_len):
     _lib.check(lib.v3d_voxel_keys(pts.data_ptr(), pts_batch.data_ptr(), n, float(edge_len), keys.data_ptr(),
                                   ws.data_ptr(), wbytes, stream), 'v3d_voxel_keys')
     uniq = sort_unique_u64(keys)                                              # torch.unique (:48)
+    # range checks of the fixed-size device tables (batch ids, cells per axis); the stream is already synchronised
+    _lib.check(lib.v3d_voxelize_status(ws.data_ptr(), wbytes, stream), 'voxelize')
     nv = uniq.shape[0]
     inv = torch.empty(n, dtype=torch.int64, device=dev)
     _lib.check(lib.v3d_lower_bound_u64(uniq.data_ptr(), nv, keys.data_ptr(), n, inv.data_ptr(), stream),

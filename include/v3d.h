@@ -36,6 +36,17 @@ extern "C" {
 #define V3D_ERR_HIP (-4)
 #define V3D_ERR_UNSUPPORTED (-5)
 
+/* Arithmetic of the matrix-core kernels (every entry point that takes `precision`).  Storage and accumulation are
+ * fp32 in both modes; the modes differ in the MFMA operands:
+ *   V3D_PRECISION_SPLIT_BF16  each fp32 operand x = hi + lo (hi = RNE_bf16(x), lo = RNE_bf16(x - hi), 16 mantissa bits);
+ *                             product = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (lo*lo dropped).  Narrower than
+ *                             the reference's fp32; passes the 1e-4 relative depth gate of BASELINE.json (the default of
+ *                             the Python modules and of bench.py's headline value).
+ *   V3D_PRECISION_FP32        exact fp32 products on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain) -- the reference's
+ *                             arithmetic type; about 2x slower on the regulariser. */
+#define V3D_PRECISION_SPLIT_BF16 0
+#define V3D_PRECISION_FP32 1
+
 /* ABI version (bumped on any signature change) and last error text of the calling thread. */
 int v3d_version(void);
 const char* v3d_last_error(void);
@@ -110,17 +121,21 @@ void v3d_costreg_free(v3d_costreg_weights* handle);
 size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights* handle, int n_ref, int D, int h, int w);
 int v3d_costreg_depth_f32(const v3d_costreg_weights* handle, const float* var,
                           const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
-                          float* reg, void* workspace, size_t workspace_bytes, void* stream);
-/* As above with the variance volume in the split format written by v3d_psv_variance_split. */
+                          float* reg, int precision, void* workspace, size_t workspace_bytes, void* stream);
+/* As above with the variance volume in the split format written by v3d_psv_variance_split (the split format IS the
+ * V3D_PRECISION_SPLIT_BF16 operand encoding, so this entry point has no precision argument). */
 int v3d_costreg_depth_split(const v3d_costreg_weights* handle, const void* var_split,
                           const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
                           float* reg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Single dense 3D layer of the regulariser (exposed for per-layer parity tests):
  * layer 0..9 = conv0..conv9 of CostRegNet incl. folded BN + ReLU (+ `skip` added after the ReLU
- * when non-NULL, mvsnet.py:159-161).  in [n, Cin, Di, Hi, Wi] -> out [n, Cout, Do, Ho, Wo]. */
+ * when non-NULL, mvsnet.py:159-161).  in [n, Cin, Di, Hi, Wi] -> out [n, Cout, Do, Ho, Wo].
+ * precision: V3D_PRECISION_FP32 = the exact-fp32 kernel of every layer; V3D_PRECISION_SPLIT_BF16 = conv0 on its
+ * split-bf16 product kernel (the other layers' split-bf16 kernels use the split activation layout: next entry point). */
 int v3d_costreg_layer_f32(const v3d_costreg_weights* handle, int layer, const float* in,
-                          const float* skip, int n, int Di, int Hi, int Wi, float* out, void* stream);
+                          const float* skip, int n, int Di, int Hi, int Wi, float* out, int precision,
+                          void* stream);
 
 /* The same layers 1..8 (conv1..conv8) on the kernels the fused path uses: split-bf16 matrix cores reading the split
  * channel-last activation layout.  `in`, `skip` (conv7 / conv8, required) and `out` are fp32 [n, C, D, H, W]; the
@@ -149,7 +164,7 @@ int v3d_backproject_variance_f32(const float* depth, const float* feat, const fl
                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Gather-GEMM on fp32 MFMA: Y[m,:] = epilogue(sum_s act(X_s[row_s(m), 0:K]) @ W_s + bias).
+ * Gather-GEMM on the matrix cores (fp32 in/out; operands per `precision`): Y[m,:] = epilogue(sum_s act(X_s[row_s(m), 0:K]) @ W_s + bias).
  * Replaces the dense arithmetic of: PointNet's Linear layers incl. the concat with the pooled voxel
  * feature and torch_scatter max (mv3d/subnetworks/scenemodeling.py:127-144); MinkowskiConvolution /
  * ConvolutionTranspose / 1x1 + MinkowskiGroupNorm + ReLU + residual (scenemodeling.py:16-44,160,181,
@@ -174,7 +189,7 @@ int v3d_gemm_gather_f32(const v3d_gemm_weights* handle, int M, const float* cons
                         const int32_t* const* seg_idx_host, const int* seg_ld_host, int group_len,
                         int relu_in, int use_gn, float gn_eps, const float* residual, int ld_res,
                         int relu_out, float* pool, const int32_t* pool_idx, int ld_pool, float* out,
-                        int ld_out, void* stream);
+                        int ld_out, int precision, void* stream);
 int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -190,6 +205,9 @@ int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
  * ------------------------------------------------------------------------------------------ */
 size_t v3d_hash_bytes(int n);
 int v3d_hash_build(const int32_t* coords, int n, void* table, size_t table_bytes, void* stream);
+/* Keys pack 16 bits per field: batch in [0, 65535], x/y/z in [-8, 65519].  A row outside that range is left out and
+ * sets the table's error word; v3d_hash_status copies it to the host (synchronises) -> V3D_ERR_BAD_SHAPE. */
+int v3d_hash_status(const void* table, int n, void* stream);
 int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* out_coords, int n_out, int step,
                          int32_t* nbr, void* stream);
 size_t v3d_sparse_interp_workspace_bytes(int n_pts, int n_hyp);
@@ -219,6 +237,10 @@ int v3d_unpack_coords(const uint64_t* keys, int n, int32_t* coords_out, void* st
 size_t v3d_voxelize_workspace_bytes(void);
 int v3d_voxel_keys(const float* pts, const int64_t* pts_batch, int n, float edge_len, uint64_t* keys_out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* Range checks of v3d_voxel_keys (batch ids in [0, 1024), at most 65000 cells per axis, no NaN): the error word lives in
+ * `workspace`; this call copies it to the host (synchronises) and returns V3D_ERR_BAD_SHAPE if it is set, in which case
+ * v3d_voxel_decode writes nothing. */
+int v3d_voxelize_status(const void* workspace, size_t workspace_bytes, void* stream);
 int v3d_lower_bound_u64(const uint64_t* sorted_unique, int n_unique, const uint64_t* queries, int n,
                         int64_t* index_out, void* stream);
 int v3d_voxel_decode(const uint64_t* unique_keys, int n_unique, float edge_len, float half_edge,

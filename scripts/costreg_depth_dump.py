@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer / test helper: depth + regularised volume of a seeded cfg1 batch, saved to the .npz given as argv[1].
-Run under V3D_COSTREG_GENERIC=1 to get the exact-fp32 per-layer kernel chain (the switch is read once per process)."""
+"""Developer helper: depth + regularised volume of a seeded cfg1 batch, saved to the .npz given as argv[1];
+argv[2] = 'split_bf16' (default) or 'fp32' selects the regulariser's MFMA operand precision."""
 import importlib
 import os
 import sys
@@ -20,7 +20,8 @@ net = net.to(dev)
 b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(dev)
 d0, dd, D = inp['depth']
 with torch.no_grad():
-    depth, var, reg = net.cost_volume_depth(inp['feat'].to(dev), b, d0, dd, D, inp['plane_size'], return_intermediates=True)
+    depth, var, reg = net.cost_volume_depth(inp['feat'].to(dev), b, d0, dd, D, inp['plane_size'], return_intermediates=True,
+                                            precision=sys.argv[2] if len(sys.argv) > 2 else 'split_bf16')
 torch.cuda.synchronize()
 np.savez(sys.argv[1], depth=depth.cpu().numpy(), reg=reg.cpu().numpy())
 print('saved', sys.argv[1], float(depth.min()), float(depth.max()))

@@ -107,6 +107,21 @@ def golden_costvolume():
          reg_sub=reg[:, ::5, ::7, ::7], depth=d)
 
 
+def golden_cfg5():
+    """BASELINE config 5 shape (480x640, 192 planes, 1 ref + 10 src = 11 edges, 120x160 plane grid): the
+    reference's own forward at full size (about 15 GB of host memory), stored sub-sampled like cfg2."""
+    sd = syn.costregnet_weights(seed=0, sharpen=200.0)
+    inp = syn.make_costvolume_inputs('cfg5', n_ref=1)
+    assert inp['edges'].shape[1] == 11
+    d, var, reg = run_reference_mvsnet(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                                       inp['edges'], sd, inp['depth'], inp['img_size'],
+                                       inp['plane_size'])
+    save('A_cfg5', n_ref=1, weights_seed=0, sharpen=200.0, weights_checksum=checksum(sd),
+         feat_checksum=float(inp['feat'].double().sum()),
+         var_sub=var[:, ::4, ::7, ::11, ::13], var_sum=float(var.double().sum()),
+         reg_sub=reg[:, ::7, ::11, ::13], depth_sub=d[:, ::3, ::3], depth_sum=float(d.double().sum()))
+
+
 def tiny_scene(n_ref=4, seed=31, two_batches=False):
     """Small sliding-window scene in the synthetic room with analytic wall depth + noise."""
     img_size, feat_size, plane_size = (64, 80), (16, 20), (12, 14)
@@ -209,3 +224,5 @@ if __name__ == '__main__':
         golden_costvolume()
     if 'B' in which:
         golden_scene()
+    if 'cfg5' in which:      # not in the default set: needs ~15 GB of host memory and a few minutes
+        golden_cfg5()

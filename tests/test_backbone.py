@@ -1,0 +1,101 @@
+"""the MnasNet-1.0 + FPN feature extractor restated without torchvision
+(mv3d/subnetworks/mvsnet.py:55-105).  torchvision is absent here, so parity with the real package is UNPINNED; these tests
+pin what the reference relies on: the five slice points and their channel widths / strides, the FPN's outputs, and the
+state_dict key names and shapes torchvision 0.8.2 documents for ``mnasnet1_0().layers[0:14]`` and
+``ops.FeaturePyramidNetwork`` (so a reference checkpoint's ``mvsnet.feat_extractor.*`` / ``feat_shrinker.*`` entries load)."""
+import pytest
+import torch
+
+from conftest import v3d
+
+
+def test_extractor_slice_points_channels_and_strides():
+    bb = v3d('backbone')
+    fe = bb.FeatureExtractor().eval()
+    with torch.no_grad():
+        outs = fe(torch.zeros(1, 3, 64, 96))
+    assert [o.shape[1] for o in outs] == [16, 24, 40, 96, 320]
+    assert [tuple(o.shape[2:]) for o in outs] == [(32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]
+    # MnasNet-1.0 stacks: (blocks, kernel, expansion) per slice (torchvision mnasnet.py: depths 24/40/80/96/192/320)
+    assert [len(s) for s in (fe.layer2[0], fe.layer3[0], fe.layer4[0], fe.layer4[1], fe.layer5[0], fe.layer5[1])] == \
+        [3, 3, 3, 2, 4, 1]
+    assert fe.layer3[0][0].layers[3].kernel_size == (5, 5) and fe.layer3[0][0].layers[3].stride == (2, 2)
+    assert fe.layer4[1][0].layers[3].stride == (1, 1) and fe.layer2[0][1].apply_residual
+    n_params = sum(p.numel() for p in fe.parameters())
+    assert n_params == 3102312 - (320 * 1280 + 2 * 1280)      # mnasnet1_0 features (3.10 M) minus the unused 1x1 head
+
+
+def test_state_dict_keys_follow_torchvision_naming():
+    bb = v3d('backbone')
+    fe, fs = bb.build_backbone(32)
+    k = fe.state_dict()
+    assert k['layer1.0.weight'].shape == (32, 3, 3, 3) and k['layer1.3.weight'].shape == (32, 1, 3, 3)
+    assert k['layer1.6.weight'].shape == (16, 32, 1, 1) and 'layer1.7.running_var' in k
+    assert k['layer2.0.0.layers.0.weight'].shape == (48, 16, 1, 1)
+    assert k['layer2.0.0.layers.3.weight'].shape == (48, 1, 3, 3)
+    assert k['layer2.0.2.layers.6.weight'].shape == (24, 72, 1, 1)
+    assert k['layer3.0.0.layers.3.weight'].shape == (72, 1, 5, 5)
+    assert k['layer4.0.0.layers.0.weight'].shape == (240, 40, 1, 1)
+    assert k['layer4.1.1.layers.6.weight'].shape == (96, 576, 1, 1)
+    assert k['layer5.0.3.layers.3.weight'].shape == (1152, 1, 5, 5)
+    assert k['layer5.1.0.layers.6.weight'].shape == (320, 1152, 1, 1) and 'layer5.1.0.layers.7.running_mean' in k
+    f = fs.state_dict()
+    assert sorted(f) == sorted(['fpn.%s.%d.%s' % (b, i, p) for b in ('inner_blocks', 'layer_blocks')
+                                for i in range(5) for p in ('weight', 'bias')])
+    assert f['fpn.inner_blocks.4.weight'].shape == (32, 320, 1, 1) and f['fpn.layer_blocks.0.weight'].shape == (32, 32, 3, 3)
+
+
+def test_shrinker_is_a_top_down_pyramid():
+    """Against a direct evaluation of the documented recursion: P5 = out5(lat5(C5)); Pk = outk(latk(Ck) + up(inner k+1))."""
+    bb, syn = v3d('backbone'), v3d('synthetic')
+    fe, fs = bb.build_backbone(16)
+    sd_e, sd_s = syn.backbone_weights(16, seed=6)
+    assert not fe.load_state_dict(sd_e, strict=False).unexpected_keys
+    fs.load_state_dict(sd_s)
+    img = syn.make_images(2, (64, 96), seed=1)
+    with torch.no_grad():
+        maps = fe(img)
+        half, quarter, eighth, sixteenth, thirtysecond = fs(*maps)
+        inner = None
+        for i in (4, 3, 2, 1, 0):
+            lat = torch.nn.functional.conv2d(maps[i], sd_s['fpn.inner_blocks.%d.weight' % i], sd_s['fpn.inner_blocks.%d.bias' % i])
+            inner = lat if inner is None else lat + torch.nn.functional.interpolate(inner, size=lat.shape[-2:], mode='nearest')
+            want = torch.nn.functional.conv2d(inner, sd_s['fpn.layer_blocks.%d.weight' % i], sd_s['fpn.layer_blocks.%d.bias' % i], padding=1)
+            got = (half, quarter, eighth, sixteenth, thirtysecond)[i]
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    assert tuple(quarter.shape) == (2, 16, 16, 24) and tuple(half.shape) == (2, 16, 32, 48)
+    assert float(quarter.std()) > 1e-3 and torch.isfinite(quarter).all()
+
+
+@pytest.mark.gpu
+def test_mvsnet_forward_from_images(cuda):
+    """MVSNet.forward(batch.images) end to end (mvsnet.py:176-229): backbone on MIOpen -> HIP cost volume; the depth must
+    equal the cost-volume path fed with the same quarter features, and match the oracle run on those features."""
+    import numpy as np
+    from oracle import costvolume as ocv
+    syn, mvs, bb = v3d('synthetic'), v3d('mvsnet'), v3d('backbone')
+    Batch = v3d('batch').Batch
+    img_size, plane_size = (128, 160), (32, 40)
+    edges, n_img = syn.make_edges(2, 1, 1)
+    R, tv, K = syn.make_cameras(n_img, img_size, seed=5)
+    fe, fs = bb.build_backbone(32)
+    sd_e, sd_s = syn.backbone_weights(32, seed=6)
+    fe.load_state_dict(sd_e, strict=False)
+    fs.load_state_dict(sd_s)
+    sd = syn.costregnet_weights(seed=0, sharpen=1.0)
+    net = mvs.MVSNet(32, img_size, fe, fs).eval()
+    net.cnn_3d.load_state_dict(sd, strict=False)
+    net = net.to(cuda)
+    b = Batch(syn.make_images(n_img, img_size, seed=2), R, tv, K, None, edges).to(cuda)
+    with torch.no_grad():
+        depth, f_half, f_quarter, f_eighth = net(b, 0.5, 0.05, 32, plane_size)
+        assert tuple(f_half.shape) == (n_img, 32, 64, 80) and tuple(f_quarter.shape) == (n_img, 32, 32, 40)
+        assert tuple(f_eighth.shape) == (n_img, 32, 16, 20)
+        depth2, var, reg = net.cost_volume_depth(f_quarter, b, 0.5, 0.05, 32, plane_size, return_intermediates=True)
+        depth_o, var_o, reg_o = ocv.mvsnet_depth(f_quarter.cpu(), R, tv, K, edges, sd, 0.5, 0.05, 32, img_size, plane_size)
+    assert torch.equal(depth, depth2)
+    # random-init backbone features are not O(1) like the U[0,1) features of the other tests: tolerances relative to the
+    # volumes' ranges (the unsharpened soft-argmin keeps the depth well conditioned)
+    np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=1e-4 * float(var_o.abs().max()))
+    np.testing.assert_allclose(reg.cpu().numpy(), reg_o.numpy(), rtol=0, atol=2e-4 * float(reg_o.abs().max()))
+    np.testing.assert_allclose(depth.cpu().numpy(), depth_o.numpy(), rtol=1e-4, atol=0)

@@ -111,6 +111,52 @@ def test_hip_matches_reference_golden_cfg(name, cfg, cuda):
     assert g['depth'].max() - g['depth'].min() > 1.0
 
 
+def test_hip_matches_reference_golden_cfg5(cuda):
+    """BASELINE config 5 at full size (480x640, 192 planes, 120x160 plane grid) against the reference-generated golden:
+    11 edges per reference (> the 8-edge LDS pass of the warp kernel: its multi-pass branch), a count that is not a power
+    of two (the IEEE-division mean), D = 192 and partial 28-wide x tiles (160 = 5 x 28 + 20) in every layer."""
+    g = load_golden('A_cfg5')
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs('cfg5', n_ref=1)
+    assert inp['edges'].shape[1] == 11
+    assert abs(float(inp['feat'].double().sum()) - float(g['feat_checksum'])) < 1e-6
+    sd = golden_costreg_weights(g)
+    net = _net(sd, cuda, inp['img_size'])
+    depth, var, reg = _run_hip(net, inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                               inp['edges'], inp['depth'], inp['plane_size'], cuda)
+    np.testing.assert_allclose(var[:, ::4, ::7, ::11, ::13].numpy(), g['var_sub'], rtol=0, atol=VAR_ATOL)
+    assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-4 * abs(float(g['var_sum']))
+    scale = float(np.abs(g['reg_sub']).max())
+    np.testing.assert_allclose(reg[:, ::7, ::11, ::13].numpy(), g['reg_sub'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(depth[:, ::3, ::3].numpy(), g['depth_sub'], rtol=DEPTH_RTOL, atol=0)
+    assert abs(float(depth.double().sum()) - float(g['depth_sum'])) < 2e-5 * abs(float(g['depth_sum']))
+    assert g['depth_sub'].max() - g['depth_sub'].min() > 1.0
+
+
+def test_full_size_properties_cfg5_batch(cuda):
+    """cfg5 size, 3 references per launch: batch invariance (bit-exact), zero variance for self-only edges, depth
+    within the plane range -- the size-independent properties of cfg2, at the stress size."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg5', n_ref=3)
+    sd = syn.costregnet_weights(seed=0, sharpen=200.0)
+    net = _net(sd, cuda, inp['img_size'])
+    d0, dd, D = inp['depth']
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    feat = inp['feat'].to(cuda)
+    with torch.no_grad():
+        depth = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
+        assert torch.isfinite(depth).all()
+        assert depth.min() >= d0 - 1e-4 and depth.max() <= d0 + dd * (D - 1) + 1e-4
+        per = inp['edges'].shape[1] // 3
+        bi = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges'][:, per:2 * per]).to(cuda)
+        assert torch.equal(net.cost_volume_depth(feat, bi, d0, dd, D, inp['plane_size'])[0], depth[1])
+        self_edges = torch.tensor([[6] * 11, [6] * 11])
+        v_self = mvs.plane_sweep_variance(feat, b.rotmats, b.tvecs, b.K, self_edges.to(cuda), d0, dd, D,
+                                          inp['img_size'], inp['plane_size'])
+        assert float(v_self.abs().max()) < 1e-6
+
+
 def test_hip_matches_oracle_multi_ref(cuda):
     """Several reference views per launch (sliding window), cfg1 shape, vs the oracle."""
     syn = v3d('synthetic')
@@ -193,25 +239,37 @@ def test_psv_kernel_variants_bit_identical(cuda):
     assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
 
 
-def test_generic_fp32_chain_agrees_with_split_bf16_chain(cuda, tmp_path):
-    """V3D_COSTREG_GENERIC=1 runs the regulariser on the exact-fp32 per-layer kernels (conv9 and the prob conv
-    unfused); the default chain runs on split-bf16 matrix cores.  Both are within 1e-4 of the oracle, hence within
-    2e-4 of each other; the regularised volumes agree to 4e-4 of their range."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for i, extra in enumerate(({}, {'V3D_COSTREG_GENERIC': '1'})):
-        path = str(tmp_path / ('d%d.npz' % i))
-        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'costreg_depth_dump.py'), path],
-                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(np.load(path))
-    np.testing.assert_allclose(res[0]['depth'], res[1]['depth'], rtol=2e-4, atol=0)
-    scale = float(np.abs(res[1]['reg']).max())
-    np.testing.assert_allclose(res[0]['reg'], res[1]['reg'], rtol=0, atol=4e-4 * scale)
-    assert not np.array_equal(res[0]['depth'], res[1]['depth'])      # the switch really selected another chain
+def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
+    """precision='fp32' runs the regulariser on the exact-fp32 per-layer kernels (conv9 and the prob conv unfused);
+    the default 'split_bf16' chain runs on split-bf16 matrix cores.  Both are within 1e-4 of the oracle, hence within
+    2e-4 of each other; the regularised volumes agree to 4e-4 of their range.  The choice is an argument of the C ABI
+    (include/v3d.h V3D_PRECISION_*), so both run in this process."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=2, seed=21)
+    sd = syn.costregnet_weights(seed=3, sharpen=200.0)
+    net = _net(sd, cuda, inp['img_size'])
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    d0, dd, D = inp['depth']
+    res = {}
+    with torch.no_grad():
+        for pr in ('split_bf16', 'fp32'):
+            depth, _, reg = net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'],
+                                                  return_intermediates=True, precision=pr)
+            res[pr] = (depth.cpu().numpy(), reg.cpu().numpy())
+        # the module-level default is the same switch
+        net32 = mvs.MVSNet(32, inp['img_size'], precision='fp32').eval()
+        net32.cnn_3d.load_state_dict(sd, strict=False)
+        d32 = net32.to(cuda).cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'])
+        depth_o = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], sd, d0, dd, D,
+                                   inp['img_size'], inp['plane_size'])[0].numpy()
+    assert np.array_equal(d32.cpu().numpy(), res['fp32'][0])
+    np.testing.assert_allclose(res['split_bf16'][0], res['fp32'][0], rtol=2e-4, atol=0)
+    scale = float(np.abs(res['fp32'][1]).max())
+    np.testing.assert_allclose(res['split_bf16'][1], res['fp32'][1], rtol=0, atol=4e-4 * scale)
+    assert not np.array_equal(res['split_bf16'][0], res['fp32'][0])      # the argument really selected another chain
+    for pr in res:
+        np.testing.assert_allclose(res[pr][0], depth_o, rtol=DEPTH_RTOL, atol=0)
 
 
 def test_psv_feat_dim_16(cuda):
@@ -252,6 +310,10 @@ def test_costreg_single_layers(layer, cuda):
     # every other layer is exact-fp32 MFMA
     tol = (4e-5 if layer == 0 else 1e-5) * max(1.0, float(ref.abs().max()))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5 if layer else 0, atol=tol)
+    if layer == 0:      # and conv0's exact-fp32 kernel (precision='fp32')
+        out32 = net.run_layer(0, x.to(cuda), precision='fp32')
+        np.testing.assert_allclose(out32.cpu().numpy(), ref.numpy(), rtol=1e-5,
+                                   atol=1e-5 * max(1.0, float(ref.abs().max())))
 
 
 @pytest.mark.parametrize('layer', list(range(1, 9)))

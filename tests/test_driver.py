@@ -90,6 +90,82 @@ def test_two_ranks_gloo_equal_single_process():
     np.testing.assert_allclose(out, run_oracle().numpy(), rtol=1e-5, atol=0)
 
 
+def _hip_net(dev):
+    lm = v3d('lightningmodel')
+    cr, pn, un, dec = weights()
+    net = lm.PL3DVNet(None, CFG, 0.16, feat_dim=32, img_size=IMG).eval()
+    net.mvsnet.cnn_3d.load_state_dict(cr, strict=False)
+    net.pointnet.load_state_dict(pn)
+    net.sparse_conv.load_state_dict(un)
+    net.decoder.load_state_dict(dec, strict=False)
+    return net.to(dev)
+
+
+def _nccl_worker(rank, world, port, q):
+    """One process per GPU over RCCL: (1) the all-gathered feature-rich point cloud must equal the single-process
+    tensor bit for bit; (2) the sharded scene driver must reproduce the single-process depths bit for bit (the HIP path
+    is batch-invariant, unlike the CPU oracle's library kernels)."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    drv, utils = v3d('eval_3dvnet'), v3d('utils')
+    net = _hip_net(dev)
+    scene = make_scene()
+    k, n_ref = 1, 5
+    with torch.no_grad():
+        # the exchange step in isolation, on analytic depths
+        syn = v3d('synthetic')
+        depth = syn.ray_box_depth(scene.rotmats[k:k + n_ref], scene.tvecs[k:k + n_ref], scene.K[k:k + n_ref], IMG,
+                                  CFG['size']).to(dev)
+        feats = scene.features_quarter.to(dev)
+        rot, tv, K = scene.rotmats.to(dev), scene.tvecs.to(dev), scene.K.to(dev)
+        edges = scene.ref_src_edges.to(dev)
+        full = net.construct_feature_rich_pointcloud(depth, torch.zeros(n_ref, dtype=torch.long, device=dev), feats, rot,
+                                                     tv, K, edges)
+        r0, r1 = drv.shard_range(n_ref, rank, world)
+        e_loc = utils.slice_edges(edges, r0 + k, r1 + k, 0) - r0
+        loc = net.construct_feature_rich_pointcloud(depth[r0:r1], torch.zeros(r1 - r0, dtype=torch.long, device=dev),
+                                                    feats[r0:r1 + 2 * k], rot[r0:r1 + 2 * k], tv[r0:r1 + 2 * k],
+                                                    K[r0:r1 + 2 * k], e_loc)
+        n_pix = CFG['size'][0] * CFG['size'][1]
+        sizes = [(drv.shard_range(n_ref, g, world)[1] - drv.shard_range(n_ref, g, world)[0]) * n_pix
+                 for g in range(world)]
+        got = drv.gather_pointcloud(*loc, sizes=sizes)
+        same_cloud = all(torch.equal(a, b) for a, b in zip(got, full))
+        out = drv.process_scene(scene, net, k, dev, CFG, OFFSETS, 2, 3, rank=rank, world=world)
+        single = drv.process_scene(scene, net, k, dev, CFG, OFFSETS, 2, 3)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((same_cloud, bool(torch.equal(out, single)), dist.get_world_size(), out.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_nccl_equal_single_process():
+    """cfg4's exchange on real devices (RCCL all-gather over xGMI): needs two HIP devices, skipped on a 1-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 HIP devices (the gpurun / driver test box has one)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same_cloud, same_depth, world_seen, out = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert world_seen == 2 and same_cloud and same_depth
+    np.testing.assert_allclose(out, run_oracle().numpy(), rtol=1e-4, atol=0)
+
+
 @pytest.mark.gpu
 def test_hip_driver_matches_oracle_driver(cuda):
     lm, drv = v3d('lightningmodel'), v3d('eval_3dvnet')

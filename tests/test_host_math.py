@@ -97,3 +97,42 @@ def test_stride_two_conv_as_four_tap_k_steps():
         xin = lambda i: x[i] if 0 <= i < n else 0.0
         out = np.array([sum(w4[t] * xin(stride * o + t - 1) for t in range(4)) for o in range(len(ref))])
         np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
+
+
+def test_product_slice_edges_matches_reference_golden():
+    """Row H1 on the PRODUCT's copy (3dvnet_amd/utils.py::slice_edges, what process_scene calls): the reference's
+    utils.slice_edges output captured in the H_misc golden, plus order preservation on a shuffled edge list."""
+    import numpy as np
+    import torch
+    from conftest import v3d
+    from helpers import load_golden, t
+    utils = v3d('utils')
+    g = load_golden('H_misc')
+    assert np.array_equal(utils.slice_edges(t(g['edges']), 3, 5, 0).numpy(), g['sliced'])
+    e = torch.tensor([[5, 2, 9, 2, 7, 5], [1, 2, 3, 4, 5, 6]])
+    assert utils.slice_edges(e, 2, 6, 0).tolist() == [[5, 2, 2, 5], [1, 2, 4, 6]]
+    assert utils.slice_edges(e, 3, 6, 1).tolist() == [[9, 2, 7], [3, 4, 5]]
+    assert utils.slice_edges(e, 10, 12, 0).shape == (2, 0)
+
+
+def test_pack_cache_key_sees_replaced_and_moved_parameters():
+    """the packed-weight caches must not be keyed on tensor._version alone -- p.data = ..., assign-style
+    loads and device moves create new storage with coinciding versions."""
+    import torch
+    from conftest import v3d
+    mvs = v3d('mvsnet')
+    m = torch.nn.Linear(4, 4)
+    k0 = mvs.module_state_key(m)
+    assert k0 == mvs.module_state_key(m)
+    with torch.no_grad():
+        m.weight.data = m.weight.data.clone()               # same version counter, new storage
+    k1 = mvs.module_state_key(m)
+    assert k1 != k0
+    m.weight = torch.nn.Parameter(m.weight.detach().clone())    # new Parameter object
+    k2 = mvs.module_state_key(m)
+    assert k2 != k1
+    with torch.no_grad():
+        m.bias.add_(1.0)                                    # in-place update bumps the version
+    assert mvs.module_state_key(m) != k2
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
+    assert mvs.module_state_key(m) != k2

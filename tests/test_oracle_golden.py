@@ -60,3 +60,21 @@ def test_oracle_matches_reference_cfg(name, cfg):
     assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-3
     np.testing.assert_allclose(reg[:, ::3, ::5, ::7].numpy(), g['reg_sub'], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=1e-5, atol=0)
+
+
+def test_oracle_matches_reference_cfg5():
+    """BASELINE config 5 at full size: the oracle against the reference-generated golden (about 15 GB of host
+    memory and a minute of CPU: the largest case of the CPU suite)."""
+    g = load_golden('A_cfg5')
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs('cfg5', n_ref=1)
+    assert abs(float(inp['feat'].double().sum()) - float(g['feat_checksum'])) < 1e-6
+    sd = golden_costreg_weights(g)
+    d0, dd, D = inp['depth']
+    with torch.no_grad():
+        depth, var, reg = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
+                                           inp['edges'], sd, d0, dd, D, inp['img_size'],
+                                           inp['plane_size'])
+    np.testing.assert_allclose(var[:, ::4, ::7, ::11, ::13].numpy(), g['var_sub'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reg[:, ::7, ::11, ::13].numpy(), g['reg_sub'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(depth[:, ::3, ::3].numpy(), g['depth_sub'], rtol=1e-5, atol=0)
