@@ -39,6 +39,8 @@ SIGNATURES = {
     'v3d_psv_workspace_bytes': (c_size_t, [c_int] * 4),
     'v3d_psv_variance_f32': (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_double] * 2 + [c_int] * 3 +
                              [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_psv_sample_positions_f32': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_double] * 2 + [c_int] * 3 +
+                                     [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'v3d_psv_variance_split': (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_double] * 2 + [c_int] * 3 +
                                [c_void_p, c_void_p, c_size_t, c_void_p]),
     'v3d_costreg_pack': (c_int, [c_float_pp] * 5 + [c_float_p, c_float_p, c_int, c_int, c_float,

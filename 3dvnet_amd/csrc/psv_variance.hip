@@ -194,6 +194,7 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
     yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
   }
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
 
   PHASE_DECL;
@@ -222,25 +223,11 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
       PHASE_MARK(1);
       // ---- phase 1: project (pixel, edge) pairs ------------------------------------------
       {
-        // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
-        float p0 = xf * z, p1 = yf * z, p2 = z;
-        float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
-        float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
-        float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
-        float X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
-        float Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
-        float Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
+        float X, Y, Z;
+        v3d::world_point(s_ref, xf, yf, z, X, Y, Z);
         for (int e = tid / kPix; e < nec; e += kThreads / kPix) {
-          const float* Pm = s_P[e];
-          float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
-          float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
-          float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
-          float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
-          float u = qx / zb, v = qy / zb;
-          float gx = (u / Wm1) * 2.f - 1.f;                    // mvsnet.py:205-206
-          float gy = (v / Hm1) * 2.f - 1.f;
-          float ix = ((gx + 1.f) / 2.f) * Wfm1;                // grid_sample, align_corners=True
-          float iy = ((gy + 1.f) / 2.f) * Hfm1;
+          float ix, iy;
+          v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
           float x0 = floorf(ix), y0 = floorf(iy);
           float x1 = x0 + 1.f, y1 = y0 + 1.f;
           bool vx0 = (x0 >= 0.f) && (x0 <= Wfm1), vx1 = (x1 >= 0.f) && (x1 <= Wfm1);
@@ -398,29 +385,12 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
     const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
     const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
     const float z = (d1 == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d1 * p.z_step);
-    // world point of (pixel, plane): X = R^T (K^-1 [x z, y z, z] - t)   (utils.py:98-106)
-    const float p0 = xf * z, p1 = yf * z, p2 = z;
-    const float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
-    const float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
-    const float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
-    X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
-    Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
-    Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
+    v3d::world_point(s_ref, xf, yf, z, X, Y, Z);
   }
   const bool live1 = gp1 < P && d1 < p.D;
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
-  // x / c for a wave-uniform c with the correctly rounded reciprocal rc: q0 = x rc, one residual correction.  The result
-  // is the correctly rounded quotient (Markstein) for finite normal operands -- the same number as the IEEE division
-  // sequence, in 3 instead of ~10 instructions.
+  // divisions by the wave-uniform image extents go through their correctly rounded reciprocals (v3d::div_uniform)
   const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
-  auto div_uniform = [](float x, float c, float rc) __attribute__((always_inline)) {
-#ifdef V3D_PSV_EXACT_DIV
-    return x / c;
-#else
-    const float q0 = x * rc;
-    return __builtin_fmaf(__builtin_fmaf(-q0, c, x), rc, q0);
-#endif
-  };
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
 
   // gather role: 8 lanes x float4 per pixel
@@ -446,16 +416,8 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       __syncthreads();
     }
     if (e1 < nec) {
-      const float* Pm = s_P[ec % kMaxE + e1];
-      const float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
-      const float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
-      const float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
-      const float zb = fabsf(qz) + 1e-8f;                        // mvsnet.py:200-201
-      const float u = qx / zb, v = qy / zb;
-      const float gx = div_uniform(u, Wm1, rWm1) * 2.f - 1.f;    // mvsnet.py:205-206: u / (W - 1) * 2 - 1
-      const float gy = div_uniform(v, Hm1, rHm1) * 2.f - 1.f;
-      const float ix = ((gx + 1.f) / 2.f) * Wfm1;                // grid_sample, align_corners=True
-      const float iy = ((gy + 1.f) / 2.f) * Hfm1;
+      float ix, iy;
+      v3d::sample_position(s_P[ec % kMaxE + e1], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
       const float x0 = floorf(ix), y0 = floorf(iy);
       const float x1 = x0 + 1.f, y1 = y0 + 1.f;
       const bool vx0 = (x0 >= 0.f) && (x0 <= Wfm1), vx1 = (x1 >= 0.f) && (x1 <= Wfm1);
@@ -567,6 +529,37 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   PHASE_FLUSH;
 }
 
+// Diagnostic twin of the warp kernels' projection (v3d_psv_sample_positions_f32): one thread per (edge, plane, pixel)
+// runs the SAME device functions (v3d::world_point / v3d::sample_position) and stores the un-normalised sample position,
+// so a test can compare the coordinates the kernels use with the reference's, bit for bit.
+__global__ __launch_bounds__(256) void psv_positions_kernel(PsvParams p, float* __restrict__ pos, float* __restrict__ world) {
+  const int P = p.h * p.w;
+  const long long n_vox = (long long)p.D * P;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (i >= n_vox) return;
+  const int d = (int)(i / P), gp = (int)(i % P), gy = gp / p.w, gx = gp % p.w;
+  const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
+  const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
+  const float z = (d == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d * p.z_step);
+  float X, Y, Z;
+  v3d::world_point(p.camp + p.ref_img[r] * kCamStride, xf, yf, z, X, Y, Z);
+  if (world) {
+    world[((size_t)r * 3 + 0) * n_vox + i] = X;
+    world[((size_t)r * 3 + 1) * n_vox + i] = Y;
+    world[((size_t)r * 3 + 2) * n_vox + i] = Z;
+  }
+  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
+  const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+  for (int e = p.edge_ofs[r]; e < p.edge_ofs[r + 1]; ++e) {
+    float ix, iy;
+    v3d::sample_position(p.camp + p.edge_src[e] * kCamStride + 24, X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
+    pos[((size_t)e * n_vox + i) * 2] = ix;
+    pos[((size_t)e * n_vox + i) * 2 + 1] = iy;
+  }
+}
+
 }  // namespace
 
 // shared with backproject.hip
@@ -657,6 +650,36 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
 #undef V3D_PSV
   }
   V3D_CHECK_LAUNCH("psv_variance_kernel");
+  return V3D_OK;
+}
+
+extern "C" int v3d_psv_sample_positions_f32(const float* K, const float* R, const float* t, const int32_t* ref_img,
+                                            const int32_t* edge_ofs, const int32_t* edge_src, int n_img, int n_ref,
+                                            int n_edges, int Hf, int Wf, int H, int W, double depth_start,
+                                            double depth_interval, int D, int h, int w, float* pos, float* world,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(K && R && t && ref_img && edge_ofs && edge_src && pos && workspace, V3D_ERR_BAD_ARG,
+              "v3d_psv_sample_positions_f32: null pointer argument");
+  V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 && D > 0 && h > 0 && w > 0,
+              V3D_ERR_BAD_SHAPE, "v3d_psv_sample_positions_f32: bad shape");
+  V3D_REQUIRE(workspace_bytes >= (size_t)n_img * kCamStride * sizeof(float), V3D_ERR_WORKSPACE_TOO_SMALL,
+              "v3d_psv_sample_positions_f32: workspace too small (n_img * 36 floats)");
+  hipStream_t s = (hipStream_t)stream;
+  float* camp = (float*)workspace;
+  cam_setup_kernel<<<(n_img + 63) / 64, 64, 0, s>>>(K, R, t, camp, n_img);
+  PsvParams p;
+  memset(&p, 0, sizeof(p));
+  p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.camp = camp;
+  p.n_img = n_img; p.n_ref = n_ref; p.Hf = Hf; p.Wf = Wf; p.H = H; p.W = W; p.D = D; p.h = h; p.w = w;
+  p.x_step = w > 1 ? (double)(W - 1) / (double)(w - 1) : 0.0;
+  p.y_step = h > 1 ? (double)(H - 1) / (double)(h - 1) : 0.0;
+  const double depth_end = depth_start + (double)(D - 1) * depth_interval;
+  p.z_start = depth_start;
+  p.z_step = D > 1 ? (depth_end - depth_start) / (double)(D - 1) : 0.0;
+  p.z_end = depth_end;
+  const long long n_vox = (long long)D * h * w;
+  psv_positions_kernel<<<dim3((unsigned)((n_vox + 255) / 256), n_ref), 256, 0, s>>>(p, pos, world);
+  V3D_CHECK_LAUNCH("psv_positions_kernel");
   return V3D_OK;
 }
 

@@ -84,6 +84,40 @@ __device__ __forceinline__ float dot4h_chain(float a0, float b0, float a1, float
   return __fadd_rn(dot3_chain(a0, b0, a1, b1, a2, b2), a3);
 }
 
+// World point of a plane-sweep / back-projected sample: X = R^T (K^-1 [x z, y z, z] - t) (utils.py:98-106,
+// lightningmodel.py:142-144).  cam = per-image block [0..8] K^-1, [9..17] R, [18..20] t.
+__device__ __forceinline__ void world_point(const float* cam, float xf, float yf, float z, float& X, float& Y, float& Z) {
+  const float p0 = __fmul_rn(xf, z), p1 = __fmul_rn(yf, z), p2 = z;
+  const float c0 = __fsub_rn(dot3_chain(cam[0], p0, cam[1], p1, cam[2], p2), cam[18]);
+  const float c1 = __fsub_rn(dot3_chain(cam[3], p0, cam[4], p1, cam[5], p2), cam[19]);
+  const float c2 = __fsub_rn(dot3_chain(cam[6], p0, cam[7], p1, cam[8], p2), cam[20]);
+  X = dot3_chain(cam[9], c0, cam[12], c1, cam[15], c2);
+  Y = dot3_chain(cam[10], c0, cam[13], c1, cam[16], c2);
+  Z = dot3_chain(cam[11], c0, cam[14], c1, cam[17], c2);
+}
+
+// x / c for a wave-uniform c with the correctly rounded reciprocal rc: q0 = x rc, one residual correction.  The result is
+// the correctly rounded quotient (Markstein) for finite normal operands -- the same number as the IEEE division sequence.
+__device__ __forceinline__ float div_uniform(float x, float c, float rc) {
+  const float q0 = __fmul_rn(x, rc);
+  return __builtin_fmaf(__builtin_fmaf(-q0, c, x), rc, q0);
+}
+
+// Source-view sample position of a world point: q = P [X;1]; uv = q_xy / (|q_z| + 1e-8) (mvsnet.py:199-202); normalised
+// with the IMAGE size (:205-206); un-normalised by grid_sample with the FEATURE size (align_corners=True).
+__device__ __forceinline__ void sample_position(const float* Pm, float X, float Y, float Z, float Wm1, float rWm1, float Hm1,
+                                                float rHm1, float Wfm1, float Hfm1, float& ix, float& iy) {
+  const float qx = dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
+  const float qy = dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
+  const float qz = dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
+  const float zb = __fadd_rn(fabsf(qz), 1e-8f);
+  const float u = __fdiv_rn(qx, zb), v = __fdiv_rn(qy, zb);
+  const float gx = __fsub_rn(__fmul_rn(div_uniform(u, Wm1, rWm1), 2.f), 1.f);
+  const float gy = __fsub_rn(__fmul_rn(div_uniform(v, Hm1, rHm1), 2.f), 1.f);
+  ix = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), Wfm1);
+  iy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), Hfm1);
+}
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 

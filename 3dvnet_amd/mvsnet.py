@@ -282,6 +282,31 @@ def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, dep
     return SplitVariance(var, var.shape) if split else var
 
 
+def plane_sweep_sample_positions(rotmats, tvecs, K, ref_src_edges, depth_start, depth_interval, n_planes, img_size,
+                                 feat_size, depth_img_size, device):
+    """Diagnostic (include/v3d.h, v3d_psv_sample_positions_f32): -> (pos [E, D*h*w, 2] = (ix, iy) in feature pixels in
+    CSR edge order, world [n_ref, 3, D*h*w], csr) exactly as the warp kernels compute them."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    csr = edges_to_csr(ref_src_edges.to(dev))
+    _, ref_img, edge_ofs, edge_src = csr
+    n_ref, n_edges = ref_img.shape[0], edge_src.shape[0]
+    h, w = depth_img_size
+    n_vox = n_planes * h * w
+    Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
+    n_img = Kc.shape[0]
+    pos = torch.empty((n_edges, n_vox, 2), dtype=torch.float32, device=dev)
+    world = torch.empty((n_ref, 3, n_vox), dtype=torch.float32, device=dev)
+    ws = torch.empty(n_img * 36 * 4 + 256, dtype=torch.uint8, device=dev)
+    rc = lib.v3d_psv_sample_positions_f32(_lib.ptr(Kc), _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(ref_img), _lib.ptr(edge_ofs),
+                                          _lib.ptr(edge_src), n_img, n_ref, n_edges, int(feat_size[0]), int(feat_size[1]),
+                                          int(img_size[0]), int(img_size[1]), float(depth_start), float(depth_interval),
+                                          int(n_planes), int(h), int(w), _lib.ptr(pos), _lib.ptr(world), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, 'v3d_psv_sample_positions_f32')
+    return pos, world, csr
+
+
 class MVSNet(nn.Module):
     """Reference ``MVSNet(feat_dim=32, img_size=(240, 320))`` (mvsnet.py:166-229).
 

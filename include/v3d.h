@@ -82,6 +82,16 @@ int v3d_psv_variance_f32(const float* feat, const float* K, const float* R, cons
                          double depth_start, double depth_interval, int D, int h, int w,
                          float* var, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostic twin of the projection inside v3d_psv_variance_* (rows A1-A2 + grid_sample's un-normalisation): the sample
+ * position (ix, iy), in feature-map pixels, of every (edge, plane, pixel) -- computed by the same device functions the warp
+ * kernels use, so tests can compare the coordinates with the reference's bit for bit.
+ *   pos   [n_edges, D*h*w, 2] out;  world [n_ref, 3, D*h*w] out, optional (NULL to skip): the plane-sweep points (row A1)
+ *   workspace >= n_img * 36 floats */
+int v3d_psv_sample_positions_f32(const float* K, const float* R, const float* t, const int32_t* ref_img,
+                                 const int32_t* edge_ofs, const int32_t* edge_src, int n_img, int n_ref, int n_edges,
+                                 int Hf, int Wf, int H, int W, double depth_start, double depth_interval, int D, int h,
+                                 int w, float* pos, float* world, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same computation, but `var_split` receives the volume in the regulariser's private input format (no
  * reference counterpart; it only exists to keep the 1.2 GB volume from being re-formatted by the next kernel):
  * every fp32 value x stored as bf16 hi = RNE(x) and bf16 lo = RNE(x - hi), channel-last in 16-byte slots of

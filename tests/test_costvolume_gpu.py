@@ -372,3 +372,30 @@ def test_full_size_properties_cfg2_batch(cuda):
         v_self = mvs.plane_sweep_variance(feat, b.rotmats, b.tvecs, b.K, self_edges.to(cuda), d0, dd, D,
                                           inp['img_size'], inp['plane_size'])
         assert float(v_self.abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('cfg', ['cfg1', 'cfg2'])
+def test_sample_positions_bit_exact_vs_oracle(cfg, cuda):
+    """The coordinates the warp kernels use (world points, row A1; sample positions, row A2 + grid_sample's
+    un-normalisation) against the oracle's torch-CPU arithmetic: BIT-EXACT.  The kernels pin the evaluation orders torch's
+    CPU kernels use (FMA chains in k order for the large batched products, unfused products for the small K [R|t] product,
+    true divisions; scripts/coord_order_probe.py), so nothing but the summation of the variance is left to rounding."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    inp = syn.make_costvolume_inputs(cfg, n_ref=2, seed=5)
+    d0, dd, D = inp['depth']
+    Hf, Wf = inp['feat'].shape[2:]
+    pos, world, csr = mvs.plane_sweep_sample_positions(inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], d0, dd, D,
+                                                       inp['img_size'], (Hf, Wf), inp['plane_size'], cuda)
+    ref_idx, _, edge_ofs, edge_src = csr
+    pts = ocv.plane_sweep_points(d0, dd, D, inp['rotmats'], inp['tvecs'], inp['K'], inp['img_size'], inp['plane_size'])
+    w_ref = pts[ref_idx.cpu()]
+    same_w = (world.cpu() == w_ref).float().mean().item()
+    # the synthetic edge lists are already grouped per reference in order => CSR order == edge order
+    assert torch.equal(edge_src.cpu().long(), inp['edges'][1])
+    grid = ocv.project_to_grid(pts[inp['edges'][0]], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'][1],
+                               inp['img_size'])[:, :, 0]                     # [E, N, 2] normalised
+    ix = ((grid[..., 0] + 1) / 2) * (Wf - 1)            # grid_sample, align_corners=True
+    iy = ((grid[..., 1] + 1) / 2) * (Hf - 1)
+    same_x = (pos[..., 0].cpu() == ix).float().mean().item()
+    same_y = (pos[..., 1].cpu() == iy).float().mean().item()
+    assert same_w == 1.0 and same_x == 1.0 and same_y == 1.0, (same_w, same_x, same_y)
