@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
   const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
   const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
   // hypothesis depth: depth + i * offset with i * offset evaluated in double then rounded (python float)
-  const float dep = p.depth[(size_t)r * P + pix] + (float)((double)(hyp - p.n_half) * p.offset);
+  const float dep = v3d::add_rn(p.depth[(size_t)r * P + pix], (float)((double)(hyp - p.n_half) * p.offset));
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1), Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
   float X = 0.f, Y = 0.f, Z = 0.f;
   float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_q = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -70,30 +71,16 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
       float v;
       // small batched product of torch.bmm: rounded products, sequential additions, no FMA (see psv_variance.hip)
       const float b0 = j < 3 ? Rp[0 * 3 + j] : tp[0], b1 = j < 3 ? Rp[1 * 3 + j] : tp[1], b2 = j < 3 ? Rp[2 * 3 + j] : tp[2];
-      v = __fadd_rn(__fadd_rn(__fmul_rn(Kp[i * 3 + 0], b0), __fmul_rn(Kp[i * 3 + 1], b1)), __fmul_rn(Kp[i * 3 + 2], b2));
+      v = v3d::add_rn(v3d::add_rn(v3d::mul_rn(Kp[i * 3 + 0], b0), v3d::mul_rn(Kp[i * 3 + 1], b1)), v3d::mul_rn(Kp[i * 3 + 2], b2));
       s_P[e][ij] = v;
       if (ij == 0) s_base[e] = src * p.Hf * p.Wf;
     }
     __syncthreads();
-    if (ec == 0) {   // world point X = R^T (K^-1 (pix * depth) - t)   (lightningmodel.py:142-144,202-204)
-      float p0 = xf * dep, p1 = yf * dep, p2 = dep;
-      float c0 = __fsub_rn(v3d::dot3_chain(s_ref[0], p0, s_ref[1], p1, s_ref[2], p2), s_ref[18]);
-      float c1 = __fsub_rn(v3d::dot3_chain(s_ref[3], p0, s_ref[4], p1, s_ref[5], p2), s_ref[19]);
-      float c2 = __fsub_rn(v3d::dot3_chain(s_ref[6], p0, s_ref[7], p1, s_ref[8], p2), s_ref[20]);
-      X = v3d::dot3_chain(s_ref[9], c0, s_ref[12], c1, s_ref[15], c2);
-      Y = v3d::dot3_chain(s_ref[10], c0, s_ref[13], c1, s_ref[16], c2);
-      Z = v3d::dot3_chain(s_ref[11], c0, s_ref[14], c1, s_ref[17], c2);
-    }
+    if (ec == 0) v3d::world_point(s_ref, xf, yf, dep, X, Y, Z);   // (lightningmodel.py:142-144,202-204)
     if (!active) continue;
     for (int e = 0; e < nec; ++e) {
-      const float* Pm = s_P[e];
-      float qx = v3d::dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
-      float qy = v3d::dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
-      float qz = v3d::dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
-      float zb = fabsf(qz) + 1e-8f;
-      float u = qx / zb, v = qy / zb;
-      float gxn = (u / Wm1) * 2.f - 1.f, gyn = (v / Hm1) * 2.f - 1.f;
-      float ix = ((gxn + 1.f) / 2.f) * Wfm1, iy = ((gyn + 1.f) / 2.f) * Hfm1;
+      float ix, iy;
+      v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ix > -1.f && ix < Wfm1 + 1.f && iy > -1.f && iy < Hfm1 + 1.f) {
         const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
@@ -106,13 +93,18 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
         const float4 v01 = *reinterpret_cast<const float4*>(fb + (yi0 * p.Wf + xi1) * C);
         const float4 v10 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi0) * C);
         const float4 v11 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi1) * C);
-        s.x = v00.x * w00; s.y = v00.y * w00; s.z = v00.z * w00; s.w = v00.w * w00;
-        s.x += v01.x * w01; s.y += v01.y * w01; s.z += v01.z * w01; s.w += v01.w * w01;
-        s.x += v10.x * w10; s.y += v10.y * w10; s.z += v10.z * w10; s.w += v10.w * w10;
-        s.x += v11.x * w11; s.y += v11.y * w11; s.z += v11.z * w11; s.w += v11.w * w11;
+        // F.grid_sample's tap order as an FMA chain: ((nw + ne) + sw) + se (same sequence as the warp kernels)
+        s.x = v3d::mul_rn(v00.x, w00); s.y = v3d::mul_rn(v00.y, w00); s.z = v3d::mul_rn(v00.z, w00); s.w = v3d::mul_rn(v00.w, w00);
+        s.x = __builtin_fmaf(v01.x, w01, s.x); s.y = __builtin_fmaf(v01.y, w01, s.y);
+        s.z = __builtin_fmaf(v01.z, w01, s.z); s.w = __builtin_fmaf(v01.w, w01, s.w);
+        s.x = __builtin_fmaf(v10.x, w10, s.x); s.y = __builtin_fmaf(v10.y, w10, s.y);
+        s.z = __builtin_fmaf(v10.z, w10, s.z); s.w = __builtin_fmaf(v10.w, w10, s.w);
+        s.x = __builtin_fmaf(v11.x, w11, s.x); s.y = __builtin_fmaf(v11.y, w11, s.y);
+        s.z = __builtin_fmaf(v11.z, w11, s.z); s.w = __builtin_fmaf(v11.w, w11, s.w);
       }
       acc_s.x += s.x; acc_s.y += s.y; acc_s.z += s.z; acc_s.w += s.w;
-      acc_q.x += s.x * s.x; acc_q.y += s.y * s.y; acc_q.z += s.z * s.z; acc_q.w += s.w * s.w;
+      acc_q.x = __builtin_fmaf(s.x, s.x, acc_q.x); acc_q.y = __builtin_fmaf(s.y, s.y, acc_q.y);
+      acc_q.z = __builtin_fmaf(s.z, s.z, acc_q.z); acc_q.w = __builtin_fmaf(s.w, s.w, acc_q.w);
     }
   }
   if (!active) return;
@@ -120,10 +112,10 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
   if (cg == 0) { p.pts[row * 3] = X; p.pts[row * 3 + 1] = Y; p.pts[row * 3 + 2] = Z; }
   const float cnt = (float)max(ne, 1);
   float4 o;
-  { float a = acc_s.x / cnt, q = acc_q.x / cnt; o.x = __fsub_rn(q, __fmul_rn(a, a)); }
-  { float a = acc_s.y / cnt, q = acc_q.y / cnt; o.y = __fsub_rn(q, __fmul_rn(a, a)); }
-  { float a = acc_s.z / cnt, q = acc_q.z / cnt; o.z = __fsub_rn(q, __fmul_rn(a, a)); }
-  { float a = acc_s.w / cnt, q = acc_q.w / cnt; o.w = __fsub_rn(q, __fmul_rn(a, a)); }
+  { float a = acc_s.x / cnt, q = acc_q.x / cnt; o.x = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = acc_s.y / cnt, q = acc_q.y / cnt; o.y = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = acc_s.z / cnt, q = acc_q.z / cnt; o.z = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = acc_s.w / cnt, q = acc_q.w / cnt; o.w = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
   *reinterpret_cast<float4*>(p.var + row * C + cg * 4) = o;
 }
 

@@ -123,8 +123,8 @@ __global__ void cam_setup_kernel(const float* __restrict__ K, const float* __res
   for (int r = 0; r < 3; ++r)
     for (int j = 0; j < 4; ++j) {
       const float b0 = j < 3 ? Rp[0 * 3 + j] : tp[0], b1 = j < 3 ? Rp[1 * 3 + j] : tp[1], b2 = j < 3 ? Rp[2 * 3 + j] : tp[2];
-      o[24 + r * 4 + j] = __fadd_rn(__fadd_rn(__fmul_rn(Kp[r * 3 + 0], b0), __fmul_rn(Kp[r * 3 + 1], b1)),
-                                    __fmul_rn(Kp[r * 3 + 2], b2));
+      o[24 + r * 4 + j] = v3d::add_rn(v3d::add_rn(v3d::mul_rn(Kp[r * 3 + 0], b0), v3d::mul_rn(Kp[r * 3 + 1], b1)),
+                                    v3d::mul_rn(Kp[r * 3 + 2], b2));
     }
 }
 
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
         for (int k = 0; k < 4; ++k) {
           const float avg = acc_s[a][k] / cnt;
           const float avg_sq = acc_q[a][k] / cnt;
-          const float v = __fsub_rn(avg_sq, __fmul_rn(avg, avg));            // mvsnet.py:216
+          const float v = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));            // mvsnet.py:216
           h[k] = psv_bf16_rne(v);
           l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
         }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
         for (int k = 0; k < 4; ++k) {
           float avg = acc_s[a][k] / cnt;
           float avg_sq = acc_q[a][k] / cnt;
-          s_out[cg * 4 + k][px] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
+          s_out[cg * 4 + k][px] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
         }
       }
       __syncthreads();
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       for (int k = 0; k < 4; ++k) {
         const float avg = mean(acc_s[pl][k]);
         const float avg_sq = mean(acc_q[pl][k]);
-        const float v = __fsub_rn(avg_sq, __fmul_rn(avg, avg));            // mvsnet.py:216
+        const float v = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));            // mvsnet.py:216
         h[k] = psv_bf16_rne(v);
         l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
       }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       for (int k = 0; k < 4; ++k) {
         const float avg = mean(acc_s[pl][k]);
         const float avg_sq = mean(acc_q[pl][k]);
-        s_out[pl][cg * 4 + k][gpx] = __fsub_rn(avg_sq, __fmul_rn(avg, avg));   // mvsnet.py:216
+        s_out[pl][cg * 4 + k][gpx] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
       }
     __syncthreads();
     for (int i = lane; i < kDB * C * kRPix; i += 64) {

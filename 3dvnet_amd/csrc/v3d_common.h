@@ -71,26 +71,42 @@ __device__ __forceinline__ int xcd_contiguous_block() {
   return x * per + (x < rem ? x : rem) + i;
 }
 
+// Single fp32 operations the compiler must not fuse with their neighbours.  HIP's __fmul_rn / __fadd_rn are plain operators
+// (hipcc's default -ffp-contract=fast-honor-pragmas contracts them into FMAs like any other a * b + c), so the rounding
+// points of the reference's arithmetic are pinned with a contraction-free scope instead.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // Pinned evaluation orders of the camera arithmetic (scripts/coord_order_probe.py): torch.bmm evaluates the large batched
 // products K^-1 p, R^T c and P [X;1] as FMA chains in k order whose first term is a plain product; hipcc's default
 // -ffp-contract=fast would pick its own mul/add pairs to fuse (it did: one row of P [X;1] came out as
 // fma(a0,b0, rnd(a1 b1)) + rnd(a2 b2)), so the chains are spelled out.  With these orders the sample coordinates and the
 // bilinear taps reproduce the reference's CPU arithmetic bit for bit.
 __device__ __forceinline__ float dot3_chain(float a0, float b0, float a1, float b1, float a2, float b2) {
-  return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, __fmul_rn(a0, b0)));
+  return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, mul_rn(a0, b0)));
 }
 // [a0 a1 a2 a3] . [b0 b1 b2 1]: the homogeneous term is fma(a3, 1, acc) = a rounded addition
 __device__ __forceinline__ float dot4h_chain(float a0, float b0, float a1, float b1, float a2, float b2, float a3) {
-  return __fadd_rn(dot3_chain(a0, b0, a1, b1, a2, b2), a3);
+  return add_rn(dot3_chain(a0, b0, a1, b1, a2, b2), a3);
 }
 
 // World point of a plane-sweep / back-projected sample: X = R^T (K^-1 [x z, y z, z] - t) (utils.py:98-106,
 // lightningmodel.py:142-144).  cam = per-image block [0..8] K^-1, [9..17] R, [18..20] t.
 __device__ __forceinline__ void world_point(const float* cam, float xf, float yf, float z, float& X, float& Y, float& Z) {
-  const float p0 = __fmul_rn(xf, z), p1 = __fmul_rn(yf, z), p2 = z;
-  const float c0 = __fsub_rn(dot3_chain(cam[0], p0, cam[1], p1, cam[2], p2), cam[18]);
-  const float c1 = __fsub_rn(dot3_chain(cam[3], p0, cam[4], p1, cam[5], p2), cam[19]);
-  const float c2 = __fsub_rn(dot3_chain(cam[6], p0, cam[7], p1, cam[8], p2), cam[20]);
+  const float p0 = mul_rn(xf, z), p1 = mul_rn(yf, z), p2 = z;
+  const float c0 = sub_rn(dot3_chain(cam[0], p0, cam[1], p1, cam[2], p2), cam[18]);
+  const float c1 = sub_rn(dot3_chain(cam[3], p0, cam[4], p1, cam[5], p2), cam[19]);
+  const float c2 = sub_rn(dot3_chain(cam[6], p0, cam[7], p1, cam[8], p2), cam[20]);
   X = dot3_chain(cam[9], c0, cam[12], c1, cam[15], c2);
   Y = dot3_chain(cam[10], c0, cam[13], c1, cam[16], c2);
   Z = dot3_chain(cam[11], c0, cam[14], c1, cam[17], c2);
@@ -99,7 +115,7 @@ __device__ __forceinline__ void world_point(const float* cam, float xf, float yf
 // x / c for a wave-uniform c with the correctly rounded reciprocal rc: q0 = x rc, one residual correction.  The result is
 // the correctly rounded quotient (Markstein) for finite normal operands -- the same number as the IEEE division sequence.
 __device__ __forceinline__ float div_uniform(float x, float c, float rc) {
-  const float q0 = __fmul_rn(x, rc);
+  const float q0 = mul_rn(x, rc);
   return __builtin_fmaf(__builtin_fmaf(-q0, c, x), rc, q0);
 }
 
@@ -110,12 +126,12 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
   const float qx = dot4h_chain(Pm[0], X, Pm[1], Y, Pm[2], Z, Pm[3]);
   const float qy = dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
   const float qz = dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
-  const float zb = __fadd_rn(fabsf(qz), 1e-8f);
+  const float zb = add_rn(fabsf(qz), 1e-8f);
   const float u = __fdiv_rn(qx, zb), v = __fdiv_rn(qy, zb);
-  const float gx = __fsub_rn(__fmul_rn(div_uniform(u, Wm1, rWm1), 2.f), 1.f);
-  const float gy = __fsub_rn(__fmul_rn(div_uniform(v, Hm1, rHm1), 2.f), 1.f);
-  ix = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), Wfm1);
-  iy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), Hfm1);
+  const float gx = sub_rn(mul_rn(div_uniform(u, Wm1, rWm1), 2.f), 1.f);
+  const float gy = sub_rn(mul_rn(div_uniform(v, Hm1, rHm1), 2.f), 1.f);
+  ix = mul_rn(mul_rn(add_rn(gx, 1.f), 0.5f), Wfm1);
+  iy = mul_rn(mul_rn(add_rn(gy, 1.f), 0.5f), Hfm1);
 }
 
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void voxel_decode_kernel(const unsigned long l
     if (live) {
       idx3d[i * 3 + d] = c[d];
       // idx * edge_len + bbox_min + edge_len / 2 with one rounding per operation, as the tensor ops (:58)
-      anchor_pts[i * 3 + d] = __fadd_rn(__fadd_rn(__fmul_rn((float)c[d], edge), meta->bmin[d]), half_edge);
+      anchor_pts[i * 3 + d] = v3d::add_rn(v3d::add_rn(v3d::mul_rn((float)c[d], edge), meta->bmin[d]), half_edge);
     }
     if (uniform) {
       int m = live ? c[d] : 0x7fffffff;

@@ -123,11 +123,18 @@ def soft_argmin_depth(x_reg, depth_start, depth_interval, n_planes):
 
 
 def mvsnet_depth(feat, rotmats, tvecs, K, edges, sd, depth_start, depth_interval, n_planes,
-                 img_size, plane_size):
+                 img_size, plane_size, pinned=False):
     """Rows A1-A6 end to end from quarter features (mvsnet.py:186-227).
-    Returns (depth [n_ref,h,w], var [n_ref,C,D,h,w], x_reg [n_ref,D,h,w])."""
-    var = warp_variance(feat, rotmats, tvecs, K, edges, depth_start, depth_interval, n_planes,
-                        img_size, plane_size)
+    Returns (depth [n_ref,h,w], var [n_ref,C,D,h,w], x_reg [n_ref,D,h,w]).
+    pinned=True: the variance volume from oracle/pinned.py -- the evaluation orders of the reference run that produced
+    the goldens, independent of this host's BLAS (torch.bmm's last bits are not)."""
+    if pinned:
+        from . import pinned as pin
+        var = pin.warp_variance(feat, rotmats, tvecs, K, edges, depth_start, depth_interval, n_planes, img_size,
+                                plane_size)
+    else:
+        var = warp_variance(feat, rotmats, tvecs, K, edges, depth_start, depth_interval, n_planes,
+                            img_size, plane_size)
     x_reg = costregnet(var, sd).squeeze(1)
     depth, _ = soft_argmin_depth(x_reg, depth_start, depth_interval, n_planes)
     return depth, var, x_reg

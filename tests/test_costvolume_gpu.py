@@ -1,13 +1,16 @@
 """GPU parity tests, rows A1-A6: the HIP path (through the C ABI) against the golden vectors
 captured from the reference and against the oracle on the same seeded inputs.
 
-Tolerances (fp32 path, BASELINE.json north_star: depth within 1e-4 relative):
-  variance volume  : 5e-5 absolute.  Values are O(0.1) on U[0,1) features whose gradient is O(1)
-                     per feature pixel; sample coordinates reach ~160 px where one fp32 ulp is
-                     1.5e-5 px, so two correct fp32 evaluation orders of the projection differ by
-                     a few 1e-5 (observed max 2.4e-5 on 4M voxels)
-  regularised vol. : 2e-4 * max|x_reg|
-  depth            : 1e-4 relative
+Tolerances (BASELINE.json north_star: depth within 1e-4 relative):
+  variance volume  : 5e-7 absolute against the reference-generated goldens and against oracle/pinned.py.  The warp
+                     kernels implement the evaluation orders of the reference run that produced the goldens (sample
+                     coordinates bit-exact, test_sample_positions_bit_exact_vs_pinned_oracle), so only the fused square
+                     in the sum of squares is left: measured 6e-8 (cfg2), 1.2e-7 (cfg1).
+                     Against oracle/costvolume.py run on THIS host the bound is 5e-5: torch.bmm's last bits depend on
+                     the host BLAS (MKL on the GPU box's EPYC host does not use FMA, the build container's does), and one
+                     ulp at ~160 px is 1.5e-5 px.
+  regularised vol. : 5e-5 * max|x_reg| for split-bf16 operands (measured 1.1e-5), 1e-5 for exact fp32 (measured 1.3e-6)
+  depth            : 1e-4 relative (measured 2.2e-5 split-bf16, 2.3e-6 exact fp32 on cfg2)
 """
 import numpy as np
 import pytest
@@ -19,7 +22,9 @@ from oracle import costvolume as ocv
 
 pytestmark = pytest.mark.gpu
 
-VAR_ATOL = 5e-5
+VAR_ATOL = 5e-7          # vs goldens / the pinned oracle
+VAR_ATOL_HOST = 5e-5     # vs the torch oracle on this host (BLAS-dependent last bits)
+REG_RTOL = 5e-5          # of max|x_reg|, split-bf16 operands
 DEPTH_RTOL = 1e-4
 
 
@@ -84,7 +89,7 @@ def test_hip_matches_reference_golden_tiny(name, cuda):
                                t(g['edges']), g['depth_cfg'], plane_size, cuda)
     np.testing.assert_allclose(var.numpy(), g['var'], rtol=0, atol=VAR_ATOL)
     scale = float(np.abs(g['reg']).max())
-    np.testing.assert_allclose(reg.numpy(), g['reg'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(reg.numpy(), g['reg'], rtol=0, atol=REG_RTOL * scale)
     np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=DEPTH_RTOL, atol=0)
 
 
@@ -105,7 +110,7 @@ def test_hip_matches_reference_golden_cfg(name, cfg, cuda):
     np.testing.assert_allclose(vs.numpy(), g['var_sub'], rtol=0, atol=VAR_ATOL)
     assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-4 * abs(float(g['var_sum']))
     scale = float(np.abs(g['reg_sub']).max())
-    np.testing.assert_allclose(rs.numpy(), g['reg_sub'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(rs.numpy(), g['reg_sub'], rtol=0, atol=REG_RTOL * scale)
     np.testing.assert_allclose(depth.numpy(), g['depth'], rtol=DEPTH_RTOL, atol=0)
     # the gate is not vacuous: the sharpened weights give a wide depth range
     assert g['depth'].max() - g['depth'].min() > 1.0
@@ -127,7 +132,7 @@ def test_hip_matches_reference_golden_cfg5(cuda):
     np.testing.assert_allclose(var[:, ::4, ::7, ::11, ::13].numpy(), g['var_sub'], rtol=0, atol=VAR_ATOL)
     assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-4 * abs(float(g['var_sum']))
     scale = float(np.abs(g['reg_sub']).max())
-    np.testing.assert_allclose(reg[:, ::7, ::11, ::13].numpy(), g['reg_sub'], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(reg[:, ::7, ::11, ::13].numpy(), g['reg_sub'], rtol=0, atol=REG_RTOL * scale)
     np.testing.assert_allclose(depth[:, ::3, ::3].numpy(), g['depth_sub'], rtol=DEPTH_RTOL, atol=0)
     assert abs(float(depth.double().sum()) - float(g['depth_sum'])) < 2e-5 * abs(float(g['depth_sum']))
     assert g['depth_sub'].max() - g['depth_sub'].min() > 1.0
@@ -166,12 +171,12 @@ def test_hip_matches_oracle_multi_ref(cuda):
     with torch.no_grad():
         depth_o, var_o, reg_o = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
                                                  inp['edges'], sd, d0, dd, D, inp['img_size'],
-                                                 inp['plane_size'])
+                                                 inp['plane_size'], pinned=True)
     net = _net(sd, cuda, inp['img_size'])
     depth, var, reg = _run_hip(net, inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'],
                                inp['edges'], inp['depth'], inp['plane_size'], cuda)
     np.testing.assert_allclose(var.numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
-    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=2e-4 * float(reg_o.abs().max()))
+    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=REG_RTOL * float(reg_o.abs().max()))
     np.testing.assert_allclose(depth.numpy(), depth_o.numpy(), rtol=DEPTH_RTOL, atol=0)
 
 
@@ -190,11 +195,11 @@ def test_fused_path_partial_tiles_and_ragged_edges(cuda):
     sd = syn.costregnet_weights(seed=5, sharpen=200.0)
     d0, dd = 0.5, 0.1
     with torch.no_grad():
-        depth_o, var_o, reg_o = ocv.mvsnet_depth(feat, R, tv, K, edges, sd, d0, dd, D, img_size, plane_size)
+        depth_o, var_o, reg_o = ocv.mvsnet_depth(feat, R, tv, K, edges, sd, d0, dd, D, img_size, plane_size, pinned=True)
     net = _net(sd, cuda, img_size)
     depth, var, reg = _run_hip(net, feat, R, tv, K, edges, (d0, dd, D), plane_size, cuda)
     np.testing.assert_allclose(var.numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
-    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=2e-4 * float(reg_o.abs().max()))
+    np.testing.assert_allclose(reg.numpy(), reg_o.numpy(), rtol=0, atol=REG_RTOL * float(reg_o.abs().max()))
     np.testing.assert_allclose(depth.numpy(), depth_o.numpy(), rtol=DEPTH_RTOL, atol=0)
     assert float(depth_o.max() - depth_o.min()) > 0.5
 
@@ -210,7 +215,8 @@ def test_psv_ragged_edges_and_odd_grid(cuda):
     srcs = [4] + [6, 7, 8] + list(range(0, 10))
     perm = torch.randperm(len(refs), generator=torch.Generator().manual_seed(0))
     edges = torch.tensor([refs, srcs])[:, perm]
-    var_o = ocv.warp_variance(feat, R, tv, K, edges, 0.5, 0.3, 6, img_size, plane_size)
+    from oracle import pinned
+    var_o = pinned.warp_variance(feat, R, tv, K, edges, 0.5, 0.3, 6, img_size, plane_size)
     var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 6, img_size,
                                    plane_size)
     torch.cuda.synchronize()
@@ -278,7 +284,8 @@ def test_psv_feat_dim_16(cuda):
     e, n_img = syn.make_edges(2, 1, 1)
     R, tv, K = syn.make_cameras(n_img, img_size, seed=9)
     feat = syn.make_features(n_img, 16, 16, 20, seed=9)
-    var_o = ocv.warp_variance(feat, R, tv, K, e, 0.5, 0.25, 8, img_size, plane_size)
+    from oracle import pinned
+    var_o = pinned.warp_variance(feat, R, tv, K, e, 0.5, 0.25, 8, img_size, plane_size)
     var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, e.to(cuda), 0.5, 0.25, 8, img_size, plane_size)
     np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
 
@@ -375,11 +382,12 @@ def test_full_size_properties_cfg2_batch(cuda):
 
 
 @pytest.mark.parametrize('cfg', ['cfg1', 'cfg2'])
-def test_sample_positions_bit_exact_vs_oracle(cfg, cuda):
+def test_sample_positions_bit_exact_vs_pinned_oracle(cfg, cuda):
     """The coordinates the warp kernels use (world points, row A1; sample positions, row A2 + grid_sample's
-    un-normalisation) against the oracle's torch-CPU arithmetic: BIT-EXACT.  The kernels pin the evaluation orders torch's
-    CPU kernels use (FMA chains in k order for the large batched products, unfused products for the small K [R|t] product,
-    true divisions; scripts/coord_order_probe.py), so nothing but the summation of the variance is left to rounding."""
+    un-normalisation) against oracle/pinned.py: BIT-EXACT.  oracle/pinned.py spells out the evaluation orders of the
+    reference's torch-CPU run that produced the goldens (it reproduces the golden variance volumes bit for bit,
+    tests/test_oracle_golden.py) and is host-independent, unlike torch.bmm itself."""
+    from oracle import pinned
     syn, mvs = v3d('synthetic'), v3d('mvsnet')
     inp = syn.make_costvolume_inputs(cfg, n_ref=2, seed=5)
     d0, dd, D = inp['depth']
@@ -387,15 +395,15 @@ def test_sample_positions_bit_exact_vs_oracle(cfg, cuda):
     pos, world, csr = mvs.plane_sweep_sample_positions(inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], d0, dd, D,
                                                        inp['img_size'], (Hf, Wf), inp['plane_size'], cuda)
     ref_idx, _, edge_ofs, edge_src = csr
-    pts = ocv.plane_sweep_points(d0, dd, D, inp['rotmats'], inp['tvecs'], inp['K'], inp['img_size'], inp['plane_size'])
-    w_ref = pts[ref_idx.cpu()]
-    same_w = (world.cpu() == w_ref).float().mean().item()
-    # the synthetic edge lists are already grouped per reference in order => CSR order == edge order
-    assert torch.equal(edge_src.cpu().long(), inp['edges'][1])
-    grid = ocv.project_to_grid(pts[inp['edges'][0]], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'][1],
-                               inp['img_size'])[:, :, 0]                     # [E, N, 2] normalised
-    ix = ((grid[..., 0] + 1) / 2) * (Wf - 1)            # grid_sample, align_corners=True
-    iy = ((grid[..., 1] + 1) / 2) * (Hf - 1)
-    same_x = (pos[..., 0].cpu() == ix).float().mean().item()
-    same_y = (pos[..., 1].cpu() == iy).float().mean().item()
-    assert same_w == 1.0 and same_x == 1.0 and same_y == 1.0, (same_w, same_x, same_y)
+    assert torch.equal(edge_src.cpu().long(), inp['edges'][1])       # grouped per reference already: CSR == edge order
+    K, R, t = inp['K'], inp['rotmats'], inp['tvecs']
+    _, P = pinned.camera_blocks(K, R, t)
+    pos, world = pos.cpu().numpy(), world.cpu().numpy()
+    for r, ref in enumerate(ref_idx.cpu().tolist()):
+        X = pinned.world_points(K, R, t, ref, d0, dd, D, inp['img_size'], inp['plane_size'])
+        Xn = X.numpy()
+        assert np.array_equal(world[r], Xn), 'world points of reference %d: %.4f bit-equal' % (ref, np.mean(world[r] == Xn))
+        for e in range(int(edge_ofs[r]), int(edge_ofs[r + 1])):
+            ix, iy = (a.numpy() for a in pinned.sample_positions(X, P[int(edge_src[e])], inp['img_size'], (Hf, Wf)))
+            assert np.array_equal(pos[e, :, 0], ix) and np.array_equal(pos[e, :, 1], iy), \
+                'edge %d: ix %.4f iy %.4f bit-equal' % (e, np.mean(pos[e, :, 0] == ix), np.mean(pos[e, :, 1] == iy))

@@ -78,3 +78,34 @@ def test_oracle_matches_reference_cfg5():
     np.testing.assert_allclose(var[:, ::4, ::7, ::11, ::13].numpy(), g['var_sub'], rtol=0, atol=1e-6)
     np.testing.assert_allclose(reg[:, ::7, ::11, ::13].numpy(), g['reg_sub'], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(depth[:, ::3, ::3].numpy(), g['depth_sub'], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize('name', ['A_tiny_flat', 'A_tiny_rotated'])
+def test_pinned_oracle_reproduces_golden_variance_bitwise_tiny(name):
+    """oracle/pinned.py (host-independent evaluation orders) against the reference-generated goldens: the variance
+    volume BIT FOR BIT -- including the rotated fixture with points behind a camera and out-of-image samples."""
+    from oracle import pinned
+    g = load_golden(name)
+    d0, dd, D = g['depth_cfg']
+    var = pinned.warp_variance(t(g['feat']), t(g['rotmats']), t(g['tvecs']), t(g['K']), t(g['edges']), float(d0),
+                               float(dd), int(D), tuple(int(v) for v in g['img_size']),
+                               tuple(int(v) for v in g['plane_size']))
+    assert np.array_equal(var.numpy(), g['var'])
+    fused = pinned.warp_variance(t(g['feat']), t(g['rotmats']), t(g['tvecs']), t(g['K']), t(g['edges']), float(d0),
+                                 float(dd), int(D), tuple(int(v) for v in g['img_size']),
+                                 tuple(int(v) for v in g['plane_size']), fused_square=True)
+    np.testing.assert_allclose(fused.numpy(), g['var'], rtol=0, atol=3e-7)        # what the HIP kernels compute
+
+
+@pytest.mark.parametrize('name,cfg,sub', [
+    ('A_cfg1', 'cfg1', (slice(None), slice(None, None, 4), slice(None, None, 3), slice(None, None, 5), slice(None, None, 7))),
+    ('A_cfg2', 'cfg2', (slice(None), slice(None, None, 4), slice(None, None, 5), slice(None, None, 7), slice(None, None, 7)))])
+def test_pinned_oracle_reproduces_golden_variance_bitwise_cfg(name, cfg, sub):
+    from oracle import pinned
+    g = load_golden(name)
+    inp = v3d('synthetic').make_costvolume_inputs(cfg, n_ref=1)
+    d0, dd, D = inp['depth']
+    var = pinned.warp_variance(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], d0, dd, D,
+                               inp['img_size'], inp['plane_size'])
+    assert np.array_equal(var.numpy()[sub], g['var_sub'])
+    assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-6
