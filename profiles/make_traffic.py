@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""Derive profiles/rNN_traffic.json (HBM-side FETCH_SIZE + WRITE_SIZE per launch of the main kernels) from
-the two PMC CSVs written by scripts/profile_bench.sh.  bench.py reads the JSON for `roofline.traffic`.
+"""Derive profiles/rNN_traffic_<cfg>.json (HBM-side bytes per launch of the main kernels) from the two PMC CSVs written by
+scripts/profile_bench.sh.  bench.py reads the JSON for `roofline.traffic`.
 
     python profiles/make_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <refs_per_step> <out.json>
+
+FETCH_SIZE correction (MI355X_MICROARCH.md §HBM): on gfx950 rocprofv3's FETCH_SIZE reports exactly half of the bytes of a
+wide coalesced read (16 B per lane; the counter tallies 128-byte requests as 64 B).  EVERY kernel listed here reads its
+bulk data with 16-byte-per-lane loads (the warp kernel gathers 128-byte cells as 8 lanes x 16 B, conv0 / convg / deconvg /
+conv9+prob copy 16-byte slots, soft_argmin is the exception with 4-byte loads and negligible traffic), so the x2 is applied
+uniformly: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Cross-check from the data itself: conv1's raw FETCH_SIZE is
+0.30 GB per launch while it must read conv0's whole 0.62 GB output exactly once.  WRITE_SIZE needs no correction
+(the warp kernel's WRITE_SIZE equals its output volume to the byte).
 """
 import csv
 import json
@@ -12,7 +20,9 @@ import sys
 NAMES = [('psv_variance_reuse_kernel', 'psv_variance'), ('psv_variance_kernel', 'psv_variance'),
          ('conv0_bf16x2_kernel', 'costreg_conv0'), ('conv9_prob_kernel', 'costreg_conv9_prob'),
          ('convg_bf16x2_kernel<CG<8, 16', 'costreg_conv1'), ('convg_bf16x2_kernel<CG<16, 16', 'costreg_conv2'),
+         ('convg_bf16x2_kernel<CG<16, 32', 'costreg_conv3'), ('convg_bf16x2_kernel<CG<32, 32', 'costreg_conv4'),
          ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin')]
+FETCH_CORRECTION = 2.0
 
 
 def read(path):
@@ -21,14 +31,21 @@ def read(path):
         for sub, name in NAMES:
             if sub in row['kernel']:
                 out[name] = float(row['avg_value_per_dispatch'])
+                break
     return out
 
 
 def main():
     fetch, write = read(sys.argv[1]), read(sys.argv[2])
-    kernels = {k: {'fetch_kb': fetch.get(k, 0.0), 'write_kb': write.get(k, 0.0)} for k in fetch.keys() | write.keys()}
+    kernels = {}
+    for k in sorted(fetch.keys() | write.keys()):
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        kernels[k] = {'fetch_kb_raw': f, 'write_kb': w, 'fetch_bytes_corrected': FETCH_CORRECTION * f * 1024.0,
+                      'write_bytes': w * 1024.0, 'hbm_bytes': (FETCH_CORRECTION * f + w) * 1024.0}
     json.dump({'refs_per_step_per_gpu': int(sys.argv[3]),
-               'unit': 'KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, gfx950, uncorrected; see profiles/README.md)',
+               'unit': 'per launch; fetch_kb_raw / write_kb = rocprofv3 FETCH_SIZE / WRITE_SIZE (KB); hbm_bytes = '
+                       '(2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction for 16-byte-per-lane reads applied '
+                       'to every kernel (profiles/README.md)',
                'kernels': kernels}, open(sys.argv[4], 'w'), indent=1)
 
 
