@@ -128,10 +128,36 @@ __global__ void cam_setup_kernel(const float* __restrict__ K, const float* __res
     }
 }
 
-struct TapInfo {      // one (pixel, edge) pair, 32 bytes
-  float w00, w01, w10, w11;   // nw, ne, sw, se weights (0 where the tap is out of range)
-  int o00, o01, o10, o11;     // element offsets of the 4 taps into featT (already * C); -1 = skip all
+struct TapInfo {      // one (pixel, plane, edge) sample, 32 bytes
+  float w00, w01, w10, w11;      // nw, ne, sw, se weights (0 where the tap is out of range: grid_sample padding_mode='zeros')
+  unsigned b00, b01, b10, b11;   // byte offsets of the 4 cells (channel 0) into featT, clamped into the source image
 };
+
+// Bilinear taps of one sample (F.grid_sample, align_corners=True, zeros padding; mvsnet.py:209-211).  Weights are the
+// reference's products (x1 - ix)(y1 - iy), ... with the factor of an out-of-range column / row replaced by 0; validity is
+// tested on the converted integers (one unsigned compare per column / row; float -> int saturates, so far-away samples stay
+// invalid); the cell coordinates are clamped into the image so that every tap has a loadable address -- a tap with weight
+// 0 contributes exactly 0, and a sample that misses the image entirely needs no special case in the gather loop.
+// CB = bytes per cell (4 C).
+template <unsigned CB>
+__device__ __forceinline__ TapInfo make_taps(float ix, float iy, int Wf, int Hf, int first_cell, bool live) {
+  const float x0 = floorf(ix), y0 = floorf(iy);
+  const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+  const int xi0 = (int)x0, yi0 = (int)y0, xi1 = xi0 + 1, yi1 = yi0 + 1;
+  const bool vx0 = live && (unsigned)xi0 < (unsigned)Wf, vx1 = live && (unsigned)xi1 < (unsigned)Wf;
+  const bool vy0 = (unsigned)yi0 < (unsigned)Hf, vy1 = (unsigned)yi1 < (unsigned)Hf;
+  const float wx0 = vx0 ? x1 - ix : 0.f, wx1 = vx1 ? ix - x0 : 0.f;
+  const float wy0 = vy0 ? y1 - iy : 0.f, wy1 = vy1 ? iy - y0 : 0.f;
+  TapInfo ti;
+  ti.w00 = v3d::mul_rn(wx0, wy0); ti.w01 = v3d::mul_rn(wx1, wy0);
+  ti.w10 = v3d::mul_rn(wx0, wy1); ti.w11 = v3d::mul_rn(wx1, wy1);
+  const int cx0 = min(max(xi0, 0), Wf - 1), cx1 = min(max(xi1, 0), Wf - 1);
+  const int cy0 = min(max(yi0, 0), Hf - 1), cy1 = min(max(yi1, 0), Hf - 1);
+  const int row0 = first_cell + cy0 * Wf, row1 = first_cell + cy1 * Wf;
+  ti.b00 = (unsigned)(row0 + cx0) * CB; ti.b01 = (unsigned)(row0 + cx1) * CB;
+  ti.b10 = (unsigned)(row1 + cx0) * CB; ti.b11 = (unsigned)(row1 + cx1) * CB;
+  return ti;
+}
 
 // SPLIT: write the variance as the regulariser's first layer consumes it (costreg.hip, conv0_bf16x2_kernel):
 // every value split x = hi + lo into two bf16, channel-last in 16-byte slots of 8 channels,
@@ -144,6 +170,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned psv_bf16_rne(float x) {
   unsigned u = __float_as_uint(x);
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// two fp32 -> two bf16 (round to nearest even) packed in one dword, a in the low half: one v_cvt_pk_bf16_f32
+typedef __bf16 psv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, psv_bf16x2));
 }
 
 // THREADS = 64: one wave per workgroup (16 pixels x 4 planes).  The projection, gather and store phases of a
@@ -228,23 +261,7 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
         for (int e = tid / kPix; e < nec; e += kThreads / kPix) {
           float ix, iy;
           v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
-          float x0 = floorf(ix), y0 = floorf(iy);
-          float x1 = x0 + 1.f, y1 = y0 + 1.f;
-          bool vx0 = (x0 >= 0.f) && (x0 <= Wfm1), vx1 = (x1 >= 0.f) && (x1 <= Wfm1);
-          bool vy0 = (y0 >= 0.f) && (y0 <= Hfm1), vy1 = (y1 >= 0.f) && (y1 <= Hfm1);
-          TapInfo ti;
-          ti.w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f;
-          ti.w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
-          ti.w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f;
-          ti.w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
-          bool any = (vx0 || vx1) && (vy0 || vy1) && (gp1 < P);
-          int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0;
-          int yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
-          int base = p.edge_src[e_begin + ec + e] * p.Hf * p.Wf;
-          ti.o00 = any ? (base + yi0 * p.Wf + xi0) * C : -1;
-          ti.o01 = (base + yi0 * p.Wf + xi1) * C;
-          ti.o10 = (base + yi1 * p.Wf + xi0) * C;
-          ti.o11 = (base + yi1 * p.Wf + xi1) * C;
+          const TapInfo ti = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, p.edge_src[e_begin + ec + e] * p.Hf * p.Wf, gp1 < P);
           s_tap[e * kPix + px1] = ti;
         }
       }
@@ -257,19 +274,19 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
         const int px = a * PPP + pix_in_pass;
         for (int e = 0; e < nec; ++e) {
           const TapInfo ti = s_tap[e * kPix + px];
-          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ti.o00 >= 0) {
-            // uniform base + zero-extended 32-bit byte offset: the load takes the address as SGPR pair + VGPR
-            // offset, no 64-bit address arithmetic per tap
+          float4 s;
+          {
+            // uniform base + 32-bit byte offset: the load takes the address as SGPR pair + VGPR offset
             const char* fb = reinterpret_cast<const char*>(p.featT);
             const unsigned cgb = cg * 16;
-            const float4 v00 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o00 * 4u + cgb));
-            const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o01 * 4u + cgb));
-            const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o10 * 4u + cgb));
-            const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
-            // fixed evaluation order (no compiler re-association): ((v00 w00 + v01 w01) + v10 w10) + v11 w11, each
-            // step one FMA -- the plane-reuse kernel below uses the same sequence, so the variants agree bit for bit
-            s.x = v00.x * ti.w00; s.y = v00.y * ti.w00; s.z = v00.z * ti.w00; s.w = v00.w * ti.w00;
+            const float4 v00 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b00 + cgb));
+            const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b01 + cgb));
+            const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b10 + cgb));
+            const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b11 + cgb));
+            // F.grid_sample's tap order as an FMA chain: ((v00 w00 + v01 w01) + v10 w10) + v11 w11 -- the plane-reuse kernel
+            // below uses the same sequence, so the variants agree bit for bit
+            s.x = v3d::mul_rn(v00.x, ti.w00); s.y = v3d::mul_rn(v00.y, ti.w00);
+            s.z = v3d::mul_rn(v00.z, ti.w00); s.w = v3d::mul_rn(v00.w, ti.w00);
             s.x = __builtin_fmaf(v01.x, ti.w01, s.x); s.y = __builtin_fmaf(v01.y, ti.w01, s.y);
             s.z = __builtin_fmaf(v01.z, ti.w01, s.z); s.w = __builtin_fmaf(v01.w, ti.w01, s.w);
             s.x = __builtin_fmaf(v10.x, ti.w10, s.x); s.y = __builtin_fmaf(v10.y, ti.w10, s.y);
@@ -277,7 +294,8 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
             s.x = __builtin_fmaf(v11.x, ti.w11, s.x); s.y = __builtin_fmaf(v11.y, ti.w11, s.y);
             s.z = __builtin_fmaf(v11.z, ti.w11, s.z); s.w = __builtin_fmaf(v11.w, ti.w11, s.w);
           }
-          acc_s[a][0] += s.x; acc_s[a][1] += s.y; acc_s[a][2] += s.z; acc_s[a][3] += s.w;
+          acc_s[a][0] = v3d::add_rn(acc_s[a][0], s.x); acc_s[a][1] = v3d::add_rn(acc_s[a][1], s.y);
+          acc_s[a][2] = v3d::add_rn(acc_s[a][2], s.z); acc_s[a][3] = v3d::add_rn(acc_s[a][3], s.w);
           acc_q[a][0] = __builtin_fmaf(s.x, s.x, acc_q[a][0]); acc_q[a][1] = __builtin_fmaf(s.y, s.y, acc_q[a][1]);
           acc_q[a][2] = __builtin_fmaf(s.z, s.z, acc_q[a][2]); acc_q[a][3] = __builtin_fmaf(s.w, s.w, acc_q[a][3]);
         }
@@ -350,23 +368,44 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
 // of the next plane differs, edge by edge.  Arithmetic and accumulation order per (pixel, plane) are those of
 // the gather kernel (bit-identical output).
 constexpr int kRPix = 8;      // pixels per wave
-constexpr int kRE = 2;        // edges per phase-1 pass: kRE x kDB x kRPix = 64 (pixel, plane, edge) items, one per lane
+#ifndef V3D_PSV_RDB
+#define V3D_PSV_RDB 4
+#endif
+constexpr int kRDB = V3D_PSV_RDB;                 // depth planes per wave
+constexpr int kRE = 64 / (kRDB * kRPix);          // edges per phase-1 pass: kRE x kRDB x kRPix = 64 (pixel, plane, edge) items, one per lane
 
+#ifndef V3D_PSV_WAVES
+#define V3D_PSV_WAVES 5
+#endif
+#ifndef V3D_PSV_ORDER
+#define V3D_PSV_ORDER 1
+#endif
+#ifndef V3D_PSV_ABLATE
+#define V3D_PSV_ABLATE 0     // developer ablations of the reuse kernel (scripts/ab_build.sh): 1 no blend, 2 no reloads, 3 no projection, 4 no store
+#endif
 template <bool SPLIT>
-__global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
+__global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(PsvParams p) {
   constexpr int C = 32;
-  __shared__ TapInfo s_tap[kRE * kDB * kRPix];
-  __shared__ __attribute__((aligned(16))) float s_out[kDB][C][kRPix + 1];
+  __shared__ TapInfo s_tap[kRE * kRDB * kRPix];
+  __shared__ __attribute__((aligned(16))) float s_out[kRDB][C][kRPix + 1];
   __shared__ float s_ref[24];
   __shared__ float s_P[kMaxE][12];        // projection matrices of up to kMaxE consecutive edges
   __shared__ int s_base[kMaxE];           // first feature cell of their source images
 
   const int lane = threadIdx.x;
-  const int n_dchunk = (p.D + kDB - 1) / kDB;
+  const int n_dchunk = (p.D + kRDB - 1) / kRDB;
   int b = v3d::xcd_contiguous_block();
+#if V3D_PSV_ORDER == 1
+  // plane chunks fastest: the waves resident on an XCD sweep all planes of a few pixel tiles, i.e. short epipolar segments of
+  // the source maps, instead of one plane chunk of the whole image (= every source map entirely, more than the 4 MB L2)
+  const int dchunk = b % n_dchunk; b /= n_dchunk;
+  const int ptile = b % p.n_ptile;
+  const int r = b / p.n_ptile;
+#else
   const int ptile = b % p.n_ptile; b /= p.n_ptile;
   const int dchunk = b % n_dchunk;
   const int r = b / n_dchunk;
+#endif
   const int P = p.h * p.w;
   const int e_begin = p.edge_ofs[r], e_end = p.edge_ofs[r + 1];
   const int ne = e_end - e_begin;
@@ -375,9 +414,9 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   __syncthreads();
 
   // phase-1 role: lane = (edge slot, plane, pixel); the world point of (pixel, plane) is the same for every edge
-  const int e1 = lane >> 5, pl1 = (lane >> 3) & 3, px1 = lane & 7;
+  const int e1 = lane / (kRDB * kRPix), pl1 = (lane >> 3) & (kRDB - 1), px1 = lane & 7;
   const int gp1 = ptile * kRPix + px1;
-  const int d1 = dchunk * kDB + pl1;
+  const int d1 = dchunk * kRDB + pl1;
   float X, Y, Z;
   {
     const int gy = gp1 / p.w, gx = gp1 % p.w;
@@ -397,9 +436,9 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
   const int gpx = lane >> 3;
   const unsigned cgb = (lane & 7) * 16;
   const char* const fb = reinterpret_cast<const char*>(p.featT);
-  f32x4 acc_s[kDB], acc_q[kDB];
+  f32x4 acc_s[kRDB], acc_q[kRDB];
 #pragma unroll
-  for (int k = 0; k < kDB; ++k) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kRDB; ++k) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   PHASE_DECL;
   for (int ec = 0; ec < ne; ec += kRE) {
@@ -408,6 +447,7 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
     PHASE_MARK(0);
     if (ec % kMaxE == 0) {
       const int nload = min(kMaxE, ne - ec) * 12;
+#pragma unroll 1
       for (int i = lane; i < nload; i += 64) {
         const int src = p.edge_src[e_begin + ec + i / 12];
         s_P[i / 12][i % 12] = p.camp[src * kCamStride + 24 + i % 12];
@@ -415,55 +455,55 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
       }
       __syncthreads();
     }
+#if V3D_PSV_ABLATE == 3      // developer ablation: no projection (tap records written once)
+    if (ec == 0)
+#endif
     if (e1 < nec) {
       float ix, iy;
       v3d::sample_position(s_P[ec % kMaxE + e1], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
-      const float x0 = floorf(ix), y0 = floorf(iy);
-      const float x1 = x0 + 1.f, y1 = y0 + 1.f;
-      const bool vx0 = (x0 >= 0.f) && (x0 <= Wfm1), vx1 = (x1 >= 0.f) && (x1 <= Wfm1);
-      const bool vy0 = (y0 >= 0.f) && (y0 <= Hfm1), vy1 = (y1 >= 0.f) && (y1 <= Hfm1);
-      TapInfo ti;
-      ti.w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f;
-      ti.w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
-      ti.w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f;
-      ti.w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
-      const bool any = (vx0 || vx1) && (vy0 || vy1) && live1;
-      const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0;
-      const int yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
-      const int base = s_base[ec % kMaxE + e1];
-      ti.o00 = any ? (base + yi0 * p.Wf + xi0) * C : -1;
-      ti.o01 = (base + yi0 * p.Wf + xi1) * C;
-      ti.o10 = (base + yi1 * p.Wf + xi0) * C;
-      ti.o11 = (base + yi1 * p.Wf + xi1) * C;
-      s_tap[(e1 * kDB + pl1) * kRPix + px1] = ti;
+      s_tap[(e1 * kRDB + pl1) * kRPix + px1] = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, s_base[ec % kMaxE + e1], live1);
     }
     __syncthreads();
     PHASE_MARK(1);
     for (int e = 0; e < nec; ++e) {
-      int c00 = -2, c11 = -2;            // footprint held in t00..t11 (o00 and o11 pin all four cells)
-      // deliberately not initialised: c00 = -2 matches no offset, so the first valid plane always loads them, and
-      // zeroing 16 registers per edge is ~10 % of the kernel's (binding) VALU work
+      unsigned c00 = ~0u, c11 = ~0u;     // footprint held in t00..t11 (b00 and b11 pin all four cells)
+      // deliberately not initialised: ~0 matches no offset, so the first plane always loads them
       f32x4 t00, t01, t10, t11;
 #pragma unroll
-      for (int pl = 0; pl < kDB; ++pl) {
-        const TapInfo ti = s_tap[(e * kDB + pl) * kRPix + gpx];
-        if (ti.o00 >= 0) {
-          if (ti.o00 != c00 || ti.o11 != c11) {
-            t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o00 * 4u + cgb));
-            t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o01 * 4u + cgb));
-            t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o10 * 4u + cgb));
-            t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)((unsigned)ti.o11 * 4u + cgb));
-            c00 = ti.o00; c11 = ti.o11;
-          }
-          f32x4 sv = t00 * ti.w00;                                   // same fixed FMA sequence as the gather kernel
-          sv = __builtin_elementwise_fma(t01, (f32x4){ti.w01, ti.w01, ti.w01, ti.w01}, sv);
-          sv = __builtin_elementwise_fma(t10, (f32x4){ti.w10, ti.w10, ti.w10, ti.w10}, sv);
-          sv = __builtin_elementwise_fma(t11, (f32x4){ti.w11, ti.w11, ti.w11, ti.w11}, sv);
-          acc_s[pl] += sv;
-          acc_q[pl] = __builtin_elementwise_fma(sv, sv, acc_q[pl]);
+      for (int pl = 0; pl < kRDB; ++pl) {
+        const TapInfo ti = s_tap[(e * kRDB + pl) * kRPix + gpx];
+#if V3D_PSV_ABLATE == 2      // developer ablation: footprint loaded once per edge only
+        if (pl == 0) {
+#else
+        if (ti.b00 != c00 || ti.b11 != c11) {
+#endif
+          t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b00 + cgb));
+          t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b01 + cgb));
+          t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b10 + cgb));
+          t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b11 + cgb));
+          c00 = ti.b00; c11 = ti.b11;
         }
+        // F.grid_sample's tap order as an FMA chain (same sequence as the gather kernel); no validity branch: taps outside
+        // the source image carry weight 0 and a clamped address
+#if V3D_PSV_ABLATE == 1      // developer ablation: no blend arithmetic (loads and tap reads kept alive)
+        asm volatile("" : : "v"(t00), "v"(t01), "v"(t10), "v"(t11), "v"(ti.w00), "v"(ti.w01), "v"(ti.w10), "v"(ti.w11));
+#else
+        f32x4 sv = t00 * ti.w00;
+        sv = __builtin_elementwise_fma(t01, (f32x4){ti.w01, ti.w01, ti.w01, ti.w01}, sv);
+        sv = __builtin_elementwise_fma(t10, (f32x4){ti.w10, ti.w10, ti.w10, ti.w10}, sv);
+        sv = __builtin_elementwise_fma(t11, (f32x4){ti.w11, ti.w11, ti.w11, ti.w11}, sv);
+        acc_s[pl] += sv;
+        acc_q[pl] = __builtin_elementwise_fma(sv, sv, acc_q[pl]);
+#endif
+#ifndef V3D_PSV_NOSERIAL
+        // Finish this plane before the next one starts: the empty statement pins the accumulators here and, as a memory
+        // barrier, keeps the next plane's tap-record read and footprint loads below it.  Without it the compiler issues the
+        // (conditional) loads of all four planes first, each into its own 16 registers: 136 VGPRs, 3 waves per SIMD.
+        asm volatile("" : "+v"(acc_s[pl]), "+v"(acc_q[pl]) : : "memory");
+#endif
       }
     }
+    PHASE_MARK(4);
   }
 
   PHASE_MARK(2);
@@ -481,37 +521,36 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
 #endif
   const int cg = lane & 7;
   if constexpr (SPLIT) {
-    // s_out reused as [plane][8 groups][kRPix + 1] 16-byte slots
-    u32x2* const s_sp = reinterpret_cast<u32x2*>(&s_out[0][0][0]);
+    // Lane (pixel gpx, channel quad cg) holds channels 4 cg .. 4 cg + 3 = one 8-byte half of the 16-byte hi slot and of the
+    // lo slot of channel group cg / 2.  Lane pairs swap halves (one DPP move per dword): the even lane assembles and stores
+    // the whole hi slot, the odd lane the whole lo slot -- no LDS round trip; the 8 pixels of a wave make 128-byte runs.
     const int chunk = cg >> 1, half = cg & 1;
+    u32x4* const out = reinterpret_cast<u32x4*>(p.var);
+    const int gp = ptile * kRPix + gpx;
 #pragma unroll
-    for (int pl = 0; pl < kDB; ++pl) {
-      unsigned h[4], l[4];
+    for (int pl = 0; pl < kRDB; ++pl) {
+      float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float avg = mean(acc_s[pl][k]);
         const float avg_sq = mean(acc_q[pl][k]);
-        const float v = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));            // mvsnet.py:216
-        h[k] = psv_bf16_rne(v);
-        l[k] = psv_bf16_rne(v - __uint_as_float(h[k] << 16));
+        v[k] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));                    // mvsnet.py:216
       }
-      s_sp[(((pl * 8 + chunk * 2 + 0) * (kRPix + 1)) + gpx) * 2 + half] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-      s_sp[(((pl * 8 + chunk * 2 + 1) * (kRPix + 1)) + gpx) * 2 + half] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
-    }
-    __syncthreads();
-    u32x4* const out = reinterpret_cast<u32x4*>(p.var);
-    const u32x4* const s_q = reinterpret_cast<const u32x4*>(s_sp);
-#pragma unroll
-    for (int k = 0; k < kDB * 8 * kRPix / 64; ++k) {
-      const int i = k * 64 + lane;
-      const int pl = i / (8 * kRPix), g = (i / kRPix) % 8, px = i % kRPix;
-      const int gp = ptile * kRPix + px, d = dchunk * kDB + pl;
-      if (gp < P && d < p.D)
-        __builtin_nontemporal_store(s_q[(pl * 8 + g) * (kRPix + 1) + px], &out[(((size_t)r * 8 + g) * p.D + d) * P + gp]);
+      // x = hi + lo: hi = RNE_bf16(x), lo = RNE_bf16(x - hi); v_cvt_pk_bf16_f32 rounds to nearest even in hardware
+      const unsigned h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+      const unsigned l01 = pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+      const unsigned l23 = pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+      const unsigned s0 = half ? h01 : l01, s1 = half ? h23 : l23;             // what the partner lane stores
+      const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+      const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, true);
+      const u32x4 slot = half ? (u32x4){r0, r1, l01, l23} : (u32x4){h01, h23, r0, r1};
+      const int d = dchunk * kRDB + pl;
+      if (gp < P && d < p.D && (V3D_PSV_ABLATE != 4 || slot[0] == 0x12345u))
+        __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);
     }
   } else {
 #pragma unroll
-    for (int pl = 0; pl < kDB; ++pl)
+    for (int pl = 0; pl < kRDB; ++pl)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float avg = mean(acc_s[pl][k]);
@@ -519,9 +558,9 @@ __global__ __launch_bounds__(64) void psv_variance_reuse_kernel(PsvParams p) {
         s_out[pl][cg * 4 + k][gpx] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
       }
     __syncthreads();
-    for (int i = lane; i < kDB * C * kRPix; i += 64) {
+    for (int i = lane; i < kRDB * C * kRPix; i += 64) {
       const int pl = i / (C * kRPix), c = (i / kRPix) % C, px = i % kRPix;
-      const int gp = ptile * kRPix + px, d = dchunk * kDB + pl;
+      const int gp = ptile * kRPix + px, d = dchunk * kRDB + pl;
       if (gp < P && d < p.D) __builtin_nontemporal_store(s_out[pl][c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
     }
   }
@@ -639,7 +678,7 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   } while (0)
     static const bool plain_gather = getenv("V3D_PSV_GATHER") != nullptr;   // developer A/B switch
     if (C == 32 && !plain_gather) {
-      const long long rblocks = (long long)n_ref * n_dchunk * ((h * w + kRPix - 1) / kRPix);
+      const long long rblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * ((h * w + kRPix - 1) / kRPix);
       V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
       p.n_ptile = (h * w + kRPix - 1) / kRPix;
       if (split) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);

@@ -119,6 +119,24 @@ __device__ __forceinline__ float div_uniform(float x, float c, float rc) {
   return __builtin_fmaf(__builtin_fmaf(-q0, c, x), rc, q0);
 }
 
+// x / den and y / den with ONE shared reciprocal: the instruction sequence hipcc emits for an IEEE-correct fp32 division
+// (v_rcp + one Newton step, quotient, two residual corrections) minus the two v_div_scale per quotient: den = |q_z| + 1e-8
+// lies in [1e-8, ~1e7] and the quotients are pixel coordinates, far from the exponent ranges in which the scaling acts, so
+// the bits are those of x / den (v_div_fixup still handles zero / inf / nan operands).  13 instructions instead of 22 for
+// the two quotients of every sample.
+__device__ __forceinline__ void div2_shared(float x, float y, float den, float& qx, float& qy) {
+  float r = __builtin_amdgcn_rcpf(den);
+  r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.f), r, r);
+  float q = mul_rn(x, r);
+  q = __builtin_fmaf(__builtin_fmaf(-den, q, x), r, q);
+  q = __builtin_fmaf(__builtin_fmaf(-den, q, x), r, q);
+  qx = __builtin_amdgcn_div_fixupf(q, den, x);
+  q = mul_rn(y, r);
+  q = __builtin_fmaf(__builtin_fmaf(-den, q, y), r, q);
+  q = __builtin_fmaf(__builtin_fmaf(-den, q, y), r, q);
+  qy = __builtin_amdgcn_div_fixupf(q, den, y);
+}
+
 // Source-view sample position of a world point: q = P [X;1]; uv = q_xy / (|q_z| + 1e-8) (mvsnet.py:199-202); normalised
 // with the IMAGE size (:205-206); un-normalised by grid_sample with the FEATURE size (align_corners=True).
 __device__ __forceinline__ void sample_position(const float* Pm, float X, float Y, float Z, float Wm1, float rWm1, float Hm1,
@@ -127,7 +145,8 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
   const float qy = dot4h_chain(Pm[4], X, Pm[5], Y, Pm[6], Z, Pm[7]);
   const float qz = dot4h_chain(Pm[8], X, Pm[9], Y, Pm[10], Z, Pm[11]);
   const float zb = add_rn(fabsf(qz), 1e-8f);
-  const float u = __fdiv_rn(qx, zb), v = __fdiv_rn(qy, zb);
+  float u, v;
+  div2_shared(qx, qy, zb, u, v);
   const float gx = sub_rn(mul_rn(div_uniform(u, Wm1, rWm1), 2.f), 1.f);
   const float gy = sub_rn(mul_rn(div_uniform(v, Hm1, rHm1), 2.f), 1.f);
   ix = mul_rn(mul_rn(add_rn(gx, 1.f), 0.5f), Wfm1);
