@@ -85,6 +85,10 @@ SIGNATURES = {
     'v3d_lower_bound_u64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'v3d_voxel_decode': (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_void_p]),
+    'v3d_decoder_fused_f32': (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, ctypes.POINTER(c_void_p),
+                                      ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
+                                      ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
 }

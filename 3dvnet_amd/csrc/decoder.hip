@@ -1,7 +1,8 @@
 // Row C2b tail + C3 of SURVEY.md §8a: the hypothesis decoder's last Conv1d(h_dim -> 1, k3, pad 1, bias)
 // along the hypothesis axis, softmax over the hypotheses (refinement.py:24,43) and, optionally, the
 // expected depth offset sum_i p_i * vals_i (lightningmodel.py:238-241).  One wave per point.
-#include "v3d_common.h"
+#include "gemm_weights.h"
+#include "sparse_hash.h"
 
 namespace {
 
@@ -55,6 +56,375 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused hypothesis decoder (rows C2a + C2b + C3 in ONE kernel): sparse trilinear interpolation of
+// the three U-Net levels (refinement.py:28-41) -> Conv1d+BN+ReLU x3 along the hypothesis axis (:16-23) -> Conv1d(128 -> 1)
+// + softmax (:24,43) -> expected offset (lightningmodel.py:237-241).  The [Nq, 352, 7] feature tensor (30.9 MB per
+// reference view and sweep) and the three [Nq*7, 128] activations never reach HBM.
+//
+// One 256-thread workgroup = kFPts query points = kFPts * n_hyp (<= 64) GEMM columns; whole hypothesis groups, so no conv
+// tap crosses the tile.  Layer 1 consumes its 352 input channels in 32-wide chunks that are PRODUCED on the fly: every
+// thread blends the 8 corner rows (hash-probed once per tile into an LDS corner table) of its (row, 4 channels) and commits
+// the split-bf16 values to the staging tile the MFMAs read; the next chunk's gathers are in flight during the MFMAs of the
+// current one.  Layer outputs (bias + ReLU) are split and kept in LDS in B-fragment order for the next layer; the last
+// layer's output stays in LDS as fp32 for the 128 -> 1 head, softmax and expectation.  Matrix arithmetic as everywhere on
+// this path: split-bf16 operands (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16), fp32 accumulation; weights are the
+// split images of v3d_gemm_pack (A fragments go from L2 straight to registers, one tap ahead).
+// LDS: two activation buffers of 33 KB (the second doubles as staging tile + corner table during layer 1).
+// STATUS: correct and parity-tested, but SLOWER than the unfused chain (cfg3: 33 ms against 23 ms per scene) -- see kFLdsBytes
+// below; it is therefore opt-in (HypothesisDecoder.fused) and the default path stays v3d_sparse_interp_f32 +
+// v3d_gemm_gather_f32 x 3 + v3d_decoder_head_f32.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kFPts = 8;            // query points per workgroup
+constexpr int kFRows = 64;          // MFMA columns per workgroup (kFPts * n_hyp <= 64)
+constexpr int kFZero = 64;               // index of the all-zero activation row (conv padding)
+constexpr int kFRT = kFZero + 1;         // rows per LDS activation array
+constexpr int kFH = 128;            // hidden width of the decoder
+constexpr int kFNB = kFRows / 16, kFMBW = 2, kFMB = 4 * kFMBW;
+constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap, K chunk) of a layer's weight image
+constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
+constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
+constexpr size_t kFUsedLdsBytes = 2 * kFActBytes;
+// Requested LDS: more than half of the CU's 160 KB, so that ONE workgroup runs per CU.  With two co-resident workgroups
+// (the 65 KB the kernel actually uses would allow it) the results were nondeterministic on MI355X / ROCm 7.2 in ways no
+// barrier, wait or LDS-overlap check explained; one workgroup per CU is deterministic and matches the
+// unfused chain to 5e-7.
+constexpr size_t kFLdsBytes = 96 * 1024;
+static_assert(kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "staging tile + corner table alias the second buffer");
+static_assert((size_t)kFRows * kFH * 4 <= kFActBytes, "fp32 output of the last layer aliases the first buffer");
+
+struct FusedLevel {
+  v3dhash::HashTable table;
+  const float* feats;     // [N, C]
+  const float* min_pts;   // [n_batch, 3]
+  float res;              // x.res of the level (= tensor_stride * voxel size)
+  int C, ts;
+};
+
+struct FusedParams {
+  FusedLevel lv[3];       // in feature-row order: channels [0, C0) = lv[0] (finest), then lv[1], lv[2], then pts_feat
+  const float* pts;       // [n_pts, n_hyp, 3]
+  const long long* pts_batch;
+  const float* pts_feat;  // [n_pts, n_hyp, c_feat] or null
+  int c_feat, n_pts, n_hyp, nkc1;
+  const float* w[3];      // split-bf16 weight images of the three Conv1d layers
+  const float* bias[3];   // folded BatchNorm biases [128]
+  const float* head_w;    // [1, 128, 3]
+  const float* head_b;
+  const float* vals;      // [n_hyp] offset values or null
+  float* preds;           // [n_pts, n_hyp]
+  float* expect;          // [n_pts] or null
+};
+
+__device__ __forceinline__ unsigned fused_pack_bf16x2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+// x = hi + lo (hi = RNE_bf16(x), lo = RNE_bf16(x - hi)) for 4 values -> two words of hi, two of lo
+__device__ __forceinline__ void fused_split4(const float (&v)[4], u32x2& hi, u32x2& lo) {
+  const unsigned h01 = fused_pack_bf16x2(v[0], v[1]), h23 = fused_pack_bf16x2(v[2], v[3]);
+  hi = (u32x2){h01, h23};
+  lo = (u32x2){fused_pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
+               fused_pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+}
+
+__global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* const actA = reinterpret_cast<u32x4*>(smem);                               // [2][kFRT][16]
+  u32x4* const actB = reinterpret_cast<u32x4*>(smem + kFActBytes);                  // [2][kFRT][16]
+  u32x4* const xq = actB;                                                           // layer 1: [2][kFRT][4]
+  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + kFStageBytes);       // layer 1: [64 rows][3 levels][8]
+  float* const cw = reinterpret_cast<float*>(crow + kFRows * 24);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  const int pt0 = blockIdx.x * kFPts;
+  const int n_hyp = p.n_hyp, rows = kFPts * n_hyp;
+  const long long q0 = (long long)pt0 * n_hyp;                       // first global (point, hypothesis) row of the tile
+  const long long n_q = (long long)p.n_pts * n_hyp;
+
+  // ---- zero rows; corner table: 8 hash probes per (row, level), as interp_corners_kernel (sparse.hip) -----------------
+  if (tid < 2 * 16) actA[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
+  if (tid < 2 * 4) xq[((tid >> 2) * kFRT + kFZero) * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
+  // (the level index is kept wave-uniform everywhere: a per-lane index into the kernel-argument array p.lv[] makes the
+  // compiler build a per-lane scratch copy of it)
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const FusedLevel L = p.lv[l];
+    for (int j = tid; j < kFRows * 8; j += 256) {
+      const int r = j >> 3, corner = j & 7;
+      int row = -1;
+      float w = 0.f;
+      if (r < rows && q0 + r < n_q) {
+        const long long q = q0 + r;
+        const int b = (int)p.pts_batch[q / n_hyp];
+        const float ts = (float)L.ts;
+        float c0, c1, c2;
+        w = 1.f;
+        {
+          // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
+          const float qx = ((p.pts[(size_t)q * 3 + 0] - L.min_pts[b * 3 + 0]) / L.res) * ts;
+          const float qy = ((p.pts[(size_t)q * 3 + 1] - L.min_pts[b * 3 + 1]) / L.res) * ts;
+          const float qz = ((p.pts[(size_t)q * 3 + 2] - L.min_pts[b * 3 + 2]) / L.res) * ts;
+          c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
+          c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
+          c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
+          w *= 1.f - fabsf(qx - c0) / ts;
+          w *= 1.f - fabsf(qy - c1) / ts;
+          w *= 1.f - fabsf(qz - c2) / ts;
+        }
+        if (c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard && c0 <= 60000.f && c1 <= 60000.f &&
+            c2 <= 60000.f)
+          row = v3dhash::hash_find(L.table, v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2));
+      }
+      // an absent corner (or a padding row) reads feature row 0 with weight 0: the gathers below are unconditional
+      crow[(r * 3 + l) * 8 + corner] = row < 0 ? 0 : row;
+      cw[(r * 3 + l) * 8 + corner] = row < 0 ? 0.f : w;
+    }
+  }
+
+  // ---- layer 1: K = 3 taps x (C0 + C1 + C2 + c_feat) channels, produced chunk by chunk ----------------------------------
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  const int cb1 = p.lv[0].C, cb2 = cb1 + p.lv[1].C, cb3 = cb2 + p.lv[2].C;
+  f32x4 xr[2][8];
+  // level of a 32-channel chunk: wave-uniform (chunk boundaries are multiples of 32)
+  auto level_of = [&](int kc) __attribute__((always_inline)) {
+    const int c = kc * 32;
+    return c < cb1 ? 0 : c < cb2 ? 1 : c < cb3 ? 2 : 3;
+  };
+  auto issue_x = [&](int kc) __attribute__((always_inline)) {
+    const int l = level_of(kc);
+    if (l < 3) {
+      const float* const feats = l == 0 ? p.lv[0].feats : l == 1 ? p.lv[1].feats : p.lv[2].feats;
+      const int C = l == 0 ? p.lv[0].C : l == 1 ? p.lv[1].C : p.lv[2].C;
+      const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int r = srow + 32 * ps;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cr = crow[(r * 3 + l) * 8 + k];
+          xr[ps][k] = *reinterpret_cast<const f32x4*>(feats + (size_t)cr * C + lc);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int r = srow + 32 * ps;
+        xr[ps][0] = (p.pts_feat && r < rows && q0 + r < n_q)
+                        ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto commit_x = [&](int kc) __attribute__((always_inline)) {
+    const int l = level_of(kc);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int r = srow + 32 * ps;
+      float v[4];
+      if (l < 3) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
+          const float w = cw[(r * 3 + l) * 8 + k];
+          a = __builtin_elementwise_fma(xr[ps][k], (f32x4){w, w, w, w}, a);
+        }
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      } else {
+        v[0] = xr[ps][0].x; v[1] = xr[ps][0].y; v[2] = xr[ps][0].z; v[3] = xr[ps][0].w;
+      }
+      u32x2 hi, lo;
+      fused_split4(v, hi, lo);
+      const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+      const int slot = kg ^ (((r >> 3) & 1) * 3);
+      u32x2* x2 = reinterpret_cast<u32x2*>(xq);
+      x2[(r * 4 + slot) * 2 + half] = hi;
+      x2[((kFRT + r) * 4 + slot) * 2 + half] = lo;
+    }
+  };
+
+  // per column block: does tap 0 / tap 2 of this lane's output row stay inside its hypothesis group?
+  unsigned tapmask = 0;
+#pragma unroll
+  for (int nb = 0; nb < kFNB; ++nb) {
+    const int hh = (nb * 16 + jn) % n_hyp;
+    tapmask |= (hh >= 1 ? 1u : 0u) << (2 * nb);
+    tapmask |= (hh + 1 < n_hyp ? 1u : 0u) << (2 * nb + 1);
+  }
+  u32x4 a_cur[2 * kFMBW], a_nxt[2 * kFMBW];
+  auto load_a = [&](u32x4 (&a)[2 * kFMBW], const float* wp, int nkc, int t, int kc) __attribute__((always_inline)) {
+    const u32x4* w = reinterpret_cast<const u32x4*>(wp + (size_t)(t * nkc + kc) * kFWslab) + lane;
+#pragma unroll
+    for (int m = 0; m < kFMBW; ++m) {
+      a[m] = w[(wave * kFMBW + m) * 64];
+      a[kFMBW + m] = w[(kFMB + wave * kFMBW + m) * 64];
+    }
+  };
+  f32x4 acc[kFNB][kFMBW];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < kFNB; ++nb)
+#pragma unroll
+      for (int m = 0; m < kFMBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto mfma_block = [&](const bf16x8 b_hi, const bf16x8 b_lo, int nb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < kFMBW; ++m) {
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a_cur[m]), a_lo = __builtin_bit_cast(bf16x8, a_cur[kFMBW + m]);
+      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[nb][m], 0, 0, 0);
+      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[nb][m], 0, 0, 0);
+      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
+    }
+  };
+  // bias + ReLU of this wave's 32 channels x 64 rows -> split -> LDS activation buffer (B-fragment order, 16-byte slots of 8
+  // channels, slot index XOR-ed with the row so that the 16 row-lanes of a ds_read_b128 hit 16 different slots)
+  auto store_act = [&](u32x4* dst, const float* bias) __attribute__((always_inline)) {
+    u32x2* d2 = reinterpret_cast<u32x2*>(dst);
+#pragma unroll
+    for (int nb = 0; nb < kFNB; ++nb) {
+      const int r = nb * 16 + jn;
+#pragma unroll
+      for (int mw = 0; mw < kFMBW; ++mw) {
+        const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bias[co0 + k], 0.f);
+        u32x2 hi, lo;
+        fused_split4(v, hi, lo);
+        const int slot = (co0 >> 3) ^ (r & 15), half = (co0 >> 2) & 1;
+        d2[(r * 16 + slot) * 2 + half] = hi;
+        d2[((kFRT + r) * 16 + slot) * 2 + half] = lo;
+      }
+    }
+  };
+
+  zero_acc();
+  __syncthreads();                         // corner table ready
+  issue_x(0);
+  load_a(a_cur, p.w[0], p.nkc1, 0, 0);
+#pragma unroll 1
+  for (int kc = 0; kc < p.nkc1; ++kc) {
+    __syncthreads();                       // the previous chunk's MFMAs are done with the staging tile
+    commit_x(kc);
+    __syncthreads();
+    if (kc + 1 < p.nkc1) issue_x(kc + 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < 2) load_a(a_nxt, p.w[0], p.nkc1, t + 1, kc);
+      else if (kc + 1 < p.nkc1) load_a(a_nxt, p.w[0], p.nkc1, 0, kc + 1);
+      else load_a(a_nxt, p.w[1], 4, 0, 0);                                     // first fragments of layer 2
+#pragma unroll
+      for (int nb = 0; nb < kFNB; ++nb) {
+        const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
+        const int R = inside ? nb * 16 + jn + t - 1 : kFZero;
+        const int slot = R * 4 + (kq ^ (((R >> 3) & 1) * 3));
+        mfma_block(__builtin_bit_cast(bf16x8, xq[slot]), __builtin_bit_cast(bf16x8, xq[kFRT * 4 + slot]), nb);
+      }
+#pragma unroll
+      for (int m = 0; m < 2 * kFMBW; ++m) a_cur[m] = a_nxt[m];
+    }
+  }
+  store_act(actA, p.bias[0]);
+  __syncthreads();        // act1 complete; staging tile / corner table (aliasing the second buffer) no longer needed
+
+  // ---- layers 2 and 3: K = 3 taps x 128 channels read from LDS ------------------------------------------------------------
+#pragma unroll 1
+  for (int layer = 1; layer < 3; ++layer) {
+    const u32x4* const src = layer == 1 ? actA : actB;
+    if (layer == 1 && tid < 2 * 16) actB[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
+    zero_acc();
+    if (layer == 1) __syncthreads();       // zero row of the second buffer visible
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float* const wl = layer == 1 ? p.w[1] : p.w[2];
+        if (t < 2) load_a(a_nxt, wl, 4, t + 1, kc);
+        else if (kc + 1 < 4) load_a(a_nxt, wl, 4, 0, kc + 1);
+        else if (layer == 1) load_a(a_nxt, p.w[2], 4, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < kFNB; ++nb) {
+          const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
+          const int R = inside ? nb * 16 + jn + t - 1 : kFZero;
+          const int slot = R * 16 + ((kc * 4 + kq) ^ (R & 15));
+          mfma_block(__builtin_bit_cast(bf16x8, src[slot]), __builtin_bit_cast(bf16x8, src[kFRT * 16 + slot]), nb);
+        }
+#pragma unroll
+        for (int m = 0; m < 2 * kFMBW; ++m) a_cur[m] = a_nxt[m];
+      }
+    }
+    if (layer == 1) {
+      store_act(actB, p.bias[1]);
+    } else {
+      // last layer: fp32 [64 rows][128] into the first buffer (act1 is dead: every wave passed the barrier after layer 2)
+      float* const of = reinterpret_cast<float*>(actA);
+#pragma unroll
+      for (int nb = 0; nb < kFNB; ++nb)
+#pragma unroll
+        for (int mw = 0; mw < kFMBW; ++mw) {
+          const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + p.bias[2][co0 + k], 0.f);
+          *reinterpret_cast<f32x4*>(of + (nb * 16 + jn) * kFH + co0) = v;
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- head: Conv1d(128 -> 1, k3, pad 1, bias) over the hypotheses, softmax, expectation (32 lanes per point) ----------------
+  {
+    const float* const of = reinterpret_cast<const float*>(actA);
+    const int pt = tid >> 5, l32 = tid & 31, c0 = l32 * 4;
+    float score[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) score[h] = 0.f;
+    float w0[4], w1[4], w2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w0[k] = p.head_w[(c0 + k) * 3]; w1[k] = p.head_w[(c0 + k) * 3 + 1]; w2[k] = p.head_w[(c0 + k) * 3 + 2]; }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      if (h < n_hyp) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(of + (pt * n_hyp + h) * kFH + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // out[h'] = sum_t in[h' + t - 1] w[t]  =>  in[h] feeds out[h+1] (t=0), out[h] (t=1), out[h-1] (t=2)
+          if (h + 1 < 8) score[h + 1] += x[k] * w0[k];
+          score[h] += x[k] * w1[k];
+          if (h > 0) score[h - 1] += x[k] * w2[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      float v = score[h];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      score[h] = v + p.head_b[0];
+    }
+    if (l32 == 0 && pt0 + pt < p.n_pts) {
+      float m = -INFINITY;
+      for (int h = 0; h < n_hyp; ++h) m = fmaxf(m, score[h]);
+      float sum = 0.f;
+      for (int h = 0; h < n_hyp; ++h) sum += expf(score[h] - m);
+      float e = 0.f;
+      for (int h = 0; h < n_hyp; ++h) {
+        const float pr = expf(score[h] - m) / sum;
+        p.preds[(size_t)(pt0 + pt) * n_hyp + h] = pr;
+        if (p.vals) e += p.vals[h] * pr;
+      }
+      if (p.expect) p.expect[pt0 + pt] = e;
+    }
+  }
+}
 }  // namespace
 
 extern "C" int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int C, const float* weight,
@@ -71,3 +441,60 @@ extern "C" int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int 
   V3D_CHECK_LAUNCH("decoder_head_kernel");
   return V3D_OK;
 }
+
+extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const float* head_weight,
+                                     const float* head_bias, const void* const* level_table_host,
+                                     const int* level_n_host, const float* const* level_feats_host,
+                                     const int* level_C_host, const int* level_stride_host,
+                                     const float* const* level_min_pts_host, const float* level_res_host,
+                                     const float* pts, const int64_t* pts_batch, const float* pts_feat, int c_feat,
+                                     int n_pts, int n_hyp, const float* offset_vals, float* preds, float* expect,
+                                     void* stream) {
+  V3D_REQUIRE(layers_host && head_weight && head_bias && level_table_host && level_n_host && level_feats_host &&
+                  level_C_host && level_stride_host && level_min_pts_host && level_res_host && pts && pts_batch && preds,
+              V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: null argument");
+  V3D_REQUIRE(n_pts >= 0 && n_hyp >= 1 && n_hyp <= 8, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: n_hyp=%d (1..8)", n_hyp);
+  V3D_REQUIRE(c_feat >= 0 && c_feat % 32 == 0 && (c_feat == 0 || pts_feat), V3D_ERR_UNSUPPORTED,
+              "v3d_decoder_fused_f32: c_feat=%d must be a multiple of 32 (with pts_feat given)", c_feat);
+  V3D_REQUIRE(!expect || offset_vals, V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: expect without offset_vals");
+  FusedParams p;
+  memset(&p, 0, sizeof(p));
+  int k1 = c_feat;
+  for (int l = 0; l < 3; ++l) {
+    V3D_REQUIRE(level_table_host[l] && level_feats_host[l] && level_min_pts_host[l] && level_n_host[l] > 0 &&
+                    level_C_host[l] > 0 && level_C_host[l] % 32 == 0 && level_stride_host[l] > 0 && level_res_host[l] > 0.f,
+                V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: level %d (channels must be a multiple of 32)", l);
+    p.lv[l].table = v3dhash::table_view(const_cast<void*>(level_table_host[l]), level_n_host[l]);
+    p.lv[l].feats = level_feats_host[l]; p.lv[l].min_pts = level_min_pts_host[l]; p.lv[l].res = level_res_host[l];
+    p.lv[l].C = level_C_host[l]; p.lv[l].ts = level_stride_host[l];
+    k1 += level_C_host[l];
+  }
+  for (int l = 0; l < 3; ++l) {
+    const v3d_gemm_weights* h = layers_host[l];
+    V3D_REQUIRE(h && h->n_seg == 3 && h->N == kFH && h->MBW == kFMBW && h->has_bias && h->K == (l == 0 ? k1 : kFH) &&
+                    h->KP == h->K,
+                V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: layer %d must be a packed Conv1d(k3) %d -> 128 with bias", l,
+                l == 0 ? k1 : kFH);
+    p.w[l] = h->dev + h->bf_ofs;
+    p.bias[l] = h->dev + h->bias_ofs;
+  }
+  p.nkc1 = k1 / 32;
+  p.pts = pts; p.pts_batch = (const long long*)pts_batch; p.pts_feat = pts_feat; p.c_feat = c_feat;
+  p.n_pts = n_pts; p.n_hyp = n_hyp;
+  p.head_w = head_weight; p.head_b = head_bias; p.vals = offset_vals; p.preds = preds; p.expect = expect;
+  if (n_pts == 0) return V3D_OK;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kFLdsBytes));
+    attr_set = true;
+  }
+  {
+    v3d::TimedScope ts("decoder_fused", s);
+    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, 256, kFLdsBytes, s>>>(p);
+  }
+  V3D_CHECK_LAUNCH("decoder_fused_kernel");
+  return V3D_OK;
+}
+

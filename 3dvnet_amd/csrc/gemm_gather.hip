@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "v3d_common.h"
+#include "gemm_weights.h"
 
 namespace {
 
@@ -471,12 +472,6 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 }  // namespace
 
 // ---- packed weights -------------------------------------------------------------------------------
-struct v3d_gemm_weights {
-  int N, K, KP, n_seg, MBW;
-  float* dev;       // packed fragments followed by bias[N] (0 if none), gn_w[N], gn_b[N]
-  size_t bias_ofs, gnw_ofs, gnb_ofs, bf_ofs;
-  int has_bias, has_gn;
-};
 
 extern "C" int v3d_gemm_pack(const float* w_host, long long stride_seg, long long stride_co,
                              long long stride_k, int n_seg, int N, int K, const float* scale_host,

@@ -5,44 +5,11 @@
 //     convs -- consumed as row maps by the gather-GEMM (gemm_gather.hip),
 //   * sparse trilinear interpolation at arbitrary query points (MinkowskiInterpolation,
 //     mv3d/subnetworks/refinement.py:26,39), written straight into the decoder's wide feature row.
-#include "v3d_common.h"
+#include "sparse_hash.h"
 
 namespace {
 
-constexpr unsigned long long kEmpty = ~0ull;
-constexpr int kGuard = 8;   // coordinates may be probed a few voxels below zero
-
-__device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int z) {
-  return ((unsigned long long)(unsigned)(b & 0xffff) << 48) | ((unsigned long long)(unsigned)((x + kGuard) & 0xffff) << 32) |
-         ((unsigned long long)(unsigned)((y + kGuard) & 0xffff) << 16) | (unsigned long long)(unsigned)((z + kGuard) & 0xffff);
-}
-
-__device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return (unsigned)k;
-}
-
-struct HashTable {          // device layout inside the caller-provided buffer
-  unsigned long long* keys; // [cap]
-  int* vals;                // [cap]
-  int* status;              // [1] != 0: a coordinate did not fit the packed key (v3d_hash_status)
-  unsigned mask;            // cap - 1 (cap = power of two)
-};
-
-// the packed key holds 16 bits per field: batch in [0, 65535], coordinates in [-kGuard, 65535 - 2 kGuard] so that the
-// +-1 voxel probes of the neighbour tables cannot wrap either
-constexpr int kCoordMax = 65535 - 2 * kGuard;
-
-__device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
-  unsigned slot = hash_u64(key) & t.mask;
-  for (unsigned probe = 0; probe <= t.mask; ++probe) {
-    const unsigned long long k = t.keys[slot];
-    if (k == key) return t.vals[slot];
-    if (k == kEmpty) return -1;
-    slot = (slot + 1) & t.mask;
-  }
-  return -1;
-}
+using namespace v3dhash;
 
 __global__ void hash_clear_kernel(unsigned long long* keys, unsigned cap, int* status) {
   unsigned i = blockIdx.x * 256 + threadIdx.x;
@@ -137,22 +104,6 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
   }
   float* o = out + (size_t)q * ld_out + col0 + c4;
   o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
-}
-
-unsigned table_capacity(int n) {
-  unsigned cap = 64;
-  while (cap < 2u * (unsigned)(n > 0 ? n : 1)) cap <<= 1;
-  return cap;
-}
-
-HashTable table_view(void* buf, int n) {
-  HashTable t;
-  const unsigned cap = table_capacity(n);
-  t.keys = (unsigned long long*)buf;
-  t.vals = (int*)((char*)buf + (size_t)cap * 8);
-  t.status = (int*)((char*)buf + (size_t)cap * 12);
-  t.mask = cap - 1;
-  return t;
 }
 
 }  // namespace

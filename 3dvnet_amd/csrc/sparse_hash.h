@@ -1,0 +1,60 @@
+// Open-addressing hash table over packed (batch, x, y, z) sparse-tensor coordinates: device-side lookup shared by
+// sparse.hip (table build, neighbour tables, interpolation) and decoder.hip (fused hypothesis decoder).
+#pragma once
+#include "v3d_common.h"
+
+namespace v3dhash {
+
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr int kGuard = 8;   // coordinates may be probed a few voxels below zero
+
+__device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int z) {
+  return ((unsigned long long)(unsigned)(b & 0xffff) << 48) | ((unsigned long long)(unsigned)((x + kGuard) & 0xffff) << 32) |
+         ((unsigned long long)(unsigned)((y + kGuard) & 0xffff) << 16) | (unsigned long long)(unsigned)((z + kGuard) & 0xffff);
+}
+
+__device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (unsigned)k;
+}
+
+struct HashTable {          // device layout inside the caller-provided buffer
+  unsigned long long* keys; // [cap]
+  int* vals;                // [cap]
+  int* status;              // [1] != 0: a coordinate did not fit the packed key (v3d_hash_status)
+  unsigned mask;            // cap - 1 (cap = power of two)
+};
+
+// the packed key holds 16 bits per field: batch in [0, 65535], coordinates in [-kGuard, 65535 - 2 kGuard] so that the
+// +-1 voxel probes of the neighbour tables cannot wrap either
+constexpr int kCoordMax = 65535 - 2 * kGuard;
+
+__device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
+  unsigned slot = hash_u64(key) & t.mask;
+  for (unsigned probe = 0; probe <= t.mask; ++probe) {
+    const unsigned long long k = t.keys[slot];
+    if (k == key) return t.vals[slot];
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & t.mask;
+  }
+  return -1;
+}
+
+
+inline unsigned table_capacity(int n) {
+  unsigned cap = 64;
+  while (cap < 2u * (unsigned)(n > 0 ? n : 1)) cap <<= 1;
+  return cap;
+}
+
+inline HashTable table_view(void* buf, int n) {
+  HashTable t;
+  const unsigned cap = table_capacity(n);
+  t.keys = (unsigned long long*)buf;
+  t.vals = (int*)((char*)buf + (size_t)cap * 8);
+  t.status = (int*)((char*)buf + (size_t)cap * 12);
+  t.mask = cap - 1;
+  return t;
+}
+
+}  // namespace v3dhash

@@ -125,6 +125,9 @@ class PL3DVNet(nn.Module):
         if key not in self._offset_vals:      # torch.linspace on the CPU then moved, like lightningmodel.py:238-240
             self._offset_vals[key] = torch.linspace(-n * offset, n * offset, 2 * n + 1).to(depth_pred.device)
         offset_vals = self._offset_vals[key]
-        feats = self.decoder.features(xs, pts_hyp, pts_feat, pts_batch)
-        _, expect = self.decoder.decode(feats, offset_vals)
+        if self.decoder.can_fuse(xs, pts_hyp, pts_feat):
+            _, expect = self.decoder.decode_fused(xs, pts_hyp, pts_feat, pts_batch, offset_vals)
+        else:
+            feats = self.decoder.features(xs, pts_hyp, pts_feat, pts_batch)
+            _, expect = self.decoder.decode(feats, offset_vals)
         return expect.view(n_imgs, *depth_pred.shape[1:])

@@ -5,6 +5,8 @@ hash-indexed trilinear kernel, the Conv1d+BN+ReLU stack a 3-segment gather-GEMM 
 storage / accumulation, MFMA operands per ``precision``: 'split_bf16' default, 'fp32' exact), the last
 conv + softmax a per-point wave kernel.  No CPU fallback.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -27,6 +29,10 @@ class HypothesisDecoder(nn.Module):
         super().__init__()
         _lib.precision_code(precision)
         self.precision = precision
+        # True: interpolation + the three conv1d layers + head in ONE kernel (v3d_decoder_fused_f32) when the configuration
+        # allows (can_fuse).  Correct and parity-tested, but measured SLOWER than the 5-launch chain on MI355X (cfg3: 33 ms
+        # against 23 ms per scene), so it is off by default.
+        self.fused = False
         assert kernel_size == 3 and padding == 1, 'the reference instantiates k=3, pad=1 (lightningmodel.py:39-40)'
         self.in_dim, self.h_dim = in_dim, h_dim
         self.net = nn.Sequential(conv1d_bn_relu(in_dim, h_dim), conv1d_bn_relu(h_dim, h_dim),
@@ -103,7 +109,61 @@ class HypothesisDecoder(nn.Module):
         _lib.check(rc, 'v3d_decoder_head_f32')
         return preds if expect is None else (preds, expect)
 
+    def can_fuse(self, xs, pts, pts_feat):
+        """The fused kernel (v3d_decoder_fused_f32) covers the reference's configuration: three levels, 128 hidden
+        channels, level / point-feature widths that are multiples of 32, at most 8 hypotheses, split-bf16 operands."""
+        cf = 0 if pts_feat is None else pts_feat.shape[2]
+        return (self.fused and self.precision == 'split_bf16' and self.h_dim == 128 and len(xs) == 3 and pts.shape[1] <= 8
+                and cf % 32 == 0 and all(x['feats'].shape[1] % 32 == 0 for x in xs)
+                and sum(x['feats'].shape[1] for x in xs) + cf == self.in_dim)
+
+    def decode_fused(self, xs, pts, pts_feat, pts_batch, offset_vals=None):
+        """Rows C2a + C2b (+ C3) in one kernel: interpolation, the three conv1d layers, head and softmax
+        (and the expected offset when offset_vals is given); nothing of size [Nq, in_dim, n_hyp] is materialised."""
+        assert not self.training, 'inference only: BatchNorm is folded with running statistics'
+        lib = _lib.load()
+        dev = pts.device
+        self._dev = dev
+        packs, w_last, b_last = self._cache.get(self._build, dev)
+        n_pts, n_hyp = pts.shape[:2]
+        pts = pts.contiguous().float()
+        pts_batch = pts_batch.contiguous().long()
+        cf = 0
+        if pts_feat is not None:
+            pts_feat = pts_feat.contiguous().float()
+            cf = pts_feat.shape[2]
+        keep = []
+        levels = list(xs)[::-1]                      # xs is coarse -> fine; feature rows are finest first (:41)
+        for x in levels:
+            if '_min_pts' not in x:
+                nb = int(x['batch'].max().item()) + 1
+                x['_min_pts'] = torch.stack([x['pts'][x['batch'] == b].amin(dim=0) for b in range(nb)]) \
+                    if nb > 1 else x['pts'].amin(dim=0, keepdim=True)
+            keep.append((x['sparse'].table, x['feats'].contiguous(), x['_min_pts'].contiguous()))
+        vp = ctypes.c_void_p
+        layers = (vp * 3)(*[pk.handle for pk in packs])
+        tables = (vp * 3)(*[k[0].data_ptr() for k in keep])
+        n_in = (ctypes.c_int * 3)(*[x['sparse'].n for x in levels])
+        feats = (vp * 3)(*[k[1].data_ptr() for k in keep])
+        chans = (ctypes.c_int * 3)(*[k[1].shape[1] for k in keep])
+        strides = (ctypes.c_int * 3)(*[int(x['stride']) for x in levels])
+        mins = (vp * 3)(*[k[2].data_ptr() for k in keep])
+        res = (ctypes.c_float * 3)(*[float(x['res']) for x in levels])
+        preds = torch.empty((n_pts, n_hyp), dtype=torch.float32, device=dev)
+        expect = None
+        if offset_vals is not None:
+            offset_vals = offset_vals.to(dev).float().contiguous()
+            expect = torch.empty(n_pts, dtype=torch.float32, device=dev)
+        rc = lib.v3d_decoder_fused_f32(layers, w_last.data_ptr(), b_last.data_ptr(), tables, n_in, feats, chans, strides,
+                                       mins, res, pts.data_ptr(), pts_batch.data_ptr(), _lib.ptr(pts_feat), cf, n_pts,
+                                       n_hyp, _lib.ptr(offset_vals), preds.data_ptr(), _lib.ptr(expect),
+                                       _lib.stream_ptr(dev))
+        _lib.check(rc, 'v3d_decoder_fused_f32')
+        return preds if expect is None else (preds, expect)
+
     def forward(self, xs, pts, pts_feat, pts_batch):
         if not pts.is_cuda:
             raise _lib.V3DLibraryError('HypothesisDecoder: tensors must live on a HIP device (no CPU fallback)')
+        if self.can_fuse(xs, pts, pts_feat):
+            return self.decode_fused(xs, pts, pts_feat, pts_batch)
         return self.decode(self.features(xs, pts, pts_feat, pts_batch))

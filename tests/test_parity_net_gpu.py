@@ -232,3 +232,43 @@ def test_hash_build_reports_coordinates_outside_the_key_range(cuda):
     lv2 = sm.SparseLevel(bad, 1)
     assert lib.v3d_hash_status(lv2.table.data_ptr(), lv2.n, libm.stream_ptr(cuda)) == -1      # V3D_ERR_BAD_SHAPE
     assert b'packed-key range' in lib.v3d_last_error()
+
+
+# ---- fused hypothesis decoder ---------------------------------------------------------------------------
+
+def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
+    """v3d_decoder_fused_f32 (interpolation -> 3 conv1d layers -> head -> softmax -> expectation in one kernel) against the
+    5-launch chain (v3d_sparse_interp_f32 + 3 x v3d_gemm_gather_f32 + v3d_decoder_head_f32) on the C_forloop scene, with and
+    without the per-point variance feature, for a point count that is not a multiple of the 8-point tile; and against the
+    reference's own dense formulation (forward_forloop golden)."""
+    from helpers import load_golden, t
+    import test_scene_gpu as tsg
+    syn, sm, rf = v3d('synthetic'), v3d('scenemodeling'), v3d('refinement')
+    g, u = tsg._unet_inputs(cuda)
+    net = sm.SparseUNet().eval()
+    net.load_state_dict(syn.sparse_unet_weights(seed=int(g['unet_seed'])))
+    xs = net.to(cuda)(u['F'], u['pts'], u['idx'], u['batch'], float(g['edge_len']))
+    pts = t(g['pts_hyp']).to(cuda)[:667]                      # 667 = 83 tiles + 3 points
+    pts_batch = t(g['pts_batch']).to(cuda)[:667]
+    vals = torch.linspace(-0.15, 0.15, 7).to(cuda)
+    for in_dim, seed in ((320, int(g['dec_seed'])), (352, 3)):
+        dec = rf.HypothesisDecoder(in_dim, 128, 3, 1).eval()
+        dec.load_state_dict(syn.decoder_weights(in_dim=in_dim, h_dim=128, seed=seed, sharpen=float(g['sharpen'])),
+                            strict=False)
+        dec = dec.to(cuda)
+        dec.fused = True                                        # opt-in path (off by default: slower than the chain)
+        pf = None if in_dim == 320 else torch.rand((667, 7, 32), generator=torch.Generator().manual_seed(1)).to(cuda) * 0.1
+        assert dec.can_fuse(xs, pts, pf)
+        p_f, e_f = dec.decode_fused(xs, pts, pf, pts_batch, vals)
+        p_f2, _ = dec.decode_fused(xs, pts, pf, pts_batch, vals)
+        assert torch.equal(p_f, p_f2)                           # deterministic (one workgroup per CU, see decoder.hip)
+        p_u, e_u = dec.decode(dec.features(xs, pts, pf, pts_batch), vals)
+        torch.cuda.synchronize()
+        assert float(p_u.max()) > 0.5                      # peaked softmax: the comparison is not vacuous
+        np.testing.assert_allclose(p_f.cpu().numpy(), p_u.cpu().numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(e_f.cpu().numpy(), e_u.cpu().numpy(), rtol=0, atol=2e-5)
+        if in_dim == 320:
+            np.testing.assert_allclose(p_f.cpu().numpy(), g['preds'][:667], rtol=0, atol=2e-4)
+        dec.fused = False
+        assert not dec.can_fuse(xs, pts, pf)
+        assert torch.equal(dec(xs, pts, pf, pts_batch), p_u)
