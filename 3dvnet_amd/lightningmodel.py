@@ -55,6 +55,12 @@ class PL3DVNet(nn.Module):
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
         ('split_bf16' | 'fp32') selects the MFMA operand precision of every matrix-core kernel (include/v3d.h)."""
         super().__init__()
+        if feat_dim != 32:
+            # the reference's signature default is 16, but its config (mv3d/config.py:42) and every released checkpoint use
+            # 32; the HIP kernels are specialised for that: the sparse U-Net's fused GroupNorm epilogue needs 16-channel
+            # groups (2*feat_dim / 4 groups), the split variance hand-off and the plane-reuse warp kernel need C = 32
+            raise ValueError('PL3DVNet: feat_dim=%d is not supported by the HIP path (only feat_dim=32, the value of '
+                             'mv3d/config.py:42)' % feat_dim)
         if backbone and feat_extractor is None:
             from .backbone import build_backbone
             feat_extractor, feat_shrinker = build_backbone(feat_dim)

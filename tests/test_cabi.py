@@ -75,3 +75,12 @@ def test_edges_to_csr_matches_unique_semantics():
     assert ref_idx.tolist() == [2, 5, 9]
     assert ofs.tolist() == [0, 2, 5, 6]
     assert src.tolist() == [1, 3, 0, 2, 5, 4]
+
+
+def test_pl3dvnet_rejects_unsupported_feat_dim():
+    """The reference's signature default feat_dim=16 is not what its config uses (32, mv3d/config.py:42); the HIP path
+    supports 32 only and says so at construction time instead of failing on an assert deep inside SparseUNet."""
+    lm = v3d('lightningmodel')
+    with pytest.raises(ValueError, match='feat_dim'):
+        lm.PL3DVNet(None, {'size': (8, 8)}, 0.08)
+    assert lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=32).sparse_conv.dims == (64, 128, 128)
