@@ -476,9 +476,16 @@ struct C0 {
   static constexpr int NITS = (SROWS + 7) / 8;               // 8 lane groups of 32 lanes per iteration
   static constexpr int WU32 = 9 * 2 * 64 * 4;                // weight words per chunk (hi + lo fragments)
   static constexpr int NWIT = WU32 / 256;                    // 18
-  static constexpr size_t LDS_BYTES = (size_t)NVOXI * 16 * 2 + (size_t)WU32 * 4 + 2 * 64 * 4;
+  static constexpr size_t LDS_BYTES = (size_t)NVOXI * 16 * 2 + (size_t)WU32 * 4 + 3 * 64 * 4;
   static_assert(WU32 % 256 == 0, "geometry");
 };
+
+// cond ? a : b as a bit select (v_bfi_b32): written with ?: on two arrays the compiler turns the pair into a private array
+// indexed by the lane, i.e. scratch memory and a vector load the epilogue then has to wait for.
+__device__ __forceinline__ float lane_select(int cond, float a, float b) {
+  const unsigned m = 0u - (unsigned)(cond != 0);
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {
   unsigned u = __float_as_uint(x);
@@ -491,6 +498,15 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 // ([n][hi, lo][D][H][W] 16-byte slots) consumed by convh_bf16x2_kernel (conv1) and conv9_prob_kernel (skip).
 // NW = waves per workgroup (4 or 8): with 8, a wave owns one output row of the 4 planes and a CU holds 4 waves per SIMD
 // (2 workgroups), so one wave's LDS / barrier waits are covered by another's MFMAs.
+#ifndef V3D_C0_ABLATE
+#define V3D_C0_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no MFMAs (0.82 ms), 2 no input loads (0.84), 3 no LDS commit (0.97), 4 no output stores (1.06), 5 stores into a 2 MB window (1.07), 6 loads from a 1 MB window (1.02); full kernel 1.09 ms per 64 views
+#endif
+// PERSISTENT: the grid is (at most) the number of workgroups the chip holds at once; a workgroup walks tiles
+// first + i, first + i + G, ... of its XCD's contiguous run (v3d::xcd_tile_walk), and the chunk pipeline runs straight across
+// tile boundaries: the first chunk of the next tile is requested during the last MFMA phase of the current one, and the
+// output stores of a tile drain while the next tile is already being staged.  Measured equal to one tile per workgroup
+// (1.09 vs 1.11 ms per 64 views, -DV3D_C0_ONE_TILE): the kernel is bound by the per-chunk chain load -> commit -> barrier ->
+// MFMA with one chunk of prefetch (registers) and a single LDS buffer (ablations at V3D_C0_ABLATE), not by tile turnover.
 template <bool SPLIT_IN, bool SPLIT_OUT, int NW>
 __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvParams p) {
   constexpr int NT = 64 * NW, RPI = NT / 32, RPW = C0::TH / NW;      // threads, staging rows per iteration, rows per wave
@@ -498,30 +514,40 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);                           // [NVOXI] hi slots
   u32x4* const xl = xh + C0::NVOXI;                                           // [NVOXI] lo slots
   unsigned* const wsu = reinterpret_cast<unsigned*>(xl + C0::NVOXI);          // [WU32] weight fragments
-  int* const rowg = reinterpret_cast<int*>(wsu + C0::WU32);                   // [64] global offset of a spatial row
-  int* const rowd = rowg + 64;                                                // [64] first voxel of the row in the tile
+  int* const rowd = reinterpret_cast<int*>(wsu + C0::WU32);                   // [64] first voxel of a spatial row in the tile
+  int* const rowg2 = rowd + 64;                                               // [2][64] global offset of the row, per tile parity
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
-  int b = v3d::xcd_contiguous_block();     // neighbouring tiles (shared halo) on the same XCD's L2
-  const int tx = b % p.ntx; b /= p.ntx;
-  const int ty = b % p.nty; b /= p.nty;
-  const int tz = b % p.ntz;
-  const int n = b / p.ntz;
-  const int oz0 = tz * C0::TD, oy0 = ty * C0::TH, ox0 = tx * C0::TW;
-  const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
   const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
-  const float* inb = p.in + (size_t)n * 32 * in_plane;
   constexpr int kRowOob = -2147483647 - 1;
 
+  struct Tile { int n, oz0, oy0, ox0; };
+  auto decode = [&](int t) __attribute__((always_inline)) {
+    Tile q;
+    const int tx = t % p.ntx; t /= p.ntx;
+    const int ty = t % p.nty; t /= p.nty;
+    q.oz0 = (t % p.ntz) * C0::TD; q.n = t / p.ntz;
+    q.oy0 = ty * C0::TH; q.ox0 = tx * C0::TW;
+    return q;
+  };
+  auto fill_rows = [&](const Tile& q, int par) __attribute__((always_inline)) {
+    if (tid < 64) {
+      const int rz = tid / C0::IH, ry = tid % C0::IH;
+      const int gz = q.oz0 - 1 + rz, gy = q.oy0 - 1 + ry;
+      const bool ok = tid < C0::SROWS && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
+      rowg2[par * 64 + tid] = ok ? (gz * p.Hi + gy) * p.Wi + q.ox0 - 1 : kRowOob;
+    }
+  };
+  const v3d::TileWalk walk = v3d::xcd_tile_walk(p.n * p.ntz * p.nty * p.ntx);   // neighbouring tiles (shared halo) on one XCD's L2
+  if (walk.t >= walk.end) return;
+  Tile cur = decode(walk.t);
   if (tid < 64) {
     const int rz = tid / C0::IH, ry = tid % C0::IH;
-    const int gz = iz0 + rz, gy = iy0 + ry;
-    const bool ok = tid < C0::SROWS && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
-    rowg[tid] = ok ? (gz * p.Hi + gy) * p.Wi + ix0 : kRowOob;
     rowd[tid] = tid < C0::SROWS ? (rz * C0::IH + ry) * C0::IW : -1;
   }
+  fill_rows(cur, 0);
   __syncthreads();
 
   // MFMA role: wave w owns output rows y = 2w, 2w+1 for all TD planes; one column block = the 14 x pairs of a row
@@ -529,40 +555,39 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
   static_assert(C0::TH == 8 && C0::TW == 28, "wave -> row mapping");
   constexpr int NACC = C0::TD * RPW;
   f32x4 acc[NACC];
-#pragma unroll
-  for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // staging role: 32 lanes = x of one spatial row, 8 rows per iteration, 8 channels per lane
   const int grp = tid >> 5, lx = tid & 31;
-  const int sgx = ix0 + lx;
   const bool xok = lx < C0::IW;
-  const bool xin = xok && sgx >= 0 && sgx < p.Wi;
   constexpr int NITS_S = (2 * C0::SROWS + RPI - 1) / RPI;       // split input: 60 hi rows then 60 lo rows
   constexpr int NITS_F = (C0::SROWS + RPI - 1) / RPI;           // fp32 input: 60 rows x 8 channels
   constexpr int NWQ = (C0::WU32 / 4 + NT - 1) / NT;             // 16-byte weight loads per thread
   float pre[SPLIT_IN ? 1 : NITS_F][C0::CG];
   u32x4 pres[SPLIT_IN ? NITS_S : 1];
   u32x4 wreg[NWQ];
-  const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * 8 * in_plane + lx;
   // The loads of the next chunk are issued in three parts between the MFMA groups of the current chunk: the
   // vector-memory pipe takes ~16 cycles per 1 KB instruction, which would otherwise stall the wave in front of
   // its MFMAs for the whole batch (measured 3.3k cycles per chunk).
-  auto issue_part = [&](int chunk, auto part_c) __attribute__((always_inline)) {
+  auto issue_part = [&](const Tile& q, int par, int chunk, auto part_c) __attribute__((always_inline)) {
     constexpr int part = decltype(part_c)::value;
+    const int* const rowg = rowg2 + par * 64;
+    const int sgx = q.ox0 - 1 + lx;
+    const bool xin = xok && sgx >= 0 && sgx < p.Wi;
     if constexpr (SPLIT_IN) {
+      const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)q.n * 8 * in_plane + lx;
       constexpr int per = (NITS_S + 2) / 3;
 #pragma unroll
       for (int it = part * per; it < (part + 1) * per && it < NITS_S; ++it) {
         const int rr = it * RPI + grp;
         const int hl = rr >= C0::SROWS ? 1 : 0;
         const int g = rowg[rr - hl * C0::SROWS];               // rows 60..63 of the table are out of range
-        pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin)
-                       ? __builtin_nontemporal_load(ins + (size_t)(chunk * 2 + hl) * in_plane + g)
+        pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin && V3D_C0_ABLATE != 2)
+                       ? __builtin_nontemporal_load(ins + (V3D_C0_ABLATE == 6 ? (size_t)(g & 0xffff) : (size_t)(chunk * 2 + hl) * in_plane + g))
                        : (u32x4){0u, 0u, 0u, 0u};
       }
     } else {
       constexpr int per = (NITS_F + 2) / 3;
-      const float* inc = inb + (size_t)chunk * C0::CG * in_plane + lx;
+      const float* inc = p.in + ((size_t)q.n * 32 + (size_t)chunk * C0::CG) * in_plane + lx;
 #pragma unroll
       for (int it = part * per; it < (part + 1) * per && it < NITS_F; ++it) {
         const int g = rowg[min(it * RPI + grp, 63)];
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
       for (int it = 0; it < NITS_S; ++it) {
         const int rr = it * RPI + grp;
         const int hl = rr >= C0::SROWS ? 1 : 0;
-        if (rr < 2 * C0::SROWS && xok) (hl ? xl : xh)[rowd[rr - hl * C0::SROWS] + lx] = pres[it];
+        if (rr < 2 * C0::SROWS && xok && (V3D_C0_ABLATE != 3 || pres[it][0] == 0x12345u)) (hl ? xl : xh)[rowd[rr - hl * C0::SROWS] + lx] = pres[it];
       }
     } else {
 #pragma unroll
@@ -640,109 +665,133 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
     }
   };
 
-  PHASE_DECL;
-  issue_part(0, std::integral_constant<int, 0>{});
-  issue_part(0, std::integral_constant<int, 1>{});
-  issue_part(0, std::integral_constant<int, 2>{});
-  PHASE_MARK(0);
-#pragma unroll 1
-  for (int chunk = 0; chunk < C0::NCH; ++chunk) {
-    __syncthreads();
-    PHASE_MARK(1);
-    commit();
-    PHASE_MARK(2);
-    __syncthreads();
-    PHASE_MARK(3);
-    const bool more = chunk + 1 < C0::NCH;
-    if (more) issue_part(chunk + 1, std::integral_constant<int, 0>{});
-    mfma_ky(0);
-    if (more) issue_part(chunk + 1, std::integral_constant<int, 1>{});
-    mfma_ky(1);
-    if (more) issue_part(chunk + 1, std::integral_constant<int, 2>{});
-    mfma_ky(2);
-    PHASE_MARK(5);
-  }
+  // The bias reaches the epilogue through SGPRs: a per-lane vector load there makes the compiler wait for vmcnt(0) in front
+  // of every conditionally stored accumulator, i.e. for the next tile's prefetch and for the stores just issued.
+  float sbias[8];                          // wave-uniform addresses: scalar loads, eight SGPRs for the whole kernel
+#pragma unroll
+  for (int r = 0; r < 8; ++r) sbias[r] = p.bias[r];
 
-  // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1: lane (kq, jn) holds channels 4 (kq & 1) .. +3 of voxel
-  // x = 2 jn + (kq >> 1).
-  if constexpr (SPLIT_OUT) {
-    // split layout: those 4 channels are one 8-byte half of the voxel's hi slot and of its lo slot; the 4 lane
-    // quarters of a wave instruction cover 16 x 2 consecutive slots completely -> direct stores, no LDS round trip
-    const size_t out_plane_s = (size_t)p.Do * p.Ho * p.Wo;
-    const int sx = kq >> 1, cbase = 4 * (kq & 1);
-    float bias[4];
+  PHASE_DECL;
+  issue_part(cur, 0, 0, std::integral_constant<int, 0>{});
+  issue_part(cur, 0, 0, std::integral_constant<int, 1>{});
+  issue_part(cur, 0, 0, std::integral_constant<int, 2>{});
+  PHASE_MARK(0);
+  int par = 0;
+#pragma unroll 1
+  for (int t = walk.t; t < walk.end; t += walk.step, par ^= 1) {
+    const int tn = t + walk.step;
+    const bool has_next = tn < walk.end;
+    const Tile nxt = decode(has_next ? tn : t);
+    // the row table of the next tile: written now, first read in the MFMA phase of this tile's last chunk (several barriers
+    // later); its previous content (tile t - step) was last read in tile t - step's chunk 2
+    if (has_next) fill_rows(nxt, par ^ 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
-    u32x2* const outs = reinterpret_cast<u32x2*>(p.out) + ((size_t)n * 2 * out_plane_s) * 2 + (kq & 1);
-    const int gx = ox0 + 2 * jn + sx;
-    if (jn < C0::TW / 2 && gx < p.Wo) {
-#pragma unroll
-      for (int j = 0; j < NACC; ++j) {
-        const int gz = oz0 + j / RPW, gy = oy0 + wave * RPW + j % RPW;
-        if (gz >= p.Do || gy >= p.Ho) continue;
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float val = acc[j][r] + bias[r];
-          if (p.relu) val = fmaxf(val, 0.f);
-          h[r] = bf16_rne(val);
-          l[r] = bf16_rne(val - __uint_as_float(h[r] << 16));
-        }
-        const size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-        outs[sp * 2] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        outs[(out_plane_s + sp) * 2] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
-      }
+    for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int chunk = 0; chunk < C0::NCH; ++chunk) {
+      __syncthreads();
+      PHASE_MARK(1);
+      commit();
+      PHASE_MARK(2);
+      __syncthreads();
+      PHASE_MARK(3);
+      const bool last = chunk + 1 == C0::NCH;
+      const bool more = !last || has_next;
+      const Tile& lt = last ? nxt : cur;                  // tile / table / chunk the next staging round belongs to
+      const int lpar = last ? par ^ 1 : par, lchunk = last ? 0 : chunk + 1;
+      if (more) issue_part(lt, lpar, lchunk, std::integral_constant<int, 0>{});
+      if (V3D_C0_ABLATE != 1) mfma_ky(0);
+      if (more) issue_part(lt, lpar, lchunk, std::integral_constant<int, 1>{});
+      if (V3D_C0_ABLATE != 1) mfma_ky(1);
+      if (more) issue_part(lt, lpar, lchunk, std::integral_constant<int, 2>{});
+      if (V3D_C0_ABLATE != 1) mfma_ky(2);
+      PHASE_MARK(5);
     }
-    PHASE_MARK(6);
-    PHASE_FLUSH;
-    return;
-  }
-  // fp32 output: the tile goes through LDS ([co][z][y][28 x], co stride padded by 4 floats against bank conflicts)
-  // so that it leaves as 16-byte row segments instead of 32 4-byte stores per lane.
-  constexpr int OCS = C0::TD * C0::TH * C0::TW + 4;
-  float* const os = reinterpret_cast<float*>(smem);
-  __syncthreads();                 // every wave is done reading the input tile
-  {
-    const int sx = kq >> 1, cbase = 4 * (kq & 1);
-    float bias[4];
+
+    // epilogue: rows 0-7 = x shift 0, rows 8-15 = x shift 1: lane (kq, jn) holds channels 4 (kq & 1) .. +3 of voxel
+    // x = 2 jn + (kq >> 1).
+    const int n = cur.n, oz0 = cur.oz0, oy0 = cur.oy0, ox0 = cur.ox0;
+    if constexpr (SPLIT_OUT) {
+      // split layout: those 4 channels are one 8-byte half of the voxel's hi slot and of its lo slot; the 4 lane
+      // quarters of a wave instruction cover 16 x 2 consecutive slots completely -> direct stores, no LDS round trip
+      const size_t out_plane_s = (size_t)p.Do * p.Ho * p.Wo;
+      const int sx = kq >> 1;
+      float bias[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
-    if (jn < C0::TW / 2) {
+      for (int r = 0; r < 4; ++r) bias[r] = lane_select(kq & 1, sbias[4 + r], sbias[r]);
+      int half = kq & 1;
+      asm volatile("" : "+v"(half));      // keeps this per-lane 64-bit base out of the tile loop's live registers (it was spilled)
+      u32x2* const outs = reinterpret_cast<u32x2*>(p.out) + ((size_t)n * 2 * out_plane_s) * 2 + half;
+      const int gx = ox0 + 2 * jn + sx;
+      if (jn < C0::TW / 2 && gx < p.Wo) {
 #pragma unroll
-      for (int j = 0; j < NACC; ++j) {
-        const int row = (j / RPW) * C0::TH + wave * RPW + j % RPW;
+        for (int j = 0; j < NACC; ++j) {
+          const int gz = oz0 + j / RPW, gy = oy0 + wave * RPW + j % RPW;
+          if (gz >= p.Do || gy >= p.Ho) continue;
+          unsigned h[4], l[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float val = acc[j][r] + bias[r];
-          if (p.relu) val = fmaxf(val, 0.f);
-          os[(cbase + r) * OCS + row * C0::TW + 2 * jn + sx] = val;
+          for (int r = 0; r < 4; ++r) {
+            float val = acc[j][r] + bias[r];
+            if (p.relu) val = fmaxf(val, 0.f);
+            h[r] = bf16_rne(val);
+            l[r] = bf16_rne(val - __uint_as_float(h[r] << 16));
+          }
+          size_t sp = ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+          if (V3D_C0_ABLATE == 4 && p.relu != 12345) continue;        // everything computed, nothing stored (runtime-false guard)
+          if (V3D_C0_ABLATE == 5) sp &= 0xffff;                       // every store lands in a 2 MB window (L2-resident)
+          outs[sp * 2] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+          outs[(out_plane_s + sp) * 2] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
         }
       }
-    }
-  }
-  __syncthreads();
-  const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
-  {
-  constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
-#pragma unroll
-  for (int k = 0; k < (NQ + NT - 1) / NT; ++k) {
-    const int i = k * NT + tid;
-    if (i >= NQ) break;
-    const int co = i / (C0::TD * C0::TH * QPR), rem = i % (C0::TD * C0::TH * QPR);
-    const int row = rem / QPR, q = rem % QPR;
-    const int gz = oz0 + row / C0::TH, gy = oy0 + row % C0::TH, gx = ox0 + 4 * q;
-    if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C0::TW + 4 * q);
-    const size_t o = ((size_t)n * 8 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-    if (gx + 3 < p.Wo && (p.Wo & 3) == 0) {
-      if (p.skip) { const f32x4 sk = *reinterpret_cast<const f32x4*>(p.skip + o); v += sk; }
-      *reinterpret_cast<f32x4*>(p.out + o) = v;
+      PHASE_MARK(6);
     } else {
-      for (int e = 0; e < 4 && gx + e < p.Wo; ++e) p.out[o + e] = v[e] + (p.skip ? p.skip[o + e] : 0.f);
+      // fp32 output: the tile goes through LDS ([co][z][y][28 x], co stride padded by 4 floats against bank conflicts)
+      // so that it leaves as 16-byte row segments instead of 32 4-byte stores per lane.
+      constexpr int OCS = C0::TD * C0::TH * C0::TW + 4;
+      float* const os = reinterpret_cast<float*>(smem);
+      __syncthreads();                 // every wave is done reading the input tile
+      {
+        const int sx = kq >> 1, cbase = 4 * (kq & 1);
+        float bias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = lane_select(kq & 1, sbias[4 + r], sbias[r]);
+        if (jn < C0::TW / 2) {
+#pragma unroll
+          for (int j = 0; j < NACC; ++j) {
+            const int row = (j / RPW) * C0::TH + wave * RPW + j % RPW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float val = acc[j][r] + bias[r];
+              if (p.relu) val = fmaxf(val, 0.f);
+              os[(cbase + r) * OCS + row * C0::TW + 2 * jn + sx] = val;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+      constexpr int QPR = C0::TW / 4, NQ = 8 * C0::TD * C0::TH * QPR;      // float4 per row, per tile
+#pragma unroll
+      for (int k = 0; k < (NQ + NT - 1) / NT; ++k) {
+        const int i = k * NT + tid;
+        if (i >= NQ) break;
+        const int co = i / (C0::TD * C0::TH * QPR), rem = i % (C0::TD * C0::TH * QPR);
+        const int row = rem / QPR, q = rem % QPR;
+        const int gz = oz0 + row / C0::TH, gy = oy0 + row % C0::TH, gx = ox0 + 4 * q;
+        if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C0::TW + 4 * q);
+        const size_t o = ((size_t)n * 8 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+        if (gx + 3 < p.Wo && (p.Wo & 3) == 0) {
+          if (p.skip) { const f32x4 sk = *reinterpret_cast<const f32x4*>(p.skip + o); v += sk; }
+          *reinterpret_cast<f32x4*>(p.out + o) = v;
+        } else {
+          for (int e = 0; e < 4 && gx + e < p.Wo; ++e) p.out[o + e] = v[e] + (p.skip ? p.skip[o + e] : 0.f);
+        }
+      }
+      PHASE_MARK(6);
     }
+    cur = nxt;
   }
-  }
-  PHASE_MARK(6);
   PHASE_FLUSH;
 }
 
@@ -1269,11 +1318,23 @@ struct C9Params {
   int n, D, H, W, ntz, nty, ntx;
 };
 
-__global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
+// 8 waves per workgroup, <= 128 VGPRs: two workgroups = 16 waves per CU (round 1's 4-wave version needed 218 VGPRs, i.e.
+// 8 waves per CU, and spent most of its time waiting for its own loads, barriers and LDS round trips: 0.55 -> 0.45 ms).  The weight fragments
+// are parked in LDS next to the input tile (both are dead before the u9 tile overwrites them) instead of 72 registers, a
+// wave owns two of the 15 cell rows in the deconvolution, and in the prob conv a lane owns two consecutive outputs so that
+// the 16 lanes of a row read 16 consecutive 16-byte slots (conflict-free; the 4-outputs-per-lane mapping read at a 32-byte
+// lane stride: 2-way conflicts on every read).  Accumulation orders are those of the 4-wave kernel: bit-identical output.
+#ifndef V3D_C9_ABLATE
+#define V3D_C9_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no prob loop, 2 one channel pair only, 3 no MFMAs, 4 no skip loads, 5 no input loads
+#endif
+__global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[C9::LDS_BYTES];
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);             // [NVOX][2 halves] hi slots
   u32x4* const xl = xh + C9::NVOX * 2;                          // lo slots
+  u32x4* const wfr = xl + C9::NVOX * 2;                         // [9 blocks][hi, lo][64 lanes] weight fragments
   float* const u9s = reinterpret_cast<float*>(smem);            // [8][HD][HH][RS], reuses the input tile
+  static_assert(C9::IN_BYTES + C9::WU32 * 4 <= C9::U9_BYTES, "input tile + weight fragments share the u9 region");
+  constexpr int NT = 512, NCBI = 2;                             // threads, cell rows per wave (15 rows over 8 waves)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1290,88 +1351,82 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
   const size_t out_plane = (size_t)p.D * p.H * p.W;
 
   PHASE_DECL;
-  // ---- global reads are requested in batches with clamped addresses (no branches): (a) the 4 x 6 x 16 x 16ch
-  // input tile and the weight fragments now; vmcnt can track 63 loads, so the skip values follow after staging
-  // u8 arrives in the split channel-last layout ([n][2 groups][hi, lo][D/2][H/2][W/2] slots): 2 x 2 x 384 slots, six
-  // 16-byte copies per thread
-  u32x4 pre[6];
+  // ---- global reads with clamped addresses (no branches): (a) the 4 x 6 x 16 x 16ch input tile ([n][2 groups][hi, lo]
+  // [D/2][H/2][W/2] slots: 2 x 2 x 384 slots, three 16-byte copies per thread) and the weight fragments
+  u32x4 pre[3], wpre[3];
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.u8) + (size_t)n * 4 * in_plane;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int it = tid + 256 * i;
+    for (int i = 0; i < 3; ++i) {
+      const int it = tid + NT * i;
       const int gp = it / 384, vox = it % 384;                       // gp = group * 2 + part
       const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
       const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
       const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
       const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1), xc = min(max(gx, 0), W2 - 1);
-      const u32x4 val = src[(size_t)gp * in_plane + ((size_t)zc * H2 + yc) * W2 + xc];
+      const u32x4 val = V3D_C9_ABLATE == 5 ? (u32x4){1u, 2u, 3u, (unsigned)tid} : src[(size_t)gp * in_plane + ((size_t)zc * H2 + yc) * W2 + xc];
       pre[i] = ok ? val : (u32x4){0u, 0u, 0u, 0u};
     }
-  }
-  // weight fragments stay in registers: block (tz3, ty3), tz3 = {(pz 0, dz 0), (0, 1), (1, 1)} likewise ty3
-  bf16x8 a_hi[9], a_lo[9];
-  {
-    const u32x4* wq = reinterpret_cast<const u32x4*>(p.wbf) + lane;
+    const u32x4* wq = reinterpret_cast<const u32x4*>(p.wbf);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      a_hi[i] = __builtin_bit_cast(bf16x8, wq[(i * 2) * 64]);
-      a_lo[i] = __builtin_bit_cast(bf16x8, wq[(i * 2 + 1) * 64]);
-    }
-  }
-
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- stage the input tile: slot = voxel * 2 + channel half (group), hi and lo arrays -----------------------------
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int it = tid + 256 * i;
-    const int gp = it / 384, vox = it % 384;
-    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + (gp >> 1);
-    ((gp & 1) ? xl : xh)[slot] = pre[i];
-  }
-  if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
-    const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
-    xh[slot] = (u32x4){0u, 0u, 0u, 0u};
-    xl[slot] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = 0; i < 3; ++i) wpre[i] = wq[min(tid + NT * i, C9::WU32 / 4 - 1)];
   }
   __builtin_amdgcn_sched_barrier(0);
-  // (b) the conv0 skip values of this lane's 64 outputs, in flight during the MFMA phase.  conv0's output is in the
-  // split channel-last layout ([n][hi, lo][D][H][W] slots of 8 channels): channels cbase..cbase+3 are 8 bytes of the hi
+  // (b) the conv0 skip values of this lane's outputs, in flight during staging and the MFMA phase.  conv0's output is in
+  // the split channel-last layout ([n][hi, lo][D][H][W] slots of 8 channels): channels cbase..cbase+3 are 8 bytes of the hi
   // slot and 8 bytes of the lo slot
   const int px = kq >> 1, cbase = 4 * (kq & 1);
-  u32x2 skh[4][4], skl[4][4];
+  u32x2 skh[NCBI][4], skl[NCBI][4];
   {
     const u32x2* skip = reinterpret_cast<const u32x2*>(p.c0) + ((size_t)n * 2 * out_plane) * 2 + (kq & 1);
 #pragma unroll
-    for (int cbi = 0; cbi < 4; ++cbi) {
-      const int cb = min(wave + 4 * cbi, C9::NCB - 1);
+    for (int cbi = 0; cbi < NCBI; ++cbi) {
+      const int cb = min(wave + 8 * cbi, C9::NCB - 1);
       const int cz = cb / C9::CY, cy = cb % C9::CY;
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
         const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
         const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
-        skh[cbi][rb] = skip[sp * 2];
-        skl[cbi][rb] = skip[(out_plane + sp) * 2];
+        skh[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){(unsigned)sp, 1u} : skip[sp * 2];
+        skl[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){(unsigned)sp, 2u} : skip[(out_plane + sp) * 2];
       }
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- stage the input tile (slot = voxel * 2 + channel half (group), hi and lo arrays) and the weight fragments ------
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int it = tid + NT * i;
+    const int gp = it / 384, vox = it % 384;
+    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + (gp >> 1);
+    ((gp & 1) ? xl : xh)[slot] = pre[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (tid + NT * i < C9::WU32 / 4) wfr[tid + NT * i] = wpre[i];
+  if (tid < C9::VZ * C9::VY * 2) {         // the idle 17th voxel of every row is read by column 15: keep it finite
+    const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
+    xh[slot] = (u32x4){0u, 0u, 0u, 0u};
+    xl[slot] = (u32x4){0u, 0u, 0u, 0u};
   }
   PHASE_MARK(0);
   __syncthreads();
   PHASE_MARK(1);
 
-  // ---- deconvolution: wave w owns cell rows w, w+4, w+8, w+12 --------------------------------------------
-  f32x4 acc[4][4];
+  // ---- deconvolution: wave w owns cell rows w and w + 8; weight block (tz3, ty3), tz3 = {(pz 0, dz 0), (0, 1), (1, 1)},
+  // likewise ty3 -------------------------------------------------------------------------------------------------------
+  f32x4 acc[NCBI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NCBI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int cbi = 0; cbi < 4; ++cbi) {
-    const int cb = wave + 4 * cbi;
-    if (cb < C9::NCB) {
+  for (int cbi = 0; cbi < NCBI; ++cbi) {
+    const int cb = wave + 8 * cbi;
+    if (cb < C9::NCB && V3D_C9_ABLATE != 3) {
       const int cz = cb / C9::CY, cy = cb % C9::CY;
 #pragma unroll
       for (int dz = 0; dz < 2; ++dz)
@@ -1386,17 +1441,19 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
             for (int py = 0; py < 2; ++py) {
               if ((pz == 0 || dz == 1) && (py == 0 || dy == 1)) {
                 const int blk = (pz == 1 ? 2 : dz) * 3 + (py == 1 ? 2 : dy);
+                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, wfr[(blk * 2) * 64 + lane]);
+                const bf16x8 a_lo = __builtin_bit_cast(bf16x8, wfr[(blk * 2 + 1) * 64 + lane]);
                 f32x4& c = acc[cbi][pz * 2 + py];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[blk], b_hi, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[blk], b_lo, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[blk], b_hi, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, c, 0, 0, 0);
               }
             }
         }
     }
   }
   PHASE_MARK(2);
-  __syncthreads();      // the input tile is dead: its LDS becomes the u9 tile
+  __syncthreads();      // the input tile and the weight fragments are dead: their LDS becomes the u9 tile
   PHASE_MARK(3);
 
   // ---- BN bias + ReLU + conv0 skip -> u9 tile (zero outside the volume = the prob conv's padding) ------------
@@ -1407,8 +1464,8 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = p.bias9[cbase + r];
 #pragma unroll
-    for (int cbi = 0; cbi < 4; ++cbi) {
-      const int cb = wave + 4 * cbi;
+    for (int cbi = 0; cbi < NCBI; ++cbi) {
+      const int cb = wave + 8 * cbi;
       if (cb < C9::NCB && jn < C9::CX) {
         const int cz = cb / C9::CY, cy = cb % C9::CY;
 #pragma unroll
@@ -1436,44 +1493,41 @@ __global__ __launch_bounds__(256, 2) void conv9_prob_kernel(C9Params p) {
   __syncthreads();
   PHASE_MARK(5);
 
-  // ---- prob conv: thread = (z = wave, y, 4 consecutive x); both channels of a pair per packed FMA -------------
+  // ---- prob conv: wave = (z plane, y half), lane = (y of 4, 2 consecutive x); both channels of a pair per packed FMA --
+  // (a register-ring software pipeline of the LDS reads over the 12 (pair, kz) stages measured the same 0.45 ms: this
+  // phase costs 0.11 ms of the kernel, the rest is the chain loads -> staging -> MFMA -> u9 tile)
   {
-    const int y = lane >> 3, xg = lane & 7;
-    if (xg < C9::TW / 4) {
-      f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f}, o2 = {0.f, 0.f}, o3 = {0.f, 0.f};
+    const int z = wave >> 1, y = (wave & 1) * 4 + (lane >> 4), xp = lane & 15;
+    if (xp < C9::TW / 2) {
+      f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
       const f32x2* wp2 = reinterpret_cast<const f32x2*>(p.wprob);       // [4 pairs][27 taps][2]
 #pragma unroll 1
-      for (int cp = 0; cp < 4; ++cp) {
+      for (int cp = 0; cp < (V3D_C9_ABLATE == 1 ? 0 : V3D_C9_ABLATE == 2 ? 1 : 4); ++cp) {
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const f32x2* row = reinterpret_cast<const f32x2*>(u9s) +
-                               (cp * (C9::HD * C9::HH) + (wave + kz) * C9::HH + (y + ky)) * C9::RS + 4 * xg;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 2),
-                        q2 = *reinterpret_cast<const f32x4*>(row + 4);
-            const f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w},
-                        a4 = {q2.x, q2.y}, a5 = {q2.z, q2.w};
+                               (cp * (C9::HD * C9::HH) + (z + kz) * C9::HH + (y + ky)) * C9::RS + 2 * xp;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 2);
+            const f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w};
             const f32x2* wk = wp2 + (cp * 27 + (kz * 3 + ky) * 3);           // wave-uniform -> s_load
             const f32x2 w0 = wk[0], w1 = wk[1], w2 = wk[2];
             o0 += a0 * w0; o0 += a1 * w1; o0 += a2 * w2;
             o1 += a1 * w0; o1 += a2 * w1; o1 += a3 * w2;
-            o2 += a2 * w0; o2 += a3 * w1; o2 += a4 * w2;
-            o3 += a3 * w0; o3 += a4 * w1; o3 += a5 * w2;
           }
         }
       }
-      const int gz = oz0 + wave, gy = oy0 + y, gx = ox0 + 4 * xg;
+      const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + 2 * xp;
       if (gz < p.D && gy < p.H && gx < p.W) {
         const float bsv = p.bprob[0];
-        const f32x4 res = {o0.x + o0.y + bsv, o1.x + o1.y + bsv, o2.x + o2.y + bsv, o3.x + o3.y + bsv};
+        const f32x2 res = {o0.x + o0.y + bsv, o1.x + o1.y + bsv};
         float* o = p.out + (size_t)n * out_plane + ((size_t)gz * p.H + gy) * p.W + gx;
-        if (gx + 3 < p.W) {
-          *reinterpret_cast<f32x4*>(o) = res;
+        if (gx + 1 < p.W && (p.W & 1) == 0) {
+          *reinterpret_cast<f32x2*>(o) = res;
         } else {
           o[0] = res.x;
           if (gx + 1 < p.W) o[1] = res.y;
-          if (gx + 2 < p.W) o[2] = res.z;
         }
       }
     }
@@ -1624,10 +1678,15 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-    if (split_in && split_out) conv0_bf16x2_kernel<true, true, kC0Waves><<<(unsigned)blocks, 64 * kC0Waves, C0::LDS_BYTES, s>>>(p);
-    else if (split_in) conv0_bf16x2_kernel<true, false, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else if (split_out) conv0_bf16x2_kernel<false, true, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
-    else conv0_bf16x2_kernel<false, false, 4><<<(unsigned)blocks, 256, C0::LDS_BYTES, s>>>(p);
+#ifdef V3D_C0_ONE_TILE      // developer A/B: one tile per workgroup (the walk degenerates)
+    const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
+#else
+    const unsigned grid = v3d::persistent_grid(blocks, 2);        // 76.8 KB of LDS: two workgroups per CU, each walks its tiles
+#endif
+    if (split_in && split_out) conv0_bf16x2_kernel<true, true, kC0Waves><<<grid, 64 * kC0Waves, C0::LDS_BYTES, s>>>(p);
+    else if (split_in) conv0_bf16x2_kernel<true, false, 4><<<grid, 256, C0::LDS_BYTES, s>>>(p);
+    else if (split_out) conv0_bf16x2_kernel<false, true, 4><<<grid, 256, C0::LDS_BYTES, s>>>(p);
+    else conv0_bf16x2_kernel<false, false, 4><<<grid, 256, C0::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH("conv0_bf16x2_kernel");
   return V3D_OK;
@@ -2065,7 +2124,7 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
     {
       v3d::TimedScope ts("costreg_conv9_prob", s);
-      conv9_prob_kernel<<<(unsigned)blocks, 256, 0, s>>>(q);
+      conv9_prob_kernel<<<(unsigned)blocks, 512, 0, s>>>(q);
     }
     V3D_CHECK_LAUNCH("conv9_prob_kernel");
   } else {

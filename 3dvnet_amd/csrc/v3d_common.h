@@ -51,6 +51,21 @@ bool timing_enabled();
 void timing_begin(const char* name, hipStream_t s);
 void timing_end(hipStream_t s);
 
+// Grid of a persistent kernel: wgs_per_cu workgroups on every CU of the current device, a multiple of 8 (one equal share per
+// XCD), never more than the tiles there are.
+inline unsigned persistent_grid(long long n_tiles, int wgs_per_cu) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu = v;
+  }
+  long long g = (long long)n_cu * wgs_per_cu;
+  if (g > n_tiles) g = n_tiles;
+  g = (g + 7) / 8 * 8;
+  return (unsigned)g;
+}
+
 struct TimedScope {
   hipStream_t s;
   bool on;
@@ -69,6 +84,18 @@ __device__ __forceinline__ int xcd_contiguous_block() {
   const int total = (int)gridDim.x, per = total >> 3, rem = total & 7;
   const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
   return x * per + (x < rem ? x : rem) + i;
+}
+
+// Persistent kernels: the grid is the number of workgroups resident at once (a multiple of 8, see persistent_grid()).
+// Workgroup (XCD x = id & 7, slot i = id >> 3) walks tiles first_x + i, first_x + i + G, ... of its XCD's contiguous run of the
+// logical tile order (G = workgroups per XCD), so at any moment an XCD's workgroups sit on G consecutive tiles.
+struct TileWalk { int t, end, step; };
+__device__ __forceinline__ TileWalk xcd_tile_walk(int n_tiles) {
+  const int G = (int)gridDim.x >> 3;
+  const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+  const int per = n_tiles >> 3, rem = n_tiles & 7;
+  const int first = x * per + (x < rem ? x : rem);
+  return {first + i, first + per + (x < rem ? 1 : 0), G};
 }
 
 // Single fp32 operations the compiler must not fuse with their neighbours.  HIP's __fmul_rn / __fadd_rn are plain operators

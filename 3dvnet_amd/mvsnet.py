@@ -225,11 +225,46 @@ class CostRegNet(nn.Module):
         return reg.unsqueeze(1)
 
 
-def edges_to_csr(ref_src_edges):
+class EdgeCsr(tuple):
+    """(ref_idx int64, ref_img i32, edge_ofs i32, edge_src i32) of ``edges_to_csr``; ``status_ws`` is the device workspace
+    of the native builder (None for the torch path) and ``check()`` reads its error word (synchronises)."""
+    status_ws = None
+
+    def check(self):
+        if self.status_ws is not None:
+            lib = _lib.load()
+            ws = self.status_ws
+            _lib.check(lib.v3d_edges_csr_status(_lib.ptr(ws), ws.numel(), _lib.stream_ptr(ws.device)), 'v3d_edges_csr')
+        return self
+
+
+def edges_to_csr(ref_src_edges, n_ref=None, n_img=None):
     """ref_src_edges [2,E] -> (ref_idx [n_ref] int64 sorted unique, ref_img i32, edge_ofs i32
     [n_ref+1], edge_src i32 [E] grouped per reference in original edge order).  Mirrors
     ``torch.unique(edges[0], return_inverse=True)`` + scatter-by-``gather_idx`` (mvsnet.py:179,
-    214-215) so the per-reference sums run over the same edges in the same order."""
+    214-215) so the per-reference sums run over the same edges in the same order.
+
+    ``torch.unique`` makes the host wait for the device (its output length is data).  A caller that knows how many
+    reference images the batch holds passes ``n_ref`` (and ``n_img``, the number of images the indices refer to): the
+    tables are then built by one device kernel (include/v3d.h, v3d_edges_csr) with no synchronisation; a wrong ``n_ref``
+    yields an empty CSR and an error reported by ``.check()``."""
+    if n_ref is not None and ref_src_edges.is_cuda:
+        if n_img is None:
+            raise ValueError('edges_to_csr: n_img is required with n_ref')
+        lib = _lib.load()
+        dev = ref_src_edges.device
+        e = ref_src_edges.to(torch.int64).contiguous()
+        n_edges = e.shape[1]
+        ref_img = torch.empty(n_ref, dtype=torch.int32, device=dev)
+        edge_ofs = torch.empty(n_ref + 1, dtype=torch.int32, device=dev)
+        edge_src = torch.empty(n_edges, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.v3d_edges_csr_workspace_bytes(int(n_img), int(n_ref)), dtype=torch.uint8, device=dev)
+        rc = lib.v3d_edges_csr(_lib.ptr(e), n_edges, int(n_img), int(n_ref), _lib.ptr(ref_img), _lib.ptr(edge_ofs),
+                               _lib.ptr(edge_src), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, 'v3d_edges_csr')
+        csr = EdgeCsr((ref_img.to(torch.int64), ref_img, edge_ofs, edge_src))
+        csr.status_ws = ws
+        return csr
     ref_idx, gather_idx = torch.unique(ref_src_edges[0], return_inverse=True)
     n_ref = ref_idx.shape[0]
     order = torch.sort(gather_idx, stable=True).indices
@@ -237,7 +272,7 @@ def edges_to_csr(ref_src_edges):
     counts = torch.bincount(gather_idx, minlength=n_ref)
     edge_ofs = torch.zeros(n_ref + 1, dtype=torch.int32, device=ref_src_edges.device)
     edge_ofs[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return ref_idx, ref_idx.to(torch.int32).contiguous(), edge_ofs, edge_src
+    return EdgeCsr((ref_idx, ref_idx.to(torch.int32).contiguous(), edge_ofs, edge_src))
 
 
 class SplitVariance:
@@ -256,7 +291,7 @@ class SplitVariance:
 
 def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, depth_start,
                          depth_interval, n_planes, img_size, depth_img_size, workspace=None,
-                         csr=None, split=False):
+                         csr=None, split=False, n_ref=None):
     """Rows A1-A4 (mvsnet.py:186-216): variance cost volume [n_ref, C, D, h, w]
     (`split=True`: the same volume as a `SplitVariance`, C == 32 only)."""
     _require_cuda(features_quarter, 'plane_sweep_variance')
@@ -265,7 +300,7 @@ def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, dep
     dev = feat.device
     n_img, C, Hf, Wf = feat.shape
     if csr is None:
-        csr = edges_to_csr(ref_src_edges.to(dev))
+        csr = edges_to_csr(ref_src_edges.to(dev), n_ref=n_ref, n_img=n_img)
     _, ref_img, edge_ofs, edge_src = csr
     n_ref, n_edges = ref_img.shape[0], edge_src.shape[0]
     h, w = depth_img_size
@@ -338,9 +373,10 @@ class MVSNet(nn.Module):
         return self._depth_vals[key]
 
     def cost_volume_depth(self, features_quarter, batch, depth_start, depth_interval, n_planes,
-                          depth_img_size, return_intermediates=False, csr=None, precision=None):
+                          depth_img_size, return_intermediates=False, csr=None, precision=None, n_ref=None):
         """Rows A1-A6 from quarter-resolution features.  ``precision`` ('split_bf16' | 'fp32') overrides the
-        regulariser's ``cnn_3d.precision``.  With split-bf16 operands, unless the caller asks for the
+        regulariser's ``cnn_3d.precision``.  ``n_ref`` (optional): the number of reference images in ``batch``; with it the
+        edge tables are built on the device without the host synchronisation ``torch.unique`` implies (`edges_to_csr`).  With split-bf16 operands, unless the caller asks for the
         intermediates, the variance volume travels to the regulariser in its split-bf16 input format
         (identical depth, no conversion pass in conv0)."""
         precision = precision or self.cnn_3d.precision
@@ -348,14 +384,14 @@ class MVSNet(nn.Module):
         var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
                                    batch.ref_src_edges, depth_start, depth_interval, n_planes,
                                    self.img_size, depth_img_size, workspace=self._ws, csr=csr,
-                                   split=split)
+                                   split=split, n_ref=n_ref)
         vals = self.depth_values(depth_start, depth_interval, n_planes, var.device)
         if return_intermediates:
             depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True, precision=precision)
             return depth, var, reg
         return self.cnn_3d.regularize_depth(var, vals, precision=precision)
 
-    def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size):
+    def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size, n_ref=None):
         if self.feat_extractor is not None:
             features_half, features_quarter, features_eighth, _, _ = \
                 self.feat_shrinker(*self.feat_extractor(batch.images))
@@ -364,5 +400,5 @@ class MVSNet(nn.Module):
             features_quarter = batch.features_quarter
             features_eighth = getattr(batch, 'features_eighth', None)
         depth_img = self.cost_volume_depth(features_quarter, batch, depth_start, depth_interval,
-                                           n_planes, depth_img_size)
+                                           n_planes, depth_img_size, n_ref=n_ref)
         return depth_img, features_half, features_quarter, features_eighth

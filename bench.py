@@ -148,11 +148,17 @@ def bench_costvolume(args, rank, world, dev, dist):
     batch = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(dev)
     feat = inp['feat'].to(dev)
 
+    # The edge list -> per-reference tables (mvsnet.py:179: torch.unique + the scatter grouping) are rebuilt every step, as
+    # in the reference's forward -- by the library's device kernel (v3d_edges_csr), which needs the number of reference
+    # images of the batch (a property of the batch, `refs` here) instead of reading torch.unique's length back to the host.
+    # Checked once against the torch construction before anything is timed.
+    csr_dev = mvs.edges_to_csr(batch.ref_src_edges, n_ref=refs, n_img=feat.shape[0]).check()
+    csr_ref = mvs.edges_to_csr(batch.ref_src_edges)
+    assert all(torch.equal(a, b) for a, b in zip(csr_dev, csr_ref)), 'device CSR differs from torch.unique + stable sort'
+
     def step(precision=None):
         with torch.no_grad():
-            # the edge list -> per-reference CSR (torch.unique + stable sort, mvsnet.py:179) is redone every step, as in
-            # the reference's forward
-            return net.cost_volume_depth(feat, batch, d0, dd, D, inp['plane_size'], precision=precision)
+            return net.cost_volume_depth(feat, batch, d0, dd, D, inp['plane_size'], precision=precision, n_ref=refs)
 
     def fence():
         torch.cuda.synchronize()

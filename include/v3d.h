@@ -59,6 +59,26 @@ int v3d_timing_collect(int max_entries, char* names_host, int name_stride, float
                        int* launches_host);
 
 /* ------------------------------------------------------------------------------------------
+ * Row A7 bookkeeping: edge list -> per-reference CSR on the device, no host round trip.
+ * Replaces mvsnet.py:179 (ref_idx, gather_idx = torch.unique(ref_src_edges[0], return_inverse=True), whose output length
+ * the host must read back) and the grouping scatter(.., gather_idx) implies at mvsnet.py:214-215.
+ *
+ *   edges     [2, n_edges] int64 (row 0 = reference image, row 1 = source image), any order
+ *   n_ref     the number of distinct reference images, known to the caller (the batch holds that many depth maps)
+ *   ref_img   [n_ref]      out: ascending distinct values of edges[0] (= torch.unique's order)
+ *   edge_ofs  [n_ref+1]    out: first edge of every reference in edge_src
+ *   edge_src  [n_edges]    out: edges[1] grouped per reference, original edge order inside a group
+ *   workspace >= v3d_edges_csr_workspace_bytes(n_img, n_ref)
+ * If n_ref is not the number of distinct references, or an index is outside [0, n_img), the kernel writes an empty CSR
+ * (all offsets 0: the consumers stay inside their buffers) and sets the workspace's error word;
+ * v3d_edges_csr_status copies it to the host (synchronises) -> V3D_ERR_BAD_SHAPE.
+ * ------------------------------------------------------------------------------------------ */
+size_t v3d_edges_csr_workspace_bytes(int n_img, int n_ref);
+int v3d_edges_csr(const int64_t* edges, int n_edges, int n_img, int n_ref, int32_t* ref_img, int32_t* edge_ofs,
+                  int32_t* edge_src, void* workspace, size_t workspace_bytes, void* stream);
+int v3d_edges_csr_status(const void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Rows A1-A4: plane-sweep warp + cross-view variance, one fused kernel.
  * Replaces mv3d/utils.py:86-108 (batched_build_plane_sweep_volume_tensor),
  * mv3d/subnetworks/mvsnet.py:192-206 (projection, |z|+1e-8, normalisation),

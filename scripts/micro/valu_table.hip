@@ -62,6 +62,11 @@ __global__ __launch_bounds__(1024) void k(long long* out, float* sink, int iters
         if constexpr (OP == 39) asm volatile("v_or_b32 %0, %1, %0" : "+v"(a[j]) : "v"(x), "v"(y));
         if constexpr (OP == 40) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(a[j]) : "v"(x), "v"(y));
         if constexpr (OP == 41) asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(a[j]) : "v"(x), "v"(y));
+        if constexpr (OP == 42) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[j]) : "v"(xx), "s"(m));          // SGPR pair operand
+        if constexpr (OP == 43) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[j & 1]) : "v"(xx), "v"(yy));     // 2 dependent chains
+        if constexpr (OP == 44) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[j & 1]) : "v"(xx), "s"(m));      // both
+        if constexpr (OP == 45) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[j & 1]) : "v"(x), "v"(y));          // scalar FMA, 2 chains
+        if constexpr (OP == 46) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[j]) : "v"(x), "s"(sx));             // scalar FMA, SGPR operand
       }
     }
   }
@@ -135,5 +140,10 @@ int main() {
   run<39>("v_or_b32 %0, %1, %0", d, s);
   run<40>("v_add3_u32 %0, %1, %2, %0", d, s);
   run<41>("v_lshrrev_b32 %0, 16, %0", d, s);
+  run<42>("v_pk_fma_f32 v, v, s[pair], v   (8 independent accumulators)", d, s);
+  run<43>("v_pk_fma_f32 v, v, v, v         (2 dependent chains)", d, s);
+  run<44>("v_pk_fma_f32 v, v, s[pair], v   (2 dependent chains)", d, s);
+  run<45>("v_fma_f32 v, v, v, v            (2 dependent chains)", d, s);
+  run<46>("v_fma_f32 v, v, s, v            (8 independent accumulators)", d, s);
   return 0;
 }

@@ -272,3 +272,58 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         dec.fused = False
         assert not dec.can_fuse(xs, pts, pf)
         assert torch.equal(dec(xs, pts, pf, pts_batch), p_u)
+
+
+@pytest.mark.parametrize('case', range(6))
+def test_device_edge_csr_equals_torch_unique_and_stable_sort(case, cuda):
+    """v3d_edges_csr (the device-side replacement of mvsnet.py:179's torch.unique + the scatter grouping) against the
+    torch construction, bit for bit: unsorted ragged edge lists, duplicate edges, self edges, references that are nobody's
+    source, 1 .. 300 references, up to 5 000 edges (more than one 1024-thread pass)."""
+    mvs = v3d('mvsnet')
+    rng = np.random.default_rng(77 + case)
+    n_img = [3, 17, 71, 400, 1200, 64][case]
+    n_ref = [1, 5, 64, 300, 7, 64][case]
+    refs = rng.choice(n_img, size=n_ref, replace=False)
+    r_list, s_list = [], []
+    for r in refs:
+        ns = int(rng.integers(1, [4, 12, 9, 20, 700, 12][case]))
+        r_list += [int(r)] * ns
+        s_list += [int(x) for x in rng.integers(0, n_img, ns)]
+    perm = rng.permutation(len(r_list))
+    edges = torch.tensor([r_list, s_list], dtype=torch.int64)[:, perm].to(cuda)
+    dev = mvs.edges_to_csr(edges, n_ref=n_ref, n_img=n_img).check()
+    ref = mvs.edges_to_csr(edges)
+    for a, b, name in zip(dev, ref, ('ref_idx', 'ref_img', 'edge_ofs', 'edge_src')):
+        assert a.dtype == b.dtype and torch.equal(a, b), name
+
+
+def test_device_edge_csr_reports_a_wrong_reference_count(cuda):
+    """A wrong n_ref (or an index outside [0, n_img)) must not pass silently: the tables come back empty (all offsets 0, so
+    the warp kernel stays inside its buffers) and .check() raises."""
+    mvs = v3d('mvsnet')
+    edges = torch.tensor([[0, 0, 2, 2, 5], [1, 2, 0, 3, 4]], dtype=torch.int64, device=cuda)
+    ok = mvs.edges_to_csr(edges, n_ref=3, n_img=6).check()
+    assert ok[1].tolist() == [0, 2, 5] and ok[2].tolist() == [0, 2, 4, 5] and ok[3].tolist() == [1, 2, 0, 3, 4]
+    for n_ref, n_img in ((2, 6), (4, 6), (3, 5)):
+        bad = mvs.edges_to_csr(edges, n_ref=n_ref, n_img=n_img)
+        assert int(bad[2].abs().sum()) == 0
+        with pytest.raises(RuntimeError):
+            bad.check()
+
+
+def test_cost_volume_depth_with_reference_count_hint_is_bit_identical(cuda):
+    """MVSNet.cost_volume_depth(..., n_ref=) (device-built edge tables, no host synchronisation) returns the same bits as
+    the torch.unique path."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=5)
+    d0, dd, D = inp['depth']
+    net = mvs.MVSNet(32, inp['img_size']).eval()
+    net.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
+    net = net.to(cuda)
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    feat = inp['feat'].to(cuda)
+    with torch.no_grad():
+        a = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
+        c = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'], n_ref=3)
+    assert torch.equal(a, c)
