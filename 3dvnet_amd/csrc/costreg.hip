@@ -498,6 +498,11 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 // ([n][hi, lo][D][H][W] 16-byte slots) consumed by convh_bf16x2_kernel (conv1) and conv9_prob_kernel (skip).
 // NW = waves per workgroup (4 or 8): with 8, a wave owns one output row of the 4 planes and a CU holds 4 waves per SIMD
 // (2 workgroups), so one wave's LDS / barrier waits are covered by another's MFMAs.
+#ifdef V3D_C0_PLAIN_LOAD
+#define V3D_C0_LOAD(p) (*(p))
+#else
+#define V3D_C0_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 #ifndef V3D_C0_ABLATE
 #define V3D_C0_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no MFMAs (0.82 ms), 2 no input loads (0.84), 3 no LDS commit (0.97), 4 no output stores (1.06), 5 stores into a 2 MB window (1.07), 6 loads from a 1 MB window (1.02); full kernel 1.09 ms per 64 views
 #endif
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
         const int hl = rr >= C0::SROWS ? 1 : 0;
         const int g = rowg[rr - hl * C0::SROWS];               // rows 60..63 of the table are out of range
         pres[it] = (rr < 2 * C0::SROWS && g != kRowOob && xin && V3D_C0_ABLATE != 2)
-                       ? __builtin_nontemporal_load(ins + (V3D_C0_ABLATE == 6 ? (size_t)(g & 0xffff) : (size_t)(chunk * 2 + hl) * in_plane + g))
+                       ? V3D_C0_LOAD(ins + (V3D_C0_ABLATE == 6 ? (size_t)(g & 0xffff) : (size_t)(chunk * 2 + hl) * in_plane + g))
                        : (u32x4){0u, 0u, 0u, 0u};
       }
     } else {

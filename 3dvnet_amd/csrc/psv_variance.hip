@@ -4,8 +4,8 @@
 //
 // Data layout in HBM
 //   feat   [n_img, C, Hf, Wf]  (reference layout)  -> transposed once per call into
-//   featT  [n_img, Hf, Wf, C]  (workspace) so that one bilinear tap of all C channels is one
-//                               contiguous 4*C-byte run (C=32: exactly one 128-B cache line);
+//   featT  [n_img, Hf+2, Wf+2, C]  (workspace, zero border) so that one bilinear tap of all C channels is one
+//                               contiguous 4*C-byte run (C=32: exactly one 128-B cache line) and out-of-image taps read zeros;
 //   var    [n_ref, C, D, h, w] (reference layout, consumed as-is by the 3D-conv regulariser).
 //
 // Work decomposition: one 256-thread workgroup per (reference view, chunk of DB depth planes,
@@ -62,6 +62,39 @@ __global__ __launch_bounds__(256) void transpose_channel_last_kernel(const float
   for (int i = threadIdx.x; i < C * kPix; i += 256) {
     int p = i / C, c = i % C;
     if (p0 + p < HW) dst[(size_t)(p0 + p) * C + c] = tile[c][p];
+  }
+}
+
+// [n_img, C, Hf, Wf] -> [n_img, Hf + 2, Wf + 2, C] with a border of zero cells (+ one zero row behind the last image).
+// grid_sample's padding_mode='zeros' then needs no per-tap validity test in the warp kernels: a tap outside the image reads
+// a zero cell, and a sample further out is clamped onto the border, where both of its in-range taps are zero cells and the
+// other two carry weight 0 (make_taps).  One workgroup = 64 cells of one padded row.
+template <int C>
+__global__ __launch_bounds__(256) void transpose_bordered_kernel(const float* __restrict__ in, float* __restrict__ out, int Hf,
+                                                                  int Wf, int n_img) {
+  __shared__ float tile[C][kPix + 1];
+  const int img = blockIdx.z, yb = blockIdx.y, x0 = blockIdx.x * kPix;
+  const int Wp = Wf + 2, HW = Hf * Wf;
+  const float* src = in + (size_t)img * C * HW + (size_t)(yb - 1) * Wf - 1;
+  float* dst = out + ((size_t)img * (Hf + 2) + yb) * Wp * C;
+  const bool row_in = yb >= 1 && yb <= Hf;
+  for (int i = threadIdx.x; i < C * kPix; i += 256) {
+    const int c = i / kPix, xb = x0 + i % kPix;
+    tile[c][i % kPix] = (row_in && xb >= 1 && xb <= Wf) ? src[(size_t)c * HW + xb] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * kPix; i += 256) {
+    const int px = i / C, c = i % C;
+    if (x0 + px < Wp) dst[(size_t)(x0 + px) * C + c] = tile[c][px];
+  }
+  // A sample clamped onto the lower border reads its weight-0 taps one padded row further down: the next image's top border,
+  // or, behind the last image, this extra row of zero cells (+ one cell for the tap right of its last cell).  Weight 0 times
+  // recycled memory holding a NaN pattern would be NaN.
+  if (img == n_img - 1 && yb == Hf + 1) {
+    float* tail = out + (size_t)n_img * (Hf + 2) * Wp * C;
+    for (int i = threadIdx.x; i < C * kPix; i += 256)
+      if (x0 + i / C < Wp) tail[(size_t)(x0 + i / C) * C + i % C] = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x < C) tail[(size_t)Wp * C + threadIdx.x] = 0.f;
   }
 }
 
@@ -129,33 +162,29 @@ __global__ void cam_setup_kernel(const float* __restrict__ K, const float* __res
 }
 
 struct TapInfo {      // one (pixel, plane, edge) sample, 32 bytes
-  float w00, w01, w10, w11;      // nw, ne, sw, se weights (0 where the tap is out of range: grid_sample padding_mode='zeros')
-  unsigned b00, b01, b10, b11;   // byte offsets of the 4 cells (channel 0) into featT, clamped into the source image
+  float w00, w01, w10, w11;      // nw, ne, sw, se weights: the reference's products (x1 - ix)(y1 - iy), ...
+  unsigned b00;                  // byte offset of the nw cell (channel 0) in the bordered featT; ne = +CB, sw = +row, se = +row + CB
+  unsigned pad[3];
 };
 
-// Bilinear taps of one sample (F.grid_sample, align_corners=True, zeros padding; mvsnet.py:209-211).  Weights are the
-// reference's products (x1 - ix)(y1 - iy), ... with the factor of an out-of-range column / row replaced by 0; validity is
-// tested on the converted integers (one unsigned compare per column / row; float -> int saturates, so far-away samples stay
-// invalid); the cell coordinates are clamped into the image so that every tap has a loadable address -- a tap with weight
-// 0 contributes exactly 0, and a sample that misses the image entirely needs no special case in the gather loop.
-// CB = bytes per cell (4 C).
+// Bilinear taps of one sample (F.grid_sample, align_corners=True, zeros padding; mvsnet.py:209-211) on the BORDERED
+// channel-last feature maps (transpose_bordered_kernel).  The sample position is clamped to [-1, Wf] x [-1, Hf] first: inside
+// that range nothing changes -- a tap outside the image is a zero cell of the border and contributes exactly 0 with its true
+// weight, as in the reference, which zeroes the tap's value; outside it every tap of the true sample is out of range (result
+// 0), and the clamped sample sits on the border with weight 1 on zero cells and weight 0 on the others: 0 as well.  NaN
+// positions clamp to -1 (fmaxf returns the number).  So there is no validity test, no per-tap clamp and one offset per
+// sample instead of four.  CB = bytes per cell (4 C); first_cell = index of cell (-1, -1) of the source image.
 template <unsigned CB>
-__device__ __forceinline__ TapInfo make_taps(float ix, float iy, int Wf, int Hf, int first_cell, bool live) {
+__device__ __forceinline__ TapInfo make_taps(float ix, float iy, int Wf, int Hf, int first_cell) {
+  ix = fminf(fmaxf(ix, -1.f), (float)Wf);
+  iy = fminf(fmaxf(iy, -1.f), (float)Hf);
   const float x0 = floorf(ix), y0 = floorf(iy);
   const float x1 = x0 + 1.f, y1 = y0 + 1.f;
-  const int xi0 = (int)x0, yi0 = (int)y0, xi1 = xi0 + 1, yi1 = yi0 + 1;
-  const bool vx0 = live && (unsigned)xi0 < (unsigned)Wf, vx1 = live && (unsigned)xi1 < (unsigned)Wf;
-  const bool vy0 = (unsigned)yi0 < (unsigned)Hf, vy1 = (unsigned)yi1 < (unsigned)Hf;
-  const float wx0 = vx0 ? x1 - ix : 0.f, wx1 = vx1 ? ix - x0 : 0.f;
-  const float wy0 = vy0 ? y1 - iy : 0.f, wy1 = vy1 ? iy - y0 : 0.f;
+  const float wx0 = x1 - ix, wx1 = ix - x0, wy0 = y1 - iy, wy1 = iy - y0;
   TapInfo ti;
   ti.w00 = v3d::mul_rn(wx0, wy0); ti.w01 = v3d::mul_rn(wx1, wy0);
   ti.w10 = v3d::mul_rn(wx0, wy1); ti.w11 = v3d::mul_rn(wx1, wy1);
-  const int cx0 = min(max(xi0, 0), Wf - 1), cx1 = min(max(xi1, 0), Wf - 1);
-  const int cy0 = min(max(yi0, 0), Hf - 1), cy1 = min(max(yi1, 0), Hf - 1);
-  const int row0 = first_cell + cy0 * Wf, row1 = first_cell + cy1 * Wf;
-  ti.b00 = (unsigned)(row0 + cx0) * CB; ti.b01 = (unsigned)(row0 + cx1) * CB;
-  ti.b10 = (unsigned)(row1 + cx0) * CB; ti.b11 = (unsigned)(row1 + cx1) * CB;
+  ti.b00 = (unsigned)(first_cell + ((int)y0 + 1) * (Wf + 2) + (int)x0 + 1) * CB;
   return ti;
 }
 
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
         for (int e = tid / kPix; e < nec; e += kThreads / kPix) {
           float ix, iy;
           v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
-          const TapInfo ti = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, p.edge_src[e_begin + ec + e] * p.Hf * p.Wf, gp1 < P);
+          const TapInfo ti = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, p.edge_src[e_begin + ec + e] * (p.Hf + 2) * (p.Wf + 2));
           s_tap[e * kPix + px1] = ti;
         }
       }
@@ -278,11 +307,11 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
           {
             // uniform base + 32-bit byte offset: the load takes the address as SGPR pair + VGPR offset
             const char* fb = reinterpret_cast<const char*>(p.featT);
-            const unsigned cgb = cg * 16;
+            const unsigned cgb = cg * 16, rowb = (unsigned)(p.Wf + 2) * (4 * C);
             const float4 v00 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b00 + cgb));
-            const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b01 + cgb));
-            const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b10 + cgb));
-            const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b11 + cgb));
+            const float4 v01 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b00 + cgb) + 4 * C);
+            const float4 v10 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b00 + rowb + cgb));
+            const float4 v11 = *reinterpret_cast<const float4*>(fb + (size_t)(ti.b00 + rowb + cgb) + 4 * C);
             // F.grid_sample's tap order as an FMA chain: ((v00 w00 + v01 w01) + v10 w10) + v11 w11 -- the plane-reuse kernel
             // below uses the same sequence, so the variants agree bit for bit
             s.x = v3d::mul_rn(v00.x, ti.w00); s.y = v3d::mul_rn(v00.y, ti.w00);
@@ -367,15 +396,23 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
 // lanes of a pixel keep the footprint of the previous plane in registers and reload it only when the footprint
 // of the next plane differs, edge by edge.  Arithmetic and accumulation order per (pixel, plane) are those of
 // the gather kernel (bit-identical output).
+//
+// What bounds it (round-2 measurements, cfg2, 64 views): the vector-memory path.  A step = one (plane, edge) for the wave's 8
+// pixels; a footprint reload is four 1 KB wave loads at 16 cycles each on the CU's single address/L1 path, issued when ANY
+// of the 8 pixels changed its footprint, with the other pixels' lanes masked.  The kernel completes one step per ~48 cycles
+// and CU at 4 or at 5 waves per SIMD alike, i.e. 3 of the 4 possible load instructions per step.  Consequences measured:
+// 18 % fewer VALU instructions in the loop (bordered maps, one offset per sample): no change; 8 planes per wave instead
+// of 4 (one forced first-plane reload per 8 steps instead of per 4): -7 %, although only 4 waves per SIMD fit; 2 planes
+// per wave at 8 waves per SIMD: +19 %; partial reloads and a persistent tile walk: slower (see below / DESIGN.md).
 constexpr int kRPix = 8;      // pixels per wave
 #ifndef V3D_PSV_RDB
-#define V3D_PSV_RDB 4
+#define V3D_PSV_RDB 8
 #endif
 constexpr int kRDB = V3D_PSV_RDB;                 // depth planes per wave
 constexpr int kRE = 64 / (kRDB * kRPix);          // edges per phase-1 pass: kRE x kRDB x kRPix = 64 (pixel, plane, edge) items, one per lane
 
 #ifndef V3D_PSV_WAVES
-#define V3D_PSV_WAVES 5
+#define V3D_PSV_WAVES 4
 #endif
 #ifndef V3D_PSV_ORDER
 #define V3D_PSV_ORDER 1
@@ -435,6 +472,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
   // gather role: 8 lanes x float4 per pixel
   const int gpx = lane >> 3;
   const unsigned cgb = (lane & 7) * 16;
+  const unsigned rowb = (unsigned)(p.Wf + 2) * (4 * C) + cgb;      // sw cell of a footprint = nw + one bordered row
   const char* const fb = reinterpret_cast<const char*>(p.featT);
   f32x4 acc_s[kRDB], acc_q[kRDB];
 #pragma unroll
@@ -451,7 +489,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
       for (int i = lane; i < nload; i += 64) {
         const int src = p.edge_src[e_begin + ec + i / 12];
         s_P[i / 12][i % 12] = p.camp[src * kCamStride + 24 + i % 12];
-        if (i % 12 == 0) s_base[i / 12] = src * p.Hf * p.Wf;
+        if (i % 12 == 0) s_base[i / 12] = src * (p.Hf + 2) * (p.Wf + 2);      // cell (-1, -1) of the bordered map
       }
       __syncthreads();
     }
@@ -461,12 +499,12 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
     if (e1 < nec) {
       float ix, iy;
       v3d::sample_position(s_P[ec % kMaxE + e1], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
-      s_tap[(e1 * kRDB + pl1) * kRPix + px1] = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, s_base[ec % kMaxE + e1], live1);
+      s_tap[(e1 * kRDB + pl1) * kRPix + px1] = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, s_base[ec % kMaxE + e1]);
     }
     __syncthreads();
     PHASE_MARK(1);
     for (int e = 0; e < nec; ++e) {
-      unsigned c00 = ~0u, c11 = ~0u;     // footprint held in t00..t11 (b00 and b11 pin all four cells)
+      unsigned c00 = ~0u;                // footprint held in t00..t11 (its nw cell pins all four)
       // deliberately not initialised: ~0 matches no offset, so the first plane always loads them
       f32x4 t00, t01, t10, t11;
 #pragma unroll
@@ -475,16 +513,19 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
 #if V3D_PSV_ABLATE == 2      // developer ablation: footprint loaded once per edge only
         if (pl == 0) {
 #else
-        if (ti.b00 != c00 || ti.b11 != c11) {
+        if (ti.b00 != c00) {
 #endif
+          // (Reloading only the two new cells when the footprint moved by one cell -- register moves for the other two -- was
+          // slower, 2.02 vs 1.84 ms: a step then issues two loads per direction the wave's pixels moved in, and the
+          // vector-memory path is charged per wave instruction, not per active lane.)
           t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b00 + cgb));
-          t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b01 + cgb));
-          t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b10 + cgb));
-          t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b11 + cgb));
-          c00 = ti.b00; c11 = ti.b11;
+          t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b00 + cgb) + 4 * C);
+          t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b00 + rowb));
+          t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)(ti.b00 + rowb) + 4 * C);
+          c00 = ti.b00;
         }
         // F.grid_sample's tap order as an FMA chain (same sequence as the gather kernel); no validity branch: taps outside
-        // the source image carry weight 0 and a clamped address
+        // the source image read zero cells of the border
 #if V3D_PSV_ABLATE == 1      // developer ablation: no blend arithmetic (loads and tap reads kept alive)
         asm volatile("" : : "v"(t00), "v"(t01), "v"(t10), "v"(t11), "v"(ti.w00), "v"(ti.w01), "v"(ti.w10), "v"(ti.w11));
 #else
@@ -611,10 +652,14 @@ int v3d::transpose_channel_last(const float* feat, float* featT, int n_img, int 
   return 0;
 }
 
+// bordered channel-last feature maps: n_img x (Hf + 2) x (Wf + 2) cells + a zero row of Wf + 3 cells behind them
+static size_t psv_feat_bytes(int n_img, int C, int Hf, int Wf) {
+  return ((size_t)n_img * (Hf + 2) * (Wf + 2) + (Wf + 3)) * C * sizeof(float);
+}
+
 extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
   // channel-last copy of the feature maps + the per-image camera blocks
-  return v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256) +
-         v3d::align_up((size_t)n_img * kCamStride * sizeof(float), 256);
+  return v3d::align_up(psv_feat_bytes(n_img, C, Hf, Wf), 256) + v3d::align_up((size_t)n_img * kCamStride * sizeof(float), 256);
 }
 
 static int psv_variance_impl(bool split, const float* feat, const float* K, const float* R,
@@ -636,16 +681,21 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 &&
                   D > 0 && h > 0 && w > 0,
               V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: bad shape");
-  V3D_REQUIRE((size_t)n_img * Hf * Wf * C < (size_t)1 << 30, V3D_ERR_BAD_SHAPE,
-              "v3d_psv_variance_f32: feature tensor exceeds 2^30 elements (32-bit byte offsets)");
+  V3D_REQUIRE(psv_feat_bytes(n_img, C, Hf, Wf) < (size_t)1 << 32, V3D_ERR_BAD_SHAPE,
+              "v3d_psv_variance_f32: bordered feature maps exceed 4 GB (32-bit byte offsets)");
   V3D_REQUIRE(workspace_bytes >= v3d_psv_workspace_bytes(n_img, C, Hf, Wf),
               V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_psv_variance_f32: workspace %zu < %zu",
               workspace_bytes, v3d_psv_workspace_bytes(n_img, C, Hf, Wf));
   hipStream_t s = (hipStream_t)stream;
   float* featT = (float*)workspace;
-  float* camp = (float*)((char*)workspace + v3d::align_up((size_t)n_img * C * Hf * Wf * sizeof(float), 256));
-  v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
-  V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
+  float* camp = (float*)((char*)workspace + v3d::align_up(psv_feat_bytes(n_img, C, Hf, Wf), 256));
+  {
+    v3d::TimedScope ts("transpose_channel_last", s);
+    const dim3 tg((Wf + 2 + kPix - 1) / kPix, Hf + 2, n_img);
+    if (C == 32) transpose_bordered_kernel<32><<<tg, 256, 0, s>>>(feat, featT, Hf, Wf, n_img);
+    else transpose_bordered_kernel<16><<<tg, 256, 0, s>>>(feat, featT, Hf, Wf, n_img);
+  }
+  V3D_CHECK_LAUNCH("transpose_bordered_kernel");
   cam_setup_kernel<<<(n_img + 63) / 64, 64, 0, s>>>(K, R, t, camp, n_img);
   V3D_CHECK_LAUNCH("cam_setup_kernel");
 

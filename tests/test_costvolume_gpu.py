@@ -407,3 +407,38 @@ def test_sample_positions_bit_exact_vs_pinned_oracle(cfg, cuda):
             ix, iy = (a.numpy() for a in pinned.sample_positions(X, P[int(edge_src[e])], inp['img_size'], (Hf, Wf)))
             assert np.array_equal(pos[e, :, 0], ix) and np.array_equal(pos[e, :, 1], iy), \
                 'edge %d: ix %.4f iy %.4f bit-equal' % (e, np.mean(pos[e, :, 0] == ix), np.mean(pos[e, :, 1] == iy))
+
+
+@pytest.mark.parametrize('name', ['A_tiny_rotated', 'A_tiny_sharp'])
+def test_poisoned_workspace_does_not_reach_the_variance(name, cuda):
+    """The warp kernels read weight-0 taps from the zero border of the channel-last feature copy and, for samples clamped
+    onto the lower border of the LAST image, from the zero row behind it.  0 x NaN is NaN: with the workspace pre-filled with
+    0xFF bytes (fp32 NaN patterns, what recycled allocator memory may hold) the variance must still be finite and equal, bit
+    for bit, to the one computed on a zero-filled workspace -- both kernel variants, fp32 and split output."""
+    mvs = v3d('mvsnet')
+    lib = v3d('_lib').load()
+    g = load_golden(name)
+    feat = torch.from_numpy(g['feat']).to(cuda)
+    cams = [torch.from_numpy(g[k]).to(cuda) for k in ('rotmats', 'tvecs', 'K')]
+    edges = torch.from_numpy(g['edges']).to(cuda)
+    d0, dd, D = g['depth_cfg']
+    img_size, ps = tuple(int(x) for x in g['img_size']), tuple(int(x) for x in g['plane_size'])
+    nbytes = lib.v3d_psv_workspace_bytes(*[int(x) for x in (feat.shape[0], feat.shape[1], feat.shape[2], feat.shape[3])])
+
+    class Ws:
+        def __init__(self, fill):
+            self.buf = torch.full((nbytes + 4096,), fill, dtype=torch.uint8, device=cuda)
+
+        def get(self, name_, n, device):
+            assert n <= self.buf.numel()
+            return self.buf
+
+    for split in (False, True):
+        out = []
+        for fill in (0, 255):
+            v = mvs.plane_sweep_variance(feat, cams[0], cams[1], cams[2], edges, float(d0), float(dd), int(D), img_size, ps,
+                                         workspace=Ws(fill), split=split)
+            out.append(v.data if split else v)
+        dec = _decode_split(mvs.SplitVariance(out[1], out[1].shape)) if split else out[1]
+        assert torch.isfinite(dec).all()
+        assert torch.equal(out[0].view(torch.int32), out[1].view(torch.int32))
