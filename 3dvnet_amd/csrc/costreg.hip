@@ -825,6 +825,11 @@ struct CG {
   static constexpr int NROWS = 2 * ID * IH, NIT = (NROWS + RPI - 1) / RPI;
   static constexpr int NWIT = (WQ + 255) / 256;
   static constexpr size_t LDS_BYTES = (size_t)(2 * NVOXP + WQ) * 16;
+  // Only the single-chunk layer (conv1) walks several items per workgroup: with one tile per workgroup it had no prefetch
+  // at all (0.26 -> 0.22 ms).  On the multi-chunk layers the staging registers of the next item, live across the epilogue,
+  // cost a workgroup per CU (conv2: 138 -> 195 VGPRs, 0.20 -> 0.25 ms), so they keep one item per workgroup.
+  static constexpr bool PERSIST = NCH == 1;
+  static constexpr int OCC = 2;      // (cutting conv2 / conv6 to 128 VGPRs for a fourth workgroup per CU: no gain / slower)
   static_assert(CIN % 8 == 0 && COUT % 16 == 0 && (WB == 14 || WB == 8), "shape");
   static_assert((size_t)NVO * 64 <= (size_t)2 * NVOXP * 16, "split output staging fits in the input tile");
   static_assert((size_t)16 * (NVO + 2) * 4 <= (size_t)2 * NVOXP * 16, "fp32 output staging fits in the input tile");
@@ -839,34 +844,47 @@ struct ConvGParams {
   int n, Di, Hi, Wi, Do, Ho, Wo, ntz, nty, ntx;
 };
 
+// PERSISTENT: the grid is the number of workgroups the chip holds; a workgroup walks (tile, output channel group) items
+// first + i, first + i + G, ... of its XCD's contiguous run (v3d::xcd_tile_walk; the channel group is the fastest index, so
+// the workgroups that read the same input tile run side by side).  These layers have 1 to 8 chunks per tile: with one tile
+// per workgroup, conv1 (one chunk) had no prefetch at all -- load, wait, compute, store, exit.  Where C::PERSIST is set the
+// first chunk of the next item is requested before the MFMAs of the current item's last chunk; elsewhere the walk has one
+// item per workgroup.
 template <class C>
-__global__ __launch_bounds__(256, 2) void convg_bf16x2_kernel(ConvGParams p) {
+__global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [hi, lo][NVOXP] slots of the current chunk
   u32x4* const wq = xs + 2 * C::NVOXP;                              // [9][hi, lo][64] weight fragments
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
-  const int cg = blockIdx.y;
-  int b = v3d::xcd_contiguous_block();
-  const int tx = b % p.ntx; b /= p.ntx;
-  const int ty = b % p.nty; b /= p.nty;
-  const int tz = b % p.ntz;
-  const int n = b / p.ntz;
-  const int oz0 = tz * C::TD, oy0 = ty * C::TH, ox0 = tx * C::TW;
-  const int iz0 = C::S * oz0 - 1, iy0 = C::S * oy0 - 1, ix0 = C::S * ox0 - 1;
   const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
 
+  struct Item { int cg, n, oz0, oy0, ox0; };
+  auto decode = [&](int t) __attribute__((always_inline)) {
+    Item q;
+    q.cg = t % C::NCG; t /= C::NCG;
+    const int tx = t % p.ntx; t /= p.ntx;
+    const int ty = t % p.nty; t /= p.nty;
+    q.oz0 = (t % p.ntz) * C::TD; q.n = t / p.ntz;
+    q.oy0 = ty * C::TH; q.ox0 = tx * C::TW;
+    return q;
+  };
+  const v3d::TileWalk walk = v3d::xcd_tile_walk(p.n * p.ntz * p.nty * p.ntx * C::NCG);
+  if (walk.t >= walk.end) return;
+
   // ---- staging: chunk c = input channel group c (hi rows then lo rows) + its weight image -----------------------
-  const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::NCH * 2 * in_plane;
-  const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)cg * C::NCH * C::WQ;
   const int lrow = tid / C::LPR, lx = tid % C::LPR;
-  const int sgx = ix0 + lx;
-  const bool xok = lx < C::IW, xin = xok && sgx >= 0 && sgx < p.Wi;
-  const int sxc = min(max(sgx, 0), p.Wi - 1);
+  const bool xok = lx < C::IW;
   u32x4 pre[C::NIT], wreg[C::NWIT];
-  auto issue = [&](int chunk) __attribute__((always_inline)) {
+  constexpr bool XPRE = C::PERSIST;
+  auto issue = [&](const Item& q, int chunk) __attribute__((always_inline)) {
+    const int iz0 = C::S * q.oz0 - 1, iy0 = C::S * q.oy0 - 1, sgx = C::S * q.ox0 - 1 + lx;
+    const bool xin = xok && sgx >= 0 && sgx < p.Wi;
+    const int sxc = min(max(sgx, 0), p.Wi - 1);
+    const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)q.n * C::NCH * 2 * in_plane;
+    const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)q.cg * C::NCH * C::WQ;
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int rr = it * C::RPI + lrow;
@@ -892,123 +910,138 @@ __global__ __launch_bounds__(256, 2) void convg_bf16x2_kernel(ConvGParams p) {
     for (int i = 0; i < C::NWIT; ++i)
       if (i * 256 + tid < C::WQ) wq[i * 256 + tid] = wreg[i];
   };
-  if (tid < 16) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};   // pad slots stay finite
 
   // ---- MFMA role: wave w = output rows y = w * NRB + r, lane column jn = (r, x) ----------------------------------
   const int lr = jn / C::WB, lxo = jn % C::WB;
   f32x4 acc[C::TD];
-#pragma unroll
-  for (int z = 0; z < C::TD; ++z) acc[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const u32x4* const wf = wq + lane;
-
-  PHASE_DECL;
-  issue(0);
-  PHASE_MARK(0);
-#pragma unroll 1
-  for (int chunk = 0; chunk < C::NCH; ++chunk) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    PHASE_MARK(1);
-    if (chunk + 1 < C::NCH) issue(chunk + 1);
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
-      bf16x8 a_hi[3], a_lo[3];
-#pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        a_hi[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2) * 64]);
-        a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
-      }
-      const int rowbase = (C::S * (wave * C::NRB + lr) + ky) * C::IW + C::S * lxo + kq;
-#pragma unroll
-      for (int iz = 0; iz < C::ID; ++iz) {
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW]);
-        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW + C::NVOXP]);
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
-          const int z2 = iz - kz;
-          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
-        }
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
-          const int z2 = iz - kz;
-          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z2 / C::S], 0, 0, 0);
-        }
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
-          const int z2 = iz - kz;
-          if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
-            acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
-        }
-      }
-    }
-    PHASE_MARK(2);
-  }
-  __syncthreads();                 // the input tile is dead: its LDS stages the output tile
-  PHASE_MARK(3);
-
-  // ---- bias + ReLU, through LDS, out in 16-byte (split layout) and / or 8-byte (fp32 rows) pieces ---------------
-  float vout[C::TD][4];
-  {
-    float bias[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = p.bias[cg * 16 + 4 * kq + r];
-#pragma unroll
-    for (int z = 0; z < C::TD; ++z)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vout[z][r] = fmaxf(acc[z][r] + bias[r], 0.f);
-  }
   const int ly = wave * C::NRB + lr;                                   // this lane's output row inside the tile
   const bool live = jn < C::NRB * C::WB;                               // lanes 14, 15 of a 14-wide column block idle
-  if constexpr ((C::OUT & kOutSplit) != 0) {
-    u32x2* const sp2 = reinterpret_cast<u32x2*>(smem);               // [2 groups][hi, lo][NVO] slots, 8-byte halves
+
+  PHASE_DECL;
+  Item cur = decode(walk.t);
+  issue(cur, 0);
+  PHASE_MARK(0);
+#pragma unroll 1
+  for (int t = walk.t; t < walk.end; t += walk.step) {
+    const int tn = t + walk.step;
+    const bool has_next = C::PERSIST && tn < walk.end;
+    const Item nxt = decode(has_next ? tn : t);
 #pragma unroll
-    for (int z = 0; z < C::TD; ++z) {
-      if (!live) break;
-      unsigned h[4], l[4];
+    for (int z = 0; z < C::TD; ++z) acc[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int chunk = 0; chunk < C::NCH; ++chunk) {
+      __syncthreads();                 // the previous chunk's MFMAs / the previous item's output staging are done with the LDS
+      commit();
+      if (chunk == 0 && tid < 16) xs[(tid >> 3) * C::NVOXP + C::NVOX + (tid & 7)] = (u32x4){0u, 0u, 0u, 0u};   // pad slots stay finite
+      __syncthreads();
+      PHASE_MARK(1);
+      if (chunk + 1 < C::NCH) issue(cur, chunk + 1);
+      else if (XPRE && has_next) issue(nxt, 0);
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {
+        bf16x8 a_hi[3], a_lo[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          a_hi[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2) * 64]);
+          a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
+        }
+        const int rowbase = (C::S * (wave * C::NRB + lr) + ky) * C::IW + C::S * lxo + kq;
+#pragma unroll
+        for (int iz = 0; iz < C::ID; ++iz) {
+          const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW]);
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW + C::NVOXP]);
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            const int z2 = iz - kz;
+            if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+              acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
+          }
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            const int z2 = iz - kz;
+            if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+              acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z2 / C::S], 0, 0, 0);
+          }
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            const int z2 = iz - kz;
+            if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
+              acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
+          }
+        }
+      }
+      PHASE_MARK(2);
+    }
+    __syncthreads();                 // the input tile is dead: its LDS stages the output tile
+    PHASE_MARK(3);
+
+    // ---- bias + ReLU, through LDS, out in 16-byte (split layout) and / or 8-byte (fp32 rows) pieces ---------------
+    const int cg = cur.cg, n = cur.n, oz0 = cur.oz0, oy0 = cur.oy0, ox0 = cur.ox0;
+    float vout[C::TD][4];
+    {
+      // the bias comes through SGPRs (a per-lane vector load here would make the epilogue wait for the prefetched tile)
+      float bias[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        h[r] = bf16_rne(vout[z][r]);
-        l[r] = bf16_rne(vout[z][r] - __uint_as_float(h[r] << 16));
+        const float b0 = p.bias[cg * 16 + r], b1 = p.bias[cg * 16 + 4 + r], b2 = p.bias[cg * 16 + 8 + r], b3 = p.bias[cg * 16 + 12 + r];
+        bias[r] = lane_select(kq & 2, lane_select(kq & 1, b3, b2), lane_select(kq & 1, b1, b0));
       }
-      const int vox = (z * C::TH + ly) * C::TW + lxo;
-      sp2[((((kq >> 1) * 2 + 0) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-      sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
-    }
-    __syncthreads();
-    u32x4* const outs = reinterpret_cast<u32x4*>(p.out_split) + ((size_t)n * (C::COUT / 8) + cg * 2) * 2 * out_plane;
-    const u32x4* const sq = reinterpret_cast<const u32x4*>(smem);
-    for (int i = tid; i < 4 * C::NVO; i += 256) {
-      const int gp = i / C::NVO, vox = i % C::NVO;
-      const int gz = oz0 + vox / (C::TH * C::TW), gy = oy0 + (vox / C::TW) % C::TH, gx = ox0 + vox % C::TW;
-      if (gz < p.Do && gy < p.Ho && gx < p.Wo) outs[(size_t)gp * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx] = sq[i];
-    }
-    if constexpr ((C::OUT & kOutF32) != 0) __syncthreads();
-  }
-  if constexpr ((C::OUT & kOutF32) != 0) {
-    constexpr int OCS = C::NVO + 2;
-    float* const os = reinterpret_cast<float*>(smem);                // [16 co][NVO (+2)]
-    if (live) {
 #pragma unroll
       for (int z = 0; z < C::TD; ++z)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) os[(4 * kq + r) * OCS + (z * C::TH + ly) * C::TW + lxo] = vout[z][r];
+        for (int r = 0; r < 4; ++r) vout[z][r] = fmaxf(acc[z][r] + bias[r], 0.f);
     }
-    __syncthreads();
-    constexpr int NR = C::TD * C::TH, QPR = C::TW / 2;
-    for (int i = tid; i < 16 * NR * QPR; i += 256) {
-      const int co = i / (NR * QPR), row = (i / QPR) % NR, q = i % QPR;
-      const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 2 * q;
-      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
-      const float2 v = *reinterpret_cast<const float2*>(os + co * OCS + row * C::TW + 2 * q);
-      float* o = p.out_f32 + ((size_t)n * C::COUT + cg * 16 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-      if (gx + 1 < p.Wo && (p.Wo & 1) == 0) *reinterpret_cast<float2*>(o) = v;
-      else { o[0] = v.x; if (gx + 1 < p.Wo) o[1] = v.y; }
+    if constexpr ((C::OUT & kOutSplit) != 0) {
+      u32x2* const sp2 = reinterpret_cast<u32x2*>(smem);               // [2 groups][hi, lo][NVO] slots, 8-byte halves
+#pragma unroll
+      for (int z = 0; z < C::TD; ++z) {
+        if (!live) break;
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = bf16_rne(vout[z][r]);
+          l[r] = bf16_rne(vout[z][r] - __uint_as_float(h[r] << 16));
+        }
+        const int vox = (z * C::TH + ly) * C::TW + lxo;
+        sp2[((((kq >> 1) * 2 + 0) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+      }
+      __syncthreads();
+      u32x4* const outs = reinterpret_cast<u32x4*>(p.out_split) + ((size_t)n * (C::COUT / 8) + cg * 2) * 2 * out_plane;
+      const u32x4* const sq = reinterpret_cast<const u32x4*>(smem);
+      for (int i = tid; i < 4 * C::NVO; i += 256) {
+        const int gp = i / C::NVO, vox = i % C::NVO;
+        const int gz = oz0 + vox / (C::TH * C::TW), gy = oy0 + (vox / C::TW) % C::TH, gx = ox0 + vox % C::TW;
+        if (gz < p.Do && gy < p.Ho && gx < p.Wo) outs[(size_t)gp * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx] = sq[i];
+      }
+      if constexpr ((C::OUT & kOutF32) != 0) __syncthreads();
     }
+    if constexpr ((C::OUT & kOutF32) != 0) {
+      constexpr int OCS = C::NVO + 2;
+      float* const os = reinterpret_cast<float*>(smem);                // [16 co][NVO (+2)]
+      if (live) {
+#pragma unroll
+        for (int z = 0; z < C::TD; ++z)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) os[(4 * kq + r) * OCS + (z * C::TH + ly) * C::TW + lxo] = vout[z][r];
+      }
+      __syncthreads();
+      constexpr int NR = C::TD * C::TH, QPR = C::TW / 2;
+      for (int i = tid; i < 16 * NR * QPR; i += 256) {
+        const int co = i / (NR * QPR), row = (i / QPR) % NR, q = i % QPR;
+        const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 2 * q;
+        if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;
+        const float2 v = *reinterpret_cast<const float2*>(os + co * OCS + row * C::TW + 2 * q);
+        float* o = p.out_f32 + ((size_t)n * C::COUT + cg * 16 + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+        if (gx + 1 < p.Wo && (p.Wo & 1) == 0) *reinterpret_cast<float2*>(o) = v;
+        else { o[0] = v.x; if (gx + 1 < p.Wo) o[1] = v.y; }
+      }
+    }
+    PHASE_MARK(4);
+    if (!C::PERSIST) break;
+    cur = nxt;
   }
-  PHASE_MARK(4);
   PHASE_FLUSH;
 }
 
@@ -1719,7 +1752,17 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
   }
   {
     v3d::TimedScope ts(name, s);
-    convg_bf16x2_kernel<C><<<dim3((unsigned)blocks, C::NCG), 256, C::LDS_BYTES, s>>>(p);
+    unsigned grid = (unsigned)((blocks * C::NCG + 7) / 8 * 8);        // one (tile, channel group) item per workgroup ...
+    if (C::PERSIST) {                                                  // ... or as many workgroups as the chip holds
+      static int wgs_per_cu = 0;
+      if (wgs_per_cu == 0) {
+        int nb = 0;
+        V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)convg_bf16x2_kernel<C>, 256, C::LDS_BYTES));
+        wgs_per_cu = nb > 0 ? nb : 1;
+      }
+      grid = v3d::persistent_grid(blocks * C::NCG, wgs_per_cu);
+    }
+    convg_bf16x2_kernel<C><<<grid, 256, C::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH(name);
   return V3D_OK;
