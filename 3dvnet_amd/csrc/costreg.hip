@@ -850,8 +850,10 @@ struct ConvGParams {
 // per workgroup, conv1 (one chunk) had no prefetch at all -- load, wait, compute, store, exit.  Where C::PERSIST is set the
 // first chunk of the next item is requested before the MFMAs of the current item's last chunk; elsewhere the walk has one
 // item per workgroup.
+// `bias_r` = p.bias as a __restrict__ kernel argument: read inside the item loop after the previous item's stores, it can
+// only stay a scalar load if the compiler can exclude that the outputs alias it.
 template <class C>
-__global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p) {
+__global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p, const float* __restrict__ bias_r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const xs = reinterpret_cast<u32x4*>(smem);                 // [hi, lo][NVOXP] slots of the current chunk
   u32x4* const wq = xs + 2 * C::NVOXP;                              // [9][hi, lo][64] weight fragments
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
       float bias[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float b0 = p.bias[cg * 16 + r], b1 = p.bias[cg * 16 + 4 + r], b2 = p.bias[cg * 16 + 8 + r], b3 = p.bias[cg * 16 + 12 + r];
+        const float b0 = bias_r[cg * 16 + r], b1 = bias_r[cg * 16 + 4 + r], b2 = bias_r[cg * 16 + 8 + r], b3 = bias_r[cg * 16 + 12 + r];
         bias[r] = lane_select(kq & 2, lane_select(kq & 1, b3, b2), lane_select(kq & 1, b1, b0));
       }
 #pragma unroll
@@ -1762,7 +1764,7 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
       }
       grid = v3d::persistent_grid(blocks * C::NCG, wgs_per_cu);
     }
-    convg_bf16x2_kernel<C><<<grid, 256, C::LDS_BYTES, s>>>(p);
+    convg_bf16x2_kernel<C><<<grid, 256, C::LDS_BYTES, s>>>(p, p.bias);
   }
   V3D_CHECK_LAUNCH(name);
   return V3D_OK;

@@ -68,33 +68,33 @@ __global__ __launch_bounds__(256) void transpose_channel_last_kernel(const float
 // [n_img, C, Hf, Wf] -> [n_img, Hf + 2, Wf + 2, C] with a border of zero cells (+ one zero row behind the last image).
 // grid_sample's padding_mode='zeros' then needs no per-tap validity test in the warp kernels: a tap outside the image reads
 // a zero cell, and a sample further out is clamped onto the border, where both of its in-range taps are zero cells and the
-// other two carry weight 0 (make_taps).  One workgroup = 64 cells of one padded row.
+// other two carry weight 0 (make_taps).  One workgroup = 64 consecutive cells of one padded image.
 template <int C>
 __global__ __launch_bounds__(256) void transpose_bordered_kernel(const float* __restrict__ in, float* __restrict__ out, int Hf,
                                                                   int Wf, int n_img) {
   __shared__ float tile[C][kPix + 1];
-  const int img = blockIdx.z, yb = blockIdx.y, x0 = blockIdx.x * kPix;
-  const int Wp = Wf + 2, HW = Hf * Wf;
-  const float* src = in + (size_t)img * C * HW + (size_t)(yb - 1) * Wf - 1;
-  float* dst = out + ((size_t)img * (Hf + 2) + yb) * Wp * C;
-  const bool row_in = yb >= 1 && yb <= Hf;
+  const int img = blockIdx.y;
+  const int Wp = Wf + 2, HW = Hf * Wf, n_cell = (Hf + 2) * Wp;
+  const int q0 = blockIdx.x * kPix;                      // 64 consecutive cells of the padded image (row-major)
+  const float* src = in + (size_t)img * C * HW;
+  float* dst = out + (size_t)img * n_cell * C;
   for (int i = threadIdx.x; i < C * kPix; i += 256) {
-    const int c = i / kPix, xb = x0 + i % kPix;
-    tile[c][i % kPix] = (row_in && xb >= 1 && xb <= Wf) ? src[(size_t)c * HW + xb] : 0.f;
+    const int c = i / kPix, q = q0 + i % kPix;
+    const int yb = q / Wp, xb = q - yb * Wp;
+    const bool inside = q < n_cell && yb >= 1 && yb <= Hf && xb >= 1 && xb <= Wf;
+    tile[c][i % kPix] = inside ? src[(size_t)c * HW + (yb - 1) * Wf + xb - 1] : 0.f;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C * kPix; i += 256) {
     const int px = i / C, c = i % C;
-    if (x0 + px < Wp) dst[(size_t)(x0 + px) * C + c] = tile[c][px];
+    if (q0 + px < n_cell) dst[(size_t)(q0 + px) * C + c] = tile[c][px];
   }
   // A sample clamped onto the lower border reads its weight-0 taps one padded row further down: the next image's top border,
   // or, behind the last image, this extra row of zero cells (+ one cell for the tap right of its last cell).  Weight 0 times
   // recycled memory holding a NaN pattern would be NaN.
-  if (img == n_img - 1 && yb == Hf + 1) {
-    float* tail = out + (size_t)n_img * (Hf + 2) * Wp * C;
-    for (int i = threadIdx.x; i < C * kPix; i += 256)
-      if (x0 + i / C < Wp) tail[(size_t)(x0 + i / C) * C + i % C] = 0.f;
-    if (blockIdx.x == 0 && threadIdx.x < C) tail[(size_t)Wp * C + threadIdx.x] = 0.f;
+  if (img == n_img - 1 && blockIdx.x == 0) {
+    float* tail = out + (size_t)n_img * n_cell * C;
+    for (int i = threadIdx.x; i < (Wp + 1) * C; i += 256) tail[i] = 0.f;
   }
 }
 
@@ -691,7 +691,7 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   float* camp = (float*)((char*)workspace + v3d::align_up(psv_feat_bytes(n_img, C, Hf, Wf), 256));
   {
     v3d::TimedScope ts("transpose_channel_last", s);
-    const dim3 tg((Wf + 2 + kPix - 1) / kPix, Hf + 2, n_img);
+    const dim3 tg(((Hf + 2) * (Wf + 2) + kPix - 1) / kPix, n_img);
     if (C == 32) transpose_bordered_kernel<32><<<tg, 256, 0, s>>>(feat, featT, Hf, Wf, n_img);
     else transpose_bordered_kernel<16><<<tg, 256, 0, s>>>(feat, featT, Hf, Wf, n_img);
   }
