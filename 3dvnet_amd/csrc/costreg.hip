@@ -506,12 +506,13 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 #ifndef V3D_C0_ABLATE
 #define V3D_C0_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no MFMAs (0.82 ms), 2 no input loads (0.84), 3 no LDS commit (0.97), 4 no output stores (1.06), 5 stores into a 2 MB window (1.07), 6 loads from a 1 MB window (1.02); full kernel 1.09 ms per 64 views
 #endif
-// PERSISTENT: the grid is (at most) the number of workgroups the chip holds at once; a workgroup walks tiles
-// first + i, first + i + G, ... of its XCD's contiguous run (v3d::xcd_tile_walk), and the chunk pipeline runs straight across
-// tile boundaries: the first chunk of the next tile is requested during the last MFMA phase of the current one, and the
-// output stores of a tile drain while the next tile is already being staged.  Measured equal to one tile per workgroup
-// (1.09 vs 1.11 ms per 64 views, -DV3D_C0_ONE_TILE): the kernel is bound by the per-chunk chain load -> commit -> barrier ->
-// MFMA with one chunk of prefetch (registers) and a single LDS buffer (ablations at V3D_C0_ABLATE), not by tile turnover.
+// The kernel is written as a tile walk (v3d::xcd_tile_walk): with a grid of the workgroups the chip holds at once
+// (-DV3D_C0_PERSIST) a workgroup walks tiles first + i, first + i + G, ... of its XCD's contiguous run and the chunk pipeline
+// runs straight across tile boundaries (the first chunk of the next tile is requested during the last MFMA phase of the
+// current one).  Measured equal to one tile per workgroup (1.09 vs 1.11 ms per 64 views) with 15 % more halo traffic
+// (4.30 vs 3.74 GB fetched: the resident workgroups run in lock step and share less in L2), so the default grid is one
+// workgroup per tile: the kernel is bound by the per-chunk chain load -> commit -> barrier -> MFMA with one chunk of
+// prefetch (registers) and a single LDS buffer (ablations at V3D_C0_ABLATE), not by tile turnover.
 template <bool SPLIT_IN, bool SPLIT_OUT, int NW>
 __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvParams p) {
   constexpr int NT = 64 * NW, RPI = NT / 32, RPW = C0::TH / NW;      // threads, staging rows per iteration, rows per wave
@@ -1718,10 +1719,10 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-#ifdef V3D_C0_ONE_TILE      // developer A/B: one tile per workgroup (the walk degenerates)
-    const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
+#ifdef V3D_C0_PERSIST       // developer A/B: 512 resident workgroups walking their tiles (same time, 15 % more halo traffic)
+    const unsigned grid = v3d::persistent_grid(blocks, 2);        // 76.8 KB of LDS: two workgroups per CU
 #else
-    const unsigned grid = v3d::persistent_grid(blocks, 2);        // 76.8 KB of LDS: two workgroups per CU, each walks its tiles
+    const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);       // one tile per workgroup: the walk has a single step
 #endif
     if (split_in && split_out) conv0_bf16x2_kernel<true, true, kC0Waves><<<grid, 64 * kC0Waves, C0::LDS_BYTES, s>>>(p);
     else if (split_in) conv0_bf16x2_kernel<true, false, 4><<<grid, 256, C0::LDS_BYTES, s>>>(p);

@@ -22,13 +22,35 @@ struct CsrMeta {
 };
 constexpr int kMagic = 0x43535231;   // "CSR1"
 
+// Inclusive sum over the 1024 threads of the workgroup (wave shuffles + 16 wave totals in LDS: two barriers); `total` = sum of all.
+__device__ __forceinline__ int block_inclusive_sum(int v, int* s_wave, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  __syncthreads();                       // s_wave may still be read from the previous call
+  if (lane == 63) s_wave[wave] = v;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    const int x = s_wave[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  total = tot;
+  return v + base;
+}
+
 // workspace: [CsrMeta][rank: n_img ints][count: n_ref_expected ints]
 __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __restrict__ edges, int n_edges, int n_img,
                                                               int n_ref_expected, int* __restrict__ ref_img,
                                                               int* __restrict__ edge_ofs, int* __restrict__ edge_src,
                                                               CsrMeta* __restrict__ meta, int* __restrict__ rank,
                                                               int* __restrict__ count) {
-  __shared__ int s_part[kThreads];
+  __shared__ int s_wave[kWaves];
   __shared__ int s_err;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long* const e_ref = edges;
@@ -50,16 +72,8 @@ __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __
   const int lo = min(tid * per, n_img), hi = min(lo + per, n_img);
   int sum = 0;
   for (int i = lo; i < hi; ++i) sum += rank[i];
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int ofs = 1; ofs < kThreads; ofs <<= 1) {
-    const int v = tid >= ofs ? s_part[tid - ofs] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  const int n_ref = s_part[kThreads - 1];
-  int run = s_part[tid] - sum;
+  int n_ref;
+  int run = block_inclusive_sum(sum, s_wave, n_ref) - sum;
   for (int i = lo; i < hi; ++i) {
     const int f = rank[i];
     rank[i] = f ? run : -1;
@@ -89,17 +103,10 @@ __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __
   const int rlo = min(tid * per_r, n_ref), rhi = min(rlo + per_r, n_ref);
   sum = 0;
   for (int r = rlo; r < rhi; ++r) sum += count[r];
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int ofs = 1; ofs < kThreads; ofs <<= 1) {
-    const int v = tid >= ofs ? s_part[tid - ofs] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  run = s_part[tid] - sum;
+  int n_counted;
+  run = block_inclusive_sum(sum, s_wave, n_counted) - sum;
   for (int r = rlo; r < rhi; ++r) { edge_ofs[r] = run; run += count[r]; }
-  if (tid == 0) edge_ofs[n_ref] = s_part[kThreads - 1];
+  if (tid == 0) edge_ofs[n_ref] = n_counted;
   __syncthreads();
   // 5. fill, original edge order inside a reference's group (stable)
   for (int r = wave; r < n_ref; r += kWaves) {

@@ -402,3 +402,47 @@ class MVSNet(nn.Module):
         depth_img = self.cost_volume_depth(features_quarter, batch, depth_start, depth_interval,
                                            n_planes, depth_img_size, n_ref=n_ref)
         return depth_img, features_half, features_quarter, features_eighth
+
+
+class CostVolumeGraph:
+    """Rows A1-A6 for FIXED shapes captured once into a HIP graph (``torch.cuda.CUDAGraph``) and replayed: the ~17 kernel
+    launches of a step (edge tables, transpose, camera blocks, warp + variance, ten regulariser layers, soft-argmin) become
+    one graph launch, which removes the host's per-launch cost and most of the gaps between dependent kernels.  Nothing in the
+    step synchronises or allocates outside the graph's private pool: the edge tables come from ``v3d_edges_csr`` (``n_ref``
+    is required), the workspaces are the module's cached buffers.
+
+    The graph reads its inputs from the tensors given at capture time (kept alive here); ``update(...)`` copies new data of the
+    same shapes into them, ``replay()`` runs the step and returns the depth tensor [n_ref, h, w] (the same storage each time).
+    No reference counterpart (the reference runs eagerly); results are those of ``MVSNet.cost_volume_depth``, bit for bit."""
+
+    def __init__(self, net, features_quarter, batch, depth_start, depth_interval, n_planes, depth_img_size, n_ref,
+                 precision=None, warmup=2):
+        _require_cuda(features_quarter, 'CostVolumeGraph')
+        self.net = net
+        self.features_quarter = features_quarter
+        self.batch = batch
+        self._args = (depth_start, depth_interval, n_planes, depth_img_size)
+        self._kw = dict(precision=precision, n_ref=int(n_ref))
+        dev = features_quarter.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up on a side stream: lazy one-time setup happens here
+            for _ in range(max(1, warmup)):
+                net.cost_volume_depth(features_quarter, batch, *self._args, **self._kw)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.depth = net.cost_volume_depth(features_quarter, batch, *self._args, **self._kw)
+
+    def update(self, features_quarter=None, rotmats=None, tvecs=None, K=None, ref_src_edges=None):
+        if features_quarter is not None:
+            self.features_quarter.copy_(features_quarter)
+        for name, val in (('rotmats', rotmats), ('tvecs', tvecs), ('K', K), ('ref_src_edges', ref_src_edges)):
+            if val is not None:
+                getattr(self.batch, name).copy_(val)
+
+    def replay(self):
+        self.graph.replay()
+        return self.depth
+

@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 python $R/profiles/summarize_rocpd.py pmc $T/sq/r_results.db $O/pmc_sq.csv
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $T/sq2 -o r -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py pmc $T/sq2/r_results.db $O/pmc_sq2.csv
+# (a pass with the TA_* counters -- TA_BUSY_avr, TA_FLAT_READ_WAVEFRONTS_sum, ... -- never returned on this pool: not collected)
 tail -1 $O/bench_under_rocprof.log | cut -c1-200
 python $R/profiles/make_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $REFS $O/traffic.json
 ls -la $O

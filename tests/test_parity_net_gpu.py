@@ -327,3 +327,29 @@ def test_cost_volume_depth_with_reference_count_hint_is_bit_identical(cuda):
         a = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
         c = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'], n_ref=3)
     assert torch.equal(a, c)
+
+
+def test_cost_volume_graph_replay_equals_eager_and_follows_updates(cuda):
+    """mvsnet.CostVolumeGraph (the step captured into a HIP graph): replay == eager bit for bit; after update() with other
+    features / cameras of the same shapes the replay equals the eager result on those."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=5)
+    d0, dd, D = inp['depth']
+    net = mvs.MVSNet(32, inp['img_size']).eval()
+    net.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
+    net = net.to(cuda)
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    feat = inp['feat'].to(cuda).clone()
+    with torch.no_grad():
+        eager = net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'], n_ref=3).clone()
+    g = mvs.CostVolumeGraph(net, feat, b, d0, dd, D, inp['plane_size'], n_ref=3)
+    assert torch.equal(g.replay(), eager)
+    assert torch.equal(g.replay(), eager)
+    inp2 = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=6)
+    g.update(features_quarter=inp2['feat'].to(cuda), rotmats=inp2['rotmats'].to(cuda), tvecs=inp2['tvecs'].to(cuda))
+    b2 = Batch(None, inp2['rotmats'], inp2['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    with torch.no_grad():
+        eager2 = net.cost_volume_depth(inp2['feat'].to(cuda), b2, d0, dd, D, inp['plane_size'], n_ref=3)
+    assert not torch.equal(eager2, eager)
+    assert torch.equal(g.replay(), eager2)
