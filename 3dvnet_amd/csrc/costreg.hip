@@ -498,10 +498,12 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 // ([n][hi, lo][D][H][W] 16-byte slots) consumed by convh_bf16x2_kernel (conv1) and conv9_prob_kernel (skip).
 // NW = waves per workgroup (4 or 8): with 8, a wave owns one output row of the 4 planes and a CU holds 4 waves per SIMD
 // (2 workgroups), so one wave's LDS / barrier waits are covered by another's MFMAs.
-#ifdef V3D_C0_PLAIN_LOAD
-#define V3D_C0_LOAD(p) (*(p))
-#else
+// conv0's input loads are plain loads: with the non-temporal hint the halo rows a neighbouring tile reads a moment later
+// were not kept in L2 (-DV3D_C0_NT_LOAD: 1.135 vs 1.09 ms per 64 views, two alternating builds on one box).
+#ifdef V3D_C0_NT_LOAD
 #define V3D_C0_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define V3D_C0_LOAD(p) (*(p))
 #endif
 #ifndef V3D_C0_ABLATE
 #define V3D_C0_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no MFMAs (0.82 ms), 2 no input loads (0.84), 3 no LDS commit (0.97), 4 no output stores (1.06), 5 stores into a 2 MB window (1.07), 6 loads from a 1 MB window (1.02); full kernel 1.09 ms per 64 views

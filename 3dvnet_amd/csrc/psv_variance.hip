@@ -587,7 +587,11 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
       const u32x4 slot = half ? (u32x4){r0, r1, l01, l23} : (u32x4){h01, h23, r0, r1};
       const int d = dchunk * kRDB + pl;
       if (gp < P && d < p.D && (V3D_PSV_ABLATE != 4 || slot[0] == 0x12345u))
+#ifdef V3D_PSV_PLAIN_STORE      // developer A/B
+        out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp] = slot;
+#else
         __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);
+#endif
     }
   } else {
 #pragma unroll
