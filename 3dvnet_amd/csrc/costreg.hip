@@ -14,7 +14,7 @@
 //       soft_argmin_kernel       softmax(-x) expectation over the depth planes
 //     Final depth vs the fp32 CPU oracle: 5e-5 relative (gate 1e-4).
 //
-// (2) The exact-fp32 per-layer kernels (v3d_costreg_layer_f32, and the whole chain under V3D_COSTREG_GENERIC=1):
+// (2) The exact-fp32 per-layer kernels (v3d_costreg_layer_f32, and the whole chain with precision = V3D_PRECISION_FP32):
 //     one templated implicit-GEMM kernel on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), described below, plus
 //     prob_conv_kernel.  They were the round's first correct path and remain the reference point for the split
 //     kernels' per-layer parity tests.
