@@ -414,41 +414,52 @@ constexpr int kRE = 64 / (kRDB * kRPix);          // edges per phase-1 pass: kRE
 #ifndef V3D_PSV_WAVES
 #define V3D_PSV_WAVES 4
 #endif
-#ifndef V3D_PSV_ORDER
-#define V3D_PSV_ORDER 1
-#endif
 #ifndef V3D_PSV_ABLATE
 #define V3D_PSV_ABLATE 0     // developer ablations of the reuse kernel (scripts/ab_build.sh): 1 no blend, 2 no reloads, 3 no projection, 4 no store
 #endif
-template <bool SPLIT>
-__global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(PsvParams p) {
-  constexpr int C = 32;
-  __shared__ TapInfo s_tap[kRE * kRDB * kRPix];
-  __shared__ __attribute__((aligned(16))) float s_out[kRDB][C][kRPix + 1];
-  __shared__ float s_ref[24];
-  __shared__ float s_P[kMaxE][12];        // projection matrices of up to kMaxE consecutive edges
-  __shared__ int s_base[kMaxE];           // first feature cell of their source images
+// Waves of one workgroup only meet in the fp32 epilogue: everything else a wave exchanges through LDS is its own (LDS
+// operations of a wave complete in order, so a fence that keeps the compiler from reordering them is enough).
+template <int WPB>
+__device__ __forceinline__ void psv_wave_sync() {
+  if constexpr (WPB == 1) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+}
 
-  const int lane = threadIdx.x;
+// SPLIT = true: single-wave workgroups, the variance leaves in the regulariser's split format (16-byte slots, 128-byte runs per
+// wave).  SPLIT = false (the public fp32 tensor [n_ref, C, D, h, w]): FOUR waves = four consecutive 8-pixel tiles per workgroup;
+// they work independently and only share the output staging, so that a (channel, plane) row leaves as 32 consecutive pixels =
+// 128-byte runs.  With one wave per workgroup the rows were 32-byte runs: 3.95 GB written for a 2.47 GB volume, 3.6 ms per 64
+// views against 1.7 ms for the split variant.
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_reuse_kernel(PsvParams p) {
+  constexpr int C = 32, WPB = SPLIT ? 1 : 4;
+  constexpr int kOutPl = 4;               // planes staged per round of the fp32 epilogue
+  static_assert(SPLIT || kRDB % kOutPl == 0, "fp32 epilogue stages 4 planes per round");
+  __shared__ TapInfo s_tap_[WPB][kRE * kRDB * kRPix];
+  __shared__ __attribute__((aligned(16))) float s_out[SPLIT ? 1 : kOutPl][SPLIT ? 1 : C][SPLIT ? 1 : WPB * kRPix + 1];
+  __shared__ float s_ref_[WPB][24];
+  __shared__ float s_P_[WPB][kMaxE][12];  // projection matrices of up to kMaxE consecutive edges
+  __shared__ int s_base_[WPB][kMaxE];     // first feature cell of their source images
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  TapInfo* const s_tap = s_tap_[wv];
+  float* const s_ref = s_ref_[wv];
+  float (*const s_P)[12] = s_P_[wv];
+  int* const s_base = s_base_[wv];
   const int n_dchunk = (p.D + kRDB - 1) / kRDB;
   int b = v3d::xcd_contiguous_block();
-#if V3D_PSV_ORDER == 1
   // plane chunks fastest: the waves resident on an XCD sweep all planes of a few pixel tiles, i.e. short epipolar segments of
   // the source maps, instead of one plane chunk of the whole image (= every source map entirely, more than the 4 MB L2)
   const int dchunk = b % n_dchunk; b /= n_dchunk;
-  const int ptile = b % p.n_ptile;
+  const int ptile = (b % p.n_ptile) * WPB + wv;      // p.n_ptile counts groups of WPB tiles
   const int r = b / p.n_ptile;
-#else
-  const int ptile = b % p.n_ptile; b /= p.n_ptile;
-  const int dchunk = b % n_dchunk;
-  const int r = b / n_dchunk;
-#endif
   const int P = p.h * p.w;
   const int e_begin = p.edge_ofs[r], e_end = p.edge_ofs[r + 1];
   const int ne = e_end - e_begin;
   const int ref = p.ref_img[r];
   if (lane < 21) s_ref[lane] = p.camp[ref * kCamStride + lane];
-  __syncthreads();
+  psv_wave_sync<WPB>();
 
   // phase-1 role: lane = (edge slot, plane, pixel); the world point of (pixel, plane) is the same for every edge
   const int e1 = lane / (kRDB * kRPix), pl1 = (lane >> 3) & (kRDB - 1), px1 = lane & 7;
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
   PHASE_DECL;
   for (int ec = 0; ec < ne; ec += kRE) {
     const int nec = min(kRE, ne - ec);
-    __syncthreads();                       // the previous pass is done with s_tap / s_P
+    psv_wave_sync<WPB>();                  // the previous pass is done with s_tap / s_P
     PHASE_MARK(0);
     if (ec % kMaxE == 0) {
       const int nload = min(kMaxE, ne - ec) * 12;
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
         s_P[i / 12][i % 12] = p.camp[src * kCamStride + 24 + i % 12];
         if (i % 12 == 0) s_base[i / 12] = src * (p.Hf + 2) * (p.Wf + 2);      // cell (-1, -1) of the bordered map
       }
-      __syncthreads();
+      psv_wave_sync<WPB>();
     }
 #if V3D_PSV_ABLATE == 3      // developer ablation: no projection (tap records written once)
     if (ec == 0)
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
       v3d::sample_position(s_P[ec % kMaxE + e1], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
       s_tap[(e1 * kRDB + pl1) * kRPix + px1] = make_taps<4 * C>(ix, iy, p.Wf, p.Hf, s_base[ec % kMaxE + e1]);
     }
-    __syncthreads();
+    psv_wave_sync<WPB>();
     PHASE_MARK(1);
     for (int e = 0; e < nec; ++e) {
       unsigned c00 = ~0u;                // footprint held in t00..t11 (its nw cell pins all four)
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
 
   PHASE_MARK(2);
   // ---- variance -> LDS -> stores ------------------------------------------------------------------------------
-  __syncthreads();
+  psv_wave_sync<WPB>();
   const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
   // x / cnt is an IEEE division (~10 instructions); for a power-of-two count (8 views in the headline configuration)
   // x * (1 / cnt) is the same number exactly.  Wave-uniform choice.
@@ -594,19 +605,29 @@ __global__ __launch_bounds__(64, V3D_PSV_WAVES) void psv_variance_reuse_kernel(P
 #endif
     }
   } else {
+    // fp32 tensor: the four waves park kOutPl planes of their 8 pixels side by side ([plane][channel][32 pixels]) and the
+    // workgroup stores every (channel, plane) row as one 128-byte run
+    constexpr int NPX = WPB * kRPix;
+    const int gp0 = (ptile - wv) * kRPix;             // first pixel of the workgroup
 #pragma unroll
-    for (int pl = 0; pl < kRDB; ++pl)
+    for (int round = 0; round < kRDB / kOutPl; ++round) {
+      if (round) __syncthreads();                      // the previous round's rows are stored
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float avg = mean(acc_s[pl][k]);
-        const float avg_sq = mean(acc_q[pl][k]);
-        s_out[pl][cg * 4 + k][gpx] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
+      for (int q = 0; q < kOutPl; ++q) {
+        const int pl = round * kOutPl + q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float avg = mean(acc_s[pl][k]);
+          const float avg_sq = mean(acc_q[pl][k]);
+          s_out[q][cg * 4 + k][wv * kRPix + gpx] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
+        }
       }
-    __syncthreads();
-    for (int i = lane; i < kRDB * C * kRPix; i += 64) {
-      const int pl = i / (C * kRPix), c = (i / kRPix) % C, px = i % kRPix;
-      const int gp = ptile * kRPix + px, d = dchunk * kRDB + pl;
-      if (gp < P && d < p.D) __builtin_nontemporal_store(s_out[pl][c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
+      __syncthreads();
+      for (int i = threadIdx.x; i < kOutPl * C * NPX; i += 64 * WPB) {
+        const int q = i / (C * NPX), c = (i / NPX) % C, px = i % NPX;
+        const int gp = gp0 + px, d = dchunk * kRDB + round * kOutPl + q;
+        if (gp < P && d < p.D) __builtin_nontemporal_store(s_out[q][c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
+      }
     }
   }
   PHASE_MARK(3);
@@ -736,7 +757,11 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
       V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
       p.n_ptile = (h * w + kRPix - 1) / kRPix;
       if (split) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
-      else psv_variance_reuse_kernel<false><<<(unsigned)rblocks, 64, 0, s>>>(p);
+      else {      // four 8-pixel tiles per workgroup
+        p.n_ptile = (p.n_ptile + 3) / 4;
+        const long long fblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * p.n_ptile;
+        psv_variance_reuse_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
+      }
     } else if (split) V3D_PSV(32, true);
     else if (C == 32) V3D_PSV(32, false);
     else V3D_PSV(16, false);

@@ -204,9 +204,10 @@ def test_fused_path_partial_tiles_and_ragged_edges(cuda):
     assert float(depth_o.max() - depth_o.min()) > 0.5
 
 
-def test_psv_ragged_edges_and_odd_grid(cuda):
+@pytest.mark.parametrize('D', [6, 13])
+def test_psv_ragged_edges_and_odd_grid(D, cuda):
     """Ragged edge lists (1, 3 and 10 sources -- more than one LDS pass), a plane grid that is not
-    a multiple of the 64-pixel tile, D not a multiple of the plane chunk, unsorted edge order."""
+    a multiple of the 8-pixel tile, D smaller than / not a multiple of the 8-plane chunk, unsorted edge order."""
     syn, mvs = v3d('synthetic'), v3d('mvsnet')
     img_size, feat_size, plane_size = (64, 80), (16, 20), (7, 9)
     R, tv, K = syn.make_cameras(12, img_size, seed=3)
@@ -216,13 +217,13 @@ def test_psv_ragged_edges_and_odd_grid(cuda):
     perm = torch.randperm(len(refs), generator=torch.Generator().manual_seed(0))
     edges = torch.tensor([refs, srcs])[:, perm]
     from oracle import pinned
-    var_o = pinned.warp_variance(feat, R, tv, K, edges, 0.5, 0.3, 6, img_size, plane_size)
-    var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 6, img_size,
+    var_o = pinned.warp_variance(feat, R, tv, K, edges, 0.5, 0.3, D, img_size, plane_size)
+    var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, D, img_size,
                                    plane_size)
     torch.cuda.synchronize()
     np.testing.assert_allclose(var.cpu().numpy(), var_o.numpy(), rtol=0, atol=VAR_ATOL)
     # the split hand-off format of the same volume: hi + lo of exactly these numbers
-    sv = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 6, img_size, plane_size,
+    sv = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, D, img_size, plane_size,
                                   split=True)
     assert torch.equal(_decode_split(sv), _split_roundtrip(var))
 
