@@ -21,6 +21,7 @@ struct CsrMeta {
   int pad;
 };
 constexpr int kMagic = 0x43535231;   // "CSR1"
+constexpr int kLdsImgs = 4096, kLdsEdges = 8192;
 
 // Inclusive sum over the 1024 threads of the workgroup (wave shuffles + 16 wave totals in LDS: two barriers); `total` = sum of all.
 __device__ __forceinline__ int block_inclusive_sum(int v, int* s_wave, int& total) {
@@ -48,10 +49,16 @@ __device__ __forceinline__ int block_inclusive_sum(int v, int* s_wave, int& tota
 __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __restrict__ edges, int n_edges, int n_img,
                                                               int n_ref_expected, int* __restrict__ ref_img,
                                                               int* __restrict__ edge_ofs, int* __restrict__ edge_src,
-                                                              CsrMeta* __restrict__ meta, int* __restrict__ rank,
+                                                              CsrMeta* __restrict__ meta, int* rank,
                                                               int* __restrict__ count) {
   __shared__ int s_wave[kWaves];
   __shared__ int s_err;
+  // small problems (every cost-volume batch) keep the rank table in LDS and cache every edge's reference rank there, so
+  // the per-reference passes below never touch global memory; larger ones use the workspace
+  __shared__ int s_rank[kLdsImgs];
+  __shared__ int s_er[kLdsEdges];
+  const bool small = n_img <= kLdsImgs && n_edges <= kLdsEdges;
+  if (small) rank = s_rank;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long* const e_ref = edges;
   const long long* const e_src = edges + n_edges;
@@ -87,12 +94,17 @@ __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __
     for (int r = tid; r <= n_ref_expected; r += kThreads) edge_ofs[r] = 0;
     return;
   }
+  if (small) {
+    for (int e = tid; e < n_edges; e += kThreads) s_er[e] = rank[e_ref[e]];
+    __syncthreads();
+  }
+  auto edge_rank = [&](int e) __attribute__((always_inline)) { return small ? s_er[e] : rank[e_ref[e]]; };
   // 3. edges per reference: wave w counts references w, w + 16, ... (ballot + popcount over the edge list)
   for (int r = wave; r < n_ref; r += kWaves) {
     int c = 0;
     for (int e0 = 0; e0 < n_edges; e0 += 64) {
       const int e = e0 + lane;
-      const bool hit = e < n_edges && rank[e_ref[e]] == r;
+      const bool hit = e < n_edges && edge_rank(e) == r;
       c += __builtin_popcountll(__ballot(hit));
     }
     if (lane == 0) count[r] = c;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __
     int pos = edge_ofs[r];
     for (int e0 = 0; e0 < n_edges; e0 += 64) {
       const int e = e0 + lane;
-      const bool hit = e < n_edges && rank[e_ref[e]] == r;
+      const bool hit = e < n_edges && edge_rank(e) == r;
       const unsigned long long m = __ballot(hit);
       if (hit) edge_src[pos + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)e_src[e];
       pos += __builtin_popcountll(m);
