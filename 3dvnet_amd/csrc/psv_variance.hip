@@ -397,13 +397,13 @@ __global__ __launch_bounds__(THREADS) void psv_variance_kernel(PsvParams p) {
 // of the next plane differs, edge by edge.  Arithmetic and accumulation order per (pixel, plane) are those of
 // the gather kernel (bit-identical output).
 //
-// What bounds it (round-2 measurements, cfg2, 64 views): the vector-memory path.  A step = one (plane, edge) for the wave's 8
-// pixels; a footprint reload is four 1 KB wave loads at 16 cycles each on the CU's single address/L1 path, issued when ANY
-// of the 8 pixels changed its footprint, with the other pixels' lanes masked.  The kernel completes one step per ~48 cycles
-// and CU at 4 or at 5 waves per SIMD alike, i.e. 3 of the 4 possible load instructions per step.  Consequences measured:
-// 18 % fewer VALU instructions in the loop (bordered maps, one offset per sample): no change; 8 planes per wave instead
-// of 4 (one forced first-plane reload per 8 steps instead of per 4): -7 %, although only 4 waves per SIMD fit; 2 planes
-// per wave at 8 waves per SIMD: +19 %; partial reloads and a persistent tile walk: slower (see below / DESIGN.md).
+// What bounds it (round-2 measurements, cfg2, 64 views): no single pipe.  A step = one (plane, edge) for the
+// wave's 8 pixels; a footprint reload is four 1 KB wave loads, issued when ANY of the 8 pixels changed its footprint, with the
+// other pixels' lanes masked: 1.8 wave loads per step at 8 planes per wave (scripts/sim_footprint_reloads.py), ~29 of the ~48
+// cycles a CU spends per step; VALU ~70 % busy, LDS ~35 %, HBM traffic 1.08x algorithmic.  Measured: 18 % fewer VALU
+// instructions in the loop (bordered maps, one offset per sample): no change; 8 planes per wave instead of 4 (2.1 -> 1.8
+// loads per step): -7 %, although only 4 waves per SIMD fit; 2 planes per wave at 8 waves per SIMD: +19 %; partial reloads,
+// a persistent tile walk, 4x2 pixel blocks: equal or slower.
 constexpr int kRPix = 8;      // pixels per wave
 #ifndef V3D_PSV_RDB
 #define V3D_PSV_RDB 8
