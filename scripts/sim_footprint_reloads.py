@@ -32,6 +32,8 @@ for src in srcs:
     chg = np.ones((D, h, w), bool); bb = b.reshape(D, h, w); chg[1:] = bb[1:] != bb[:-1]; chg[::8] = True
     blk = chg.reshape(D, h // 2, 2, w // 4, 4).any(axis=(2, 4))
     count('reload_steps_4x2', int(blk.sum()))
+    blk24 = chg.reshape(D, h // 4, 4, w // 2, 2).any(axis=(2, 4))
+    count('reload_steps_2x4', int(blk24.sum()))
     col = chg.reshape(D, h // 8, 8, w).any(axis=2)
     count('reload_steps_1x8', int(col.sum()))
     # 3x2 window anchored at even x: footprint id = (y0, x0 // 2 * 2) with special: x0 odd -> cells x0,x0+1 = anchor+1, anchor+2 ok
@@ -46,6 +48,7 @@ for src in srcs:
     count('moves_x', int((dx > 0).sum())); count('moves_y', int((dy > 0).sum())); count('moves_big', int(((dx > 1) | (dy > 1)).sum()))
 steps = tot['steps']
 for k, v in tot.items(): print('%-24s %10d  %.3f per step' % (k, v, v / steps))
+print('2x4 loads/step: %.2f' % (4 * tot['reload_steps_2x4'] / steps))
 print('loads/step now (RDB8): %.2f ; RDB4: %.2f ; 4x2: %.2f ; 1x8: %.2f ; win3x2 (6 loads): %.2f ; win3x3 (9 loads): %.2f' % (
     4 * tot['reload_steps_RDB8'] / steps, 4 * tot['reload_steps_RDB4'] / steps, 4 * tot['reload_steps_4x2'] / steps,
     4 * tot['reload_steps_1x8'] / steps, 6 * tot['reload_steps_win3x2'] / steps, 9 * tot['reload_steps_win3x3'] / steps))
