@@ -93,7 +93,20 @@ struct ConvParams {
   float* out;
   int n, Di, Hi, Wi, Do, Ho, Wo, ntz, nty, ntx;
   int relu;
+  int zy_order;        // tile order inside a view: 0 = x, y, z (z slowest), 1 = x, z, y (conv0 on large planes, see tile_order())
 };
+
+// The workgroups resident on an XCD (64 tiles of conv0 / conv9+prob) should be neighbours in the directions with the most
+// halo: a 4 x 8 x 28 tile re-reads 50 % in z, 25 % in y, 7 % in x.  With x, y, z order they cover several whole z slabs when
+// a slab is small (cfg2: 2 x 7 = 14 tiles) but only part of one when it is large (cfg5: 6 x 15 = 90 tiles: conv0 fetched
+// 1.5x its input); then x, z, y order puts z neighbours side by side.
+inline int tile_order(int ntx, int nty) {
+#ifdef V3D_TILE_ORDER_XYZ      // developer A/B
+  return 0;
+#else
+  return ntx * nty > 32 ? 1 : 0;
+#endif
+}
 
 template <int MODE_, int CIN_, int COUT_, int TD_, int TH_, int TW_, int CK_, int OCC_ = 2>
 struct ConvCfg {
@@ -535,9 +548,10 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
   auto decode = [&](int t) __attribute__((always_inline)) {
     Tile q;
     const int tx = t % p.ntx; t /= p.ntx;
-    const int ty = t % p.nty; t /= p.nty;
-    q.oz0 = (t % p.ntz) * C0::TD; q.n = t / p.ntz;
-    q.oy0 = ty * C0::TH; q.ox0 = tx * C0::TW;
+    int ty, tz;
+    if (p.zy_order) { tz = t % p.ntz; t /= p.ntz; ty = t % p.nty; q.n = t / p.nty; }
+    else { ty = t % p.nty; t /= p.nty; tz = t % p.ntz; q.n = t / p.ntz; }
+    q.oz0 = tz * C0::TD; q.oy0 = ty * C0::TH; q.ox0 = tx * C0::TW;
     return q;
   };
   auto fill_rows = [&](const Tile& q, int par) __attribute__((always_inline)) {
@@ -1359,6 +1373,7 @@ struct C9Params {
   const float* bprob;  // [1]
   float* out;          // [n, D, H, W]
   int n, D, H, W, ntz, nty, ntx;
+  int zy_order;        // tile_order(): 1 = x, z, y
 };
 
 // 8 waves per workgroup, <= 128 VGPRs: two workgroups = 16 waves per CU (round 1's 4-wave version needed 218 VGPRs, i.e.
@@ -1384,9 +1399,9 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   const int kq = lane >> 4, jn = lane & 15;
   int b = v3d::xcd_contiguous_block();
   const int tx = b % p.ntx; b /= p.ntx;
-  const int ty = b % p.nty; b /= p.nty;
-  const int tz = b % p.ntz;
-  const int n = b / p.ntz;
+  int ty, tz, n;
+  if (p.zy_order) { tz = b % p.ntz; b /= p.ntz; ty = b % p.nty; n = b / p.nty; }
+  else { ty = b % p.nty; b /= p.nty; tz = b % p.ntz; n = b / p.ntz; }
   const int oz0 = tz * C9::TD, oy0 = ty * C9::TH, ox0 = tx * C9::TW;
   const int D2 = p.D >> 1, H2 = p.H >> 1, W2 = p.W >> 1;
   const int iz0 = (oz0 >> 1) - 1, iy0 = (oy0 >> 1) - 1, ix0 = (ox0 >> 1) - 1;
@@ -1678,6 +1693,7 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
   else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
   p.ntz = (p.Do + C::TD - 1) / C::TD; p.nty = (p.Ho + C::TH - 1) / C::TH; p.ntx = (p.Wo + C::TW - 1) / C::TW;
   p.relu = 1;
+  p.zy_order = 0;
   const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv3d: bad grid");
   V3D_REQUIRE((long long)C::CK * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE,
@@ -1704,6 +1720,7 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
   p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
   p.ntz = (Di + C0::TD - 1) / C0::TD; p.nty = (Hi + C0::TH - 1) / C0::TH; p.ntx = (Wi + C0::TW - 1) / C0::TW;
   p.relu = 1;
+  p.zy_order = tile_order(p.ntx, p.nty);
   const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: bad grid");
   V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
@@ -2173,6 +2190,7 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
     q.n = n; q.D = D; q.H = H; q.W = W;
     q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
+    q.zy_order = tile_order(q.ntx, q.nty);
     const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
     V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
     {
