@@ -179,3 +179,31 @@ def test_hip_driver_matches_oracle_driver(cuda):
     out = drv.process_scene(make_scene(), net, 1, cuda, CFG, OFFSETS, 2, 3)
     ref = run_oracle()
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=0)
+
+
+@pytest.mark.gpu
+def test_bench_line_schema_and_checks(cuda):
+    """`bench.py` end to end on a small batch (8 views, 2 steps): ONE JSON line with the contract's fields, both operand
+    precisions, a roofline object for the dominant kernel, the CPU baseline object with the parity check of the timed batch
+    against the pinned oracle, and per-kernel times that cover the step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--refs', '8',
+                        '--cpu-refs', '1', '--check-refs', '2'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_fp32_exact'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0 and d['value_fp32_exact'] > 0
+    assert 'split-bf16' in d['dtype'] and 'workload' in d['config']
+    rf = d['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1
+    assert cb['max_rel_depth_err_gpu_vs_cpu'] < 1e-4 and cb['max_rel_depth_err_gpu_fp32_exact_vs_cpu'] < 2e-5
+    assert abs(sum(v['avg_ms'] for v in d['kernels'].values()) / d['ms_per_step'] - 1) < 0.5
