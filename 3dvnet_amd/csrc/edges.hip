@@ -90,8 +90,12 @@ __global__ __launch_bounds__(kThreads) void edges_csr_kernel(const long long* __
   int err = s_err | (n_ref != n_ref_expected ? 1 : 0);
   if (tid == 0) { meta->magic = kMagic; meta->error = err; meta->n_ref = n_ref; }
   __syncthreads();
-  if (err) {        // nothing downstream may trust the tables: an empty CSR keeps the consumers inside their buffers
+  if (err) {
+    // Nothing downstream may trust the tables.  The consumers read ref_img[r] and that image's camera block for every
+    // r < n_ref_expected even when a reference has no edges, so BOTH tables are made safe: no edges anywhere, and every
+    // reference slot names image 0 (rows at or above the number of references actually found were never written).
     for (int r = tid; r <= n_ref_expected; r += kThreads) edge_ofs[r] = 0;
+    for (int r = tid; r < n_ref_expected; r += kThreads) ref_img[r] = 0;
     return;
   }
   if (small) {

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void transpose_channel_last_kernel(const float
   }
 }
 
-// [n_img, C, Hf, Wf] -> [n_img, Hf + 2, Wf + 2, C] with a border of zero cells (+ one zero row behind the last image).
+// zero cells behind the last bordered image (see transpose_bordered_kernel)
+__host__ __device__ constexpr int kTailCells(int Wf) { return 2 * (Wf + 2) + 16; }
+
+// [n_img, C, Hf, Wf] -> [n_img, Hf + 2, Wf + 2, C] with a border of zero cells (+ a tail of zero cells behind the last image).
 // grid_sample's padding_mode='zeros' then needs no per-tap validity test in the warp kernels: a tap outside the image reads
 // a zero cell, and a sample further out is clamped onto the border, where both of its in-range taps are zero cells and the
 // other two carry weight 0 (make_taps).  One workgroup = 64 consecutive cells of one padded image.
@@ -90,11 +93,11 @@ __global__ __launch_bounds__(256) void transpose_bordered_kernel(const float* __
     if (q0 + px < n_cell) dst[(size_t)(q0 + px) * C + c] = tile[c][px];
   }
   // A sample clamped onto the lower border reads its weight-0 taps one padded row further down: the next image's top border,
-  // or, behind the last image, this extra row of zero cells (+ one cell for the tap right of its last cell).  Weight 0 times
-  // recycled memory holding a NaN pattern would be NaN.
+  // or, behind the last image, this tail of zero cells.  Weight 0 times recycled memory holding a NaN pattern would be NaN.
+  // The window kernel copies whole 8-cell runs of up to one row below a footprint: the tail is two bordered rows + 16 cells.
   if (img == n_img - 1 && blockIdx.x == 0) {
     float* tail = out + (size_t)n_img * n_cell * C;
-    for (int i = threadIdx.x; i < (Wp + 1) * C; i += 256) tail[i] = 0.f;
+    for (int i = threadIdx.x; i < kTailCells(Wf) * C; i += 256) tail[i] = 0.f;
   }
 }
 
@@ -634,6 +637,305 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   PHASE_FLUSH;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Window variant of the plane-reuse kernel (C == 32, 8 planes per wave), the default since round 3.
+//
+// Round-3 measurements behind it (scripts/micro/ta_mask.hip): a 16-byte-per-lane gather costs the CU's
+// vector-memory path 7.2 ns per WAVE INSTRUCTION -- whatever the exec mask (8 or 64 active lanes) and whether a lane moves 8 or
+// 16 bytes -- and the reuse kernel issues 1.8 of them per (plane, edge) step: 0.98 ms of its 1.65 ms per 64 cfg2 views are
+// that path's busy time, queued behind each other (the ~1 300-cycle reload latency a wave sees).  Its reloads are mostly
+// waste: a wave's 8 pixels x 8 planes x 1 edge touch 16 DISTINCT cells on average (the 2x2 footprints of neighbouring
+// pixels and of consecutive planes overlap), the kernel loads 115 (forced reload of every pixel on the first plane, all four
+// cells again when a footprint moves by one cell, masked lanes at full price).
+//
+// Here the wave takes the box spanned by the four corner samples of its 64 footprints per edge, cut to 16 x 4 cells (the whole
+// box in 95 % of the passes at cfg2, 97 % at cfg5), and copies it into LDS with global_load_lds_dwordx4 -- one instruction
+// per 8 cells of a row, no staging registers, 0.53 instructions per step instead of 1.8 -- and the footprints are read from
+// there (ds_read_b128, a quarter of the L1 path's price per KB, tens instead of hundreds of cycles of latency).  Whether any
+// pixel changes its footprint on plane k is known after the projection (one ballot): the reload branch is scalar and all
+// lanes reload together.  A sample whose footprint lies outside the window (near planes with long epipolar slides, exotic
+// camera pairs, the few tiles whose corners are not extreme) carries a flag in its tap word and reads its four cells from
+// featT as the reuse kernel does, inside the same step.  Arithmetic and accumulation order are those of the other two
+// kernels: bit-identical output.
+constexpr int kWinCols = 16, kWinRows = 4;                 // window: 16 x 4 cells x 128 B = 8 KB per wave
+
+#ifndef V3D_PSVW_ABLATE
+#define V3D_PSVW_ABLATE 0    // developer ablations of the window kernel: 1 no blend, 2 no footprint reads, 3 no window copy, 5 no store, 6 no out-of-window path
+#endif
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_window_kernel(PsvParams p) {
+  constexpr int C = 32, WPB = SPLIT ? 1 : 4;
+  constexpr unsigned CB = 4 * C;                            // bytes per cell
+  constexpr int kOutPl = 4;                                 // planes staged per round of the fp32 epilogue
+  static_assert(kRDB == 8 && kRE == 1, "the window kernel projects one edge per pass: 8 planes x 8 pixels = 64 lanes");
+  __shared__ __attribute__((aligned(16))) float s_win_[WPB][kWinRows * kWinCols * C];
+  __shared__ __attribute__((aligned(16))) f32x4 s_w_[WPB][kRDB * kRPix];      // nw, ne, sw, se weights per (plane, pixel)
+  __shared__ unsigned s_slot_[WPB][kRDB * kRPix];           // byte offset of the nw cell: in the window / in featT
+  __shared__ float s_ref_[WPB][24];
+  __shared__ float s_P_[WPB][kMaxE][12];
+  __shared__ int s_base_[WPB][kMaxE];
+  // fp32 epilogue: [kOutPl][C][WPB * kRPix + 1] floats = 16.5 KB, parked on the four (by then dead) windows
+  static_assert(SPLIT || kOutPl * C * (WPB * kRPix + 1) <= WPB * kWinRows * kWinCols * C, "epilogue staging fits the windows");
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const s_win = s_win_[wv];
+  f32x4* const s_w = s_w_[wv];
+  unsigned* const s_slot = s_slot_[wv];
+  float* const s_ref = s_ref_[wv];
+  float (*const s_P)[12] = s_P_[wv];
+  int* const s_base = s_base_[wv];
+  const int n_dchunk = (p.D + kRDB - 1) / kRDB;
+  int b = v3d::xcd_contiguous_block();
+  const int dchunk = b % n_dchunk; b /= n_dchunk;            // plane chunks fastest (see the reuse kernel)
+  const int ptile = (b % p.n_ptile) * WPB + wv;
+  const int r = b / p.n_ptile;
+  const int P = p.h * p.w;
+  const int e_begin = p.edge_ofs[r], e_end = p.edge_ofs[r + 1];
+  const int ne = e_end - e_begin;
+  const int ref = p.ref_img[r];
+  if (lane < 21) s_ref[lane] = p.camp[ref * kCamStride + lane];
+  psv_wave_sync<WPB>();
+
+  // projection role: lane = (plane, pixel)
+  const int pl1 = lane >> 3, px1 = lane & 7;
+  const int gp1 = ptile * kRPix + px1;
+  const int d1 = dchunk * kRDB + pl1;
+  float X, Y, Z;
+  {
+    const int gy = gp1 / p.w, gx = gp1 % p.w;
+    const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
+    const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
+    const float z = (d1 == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d1 * p.z_step);
+    v3d::world_point(s_ref, xf, yf, z, X, Y, Z);
+  }
+  const bool live1 = gp1 < P && d1 < p.D;                   // lane 0 is always live
+  const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
+  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
+  const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
+  const int Wp = p.Wf + 2;
+  const float Wff = (float)p.Wf, Hff = (float)p.Hf;
+
+  // gather role: 8 lanes x float4 per pixel
+  const int gpx = lane >> 3;
+  const unsigned cgb = (lane & 7) * 16;
+  const unsigned rowb = (unsigned)Wp * CB + cgb;
+  const char* const fb = reinterpret_cast<const char*>(p.featT);
+  const char* const wb = reinterpret_cast<const char*>(s_win);
+  f32x4 acc_s[kRDB], acc_q[kRDB];
+#pragma unroll
+  for (int k = 0; k < kRDB; ++k) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#if V3D_PSVW_ABLATE == 1
+#define V3D_PSV_BLEND(pl_, w_) asm volatile("" : : "v"(t00), "v"(t01), "v"(t10), "v"(t11), "v"(w_) : "memory")
+#else
+#define V3D_PSV_BLEND(pl_, w_)                                                                       \
+  do {                                                                                               \
+    f32x4 sv_ = t00 * (w_)[0];                                                                       \
+    sv_ = __builtin_elementwise_fma(t01, (f32x4){(w_)[1], (w_)[1], (w_)[1], (w_)[1]}, sv_);          \
+    sv_ = __builtin_elementwise_fma(t10, (f32x4){(w_)[2], (w_)[2], (w_)[2], (w_)[2]}, sv_);          \
+    sv_ = __builtin_elementwise_fma(t11, (f32x4){(w_)[3], (w_)[3], (w_)[3], (w_)[3]}, sv_);          \
+    acc_s[pl_] += sv_;                                                                               \
+    acc_q[pl_] = __builtin_elementwise_fma(sv_, sv_, acc_q[pl_]);                                    \
+    /* finish this plane before the next one starts (see the reuse kernel) */                        \
+    asm volatile("" : "+v"(acc_s[pl_]), "+v"(acc_q[pl_]) : : "memory");                              \
+  } while (0)
+#endif
+
+  // camera blocks (P = K [R|t], first cell of the bordered map) of edges e0 .. e0 + 7
+  auto load_cams = [&](int e0) __attribute__((always_inline)) {
+    const int nload = min(kMaxE, ne - e0) * 12;
+#pragma unroll 1
+    for (int i = lane; i < nload; i += 64) {
+      const int src = p.edge_src[e_begin + e0 + i / 12];
+      s_P[i / 12][i % 12] = p.camp[src * kCamStride + 24 + i % 12];
+      if (i % 12 == 0) s_base[i / 12] = src * (p.Hf + 2) * Wp;      // cell (-1, -1) of the bordered map
+    }
+  };
+  // projection of this lane's (pixel, plane) sample into the source view of edge e (make_taps, spelled out: the cell
+  // coordinates are needed): nw cell of the footprint in the bordered map (x0 + 1, y0 + 1) + the four bilinear weights
+  auto project = [&](int e, int& xb, int& yb, f32x4& wq) __attribute__((always_inline)) {
+    float ix, iy;
+    v3d::sample_position(s_P[e % kMaxE], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
+    // clamp to [-1, Wf] x [-1, Hf] (make_taps): v_med3_f32 returns the smallest number when an operand is NaN, i.e. -1,
+    // what fminf(fmaxf(NaN, -1), Wf) gives
+    ix = __builtin_amdgcn_fmed3f(ix, -1.f, Wff);
+    iy = __builtin_amdgcn_fmed3f(iy, -1.f, Hff);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+    const float wx0 = x1 - ix, wx1 = ix - x0, wy0 = y1 - iy, wy1 = iy - y0;
+    wq = (f32x4){v3d::mul_rn(wx0, wy0), v3d::mul_rn(wx1, wy0), v3d::mul_rn(wx0, wy1), v3d::mul_rn(wx1, wy1)};
+    xb = (int)x0 + 1;
+    yb = (int)y0 + 1;
+    if (!live1) {                          // lanes beyond the plane grid / the last plane must not stretch the box
+      xb = __builtin_amdgcn_readfirstlane(xb);
+      yb = __builtin_amdgcn_readfirstlane(yb);
+    }
+  };
+  // Software pipeline over the edges: the samples of edge e + 1 are projected while the window of edge e is on its way
+  // from L2 to LDS (the copy's latency was 0.27 of 1.59 ms when the wave simply waited for it)
+  int xb = 0, yb = 0;
+  f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+  if (ne > 0) {
+    load_cams(0);
+    psv_wave_sync<WPB>();
+    project(0, xb, yb, wq);
+  }
+  for (int e = 0; e < ne; ++e) {
+    psv_wave_sync<WPB>();                  // the previous pass is done with s_w / s_slot / s_win
+#ifdef V3D_PSV_NOPIPE                      // developer A/B: project at the top of the pass, wait for the copy right after issuing it
+    if (e > 0) {
+      if (e % kMaxE == 0) { load_cams(e); psv_wave_sync<WPB>(); }
+      project(e, xb, yb, wq);
+    }
+#endif
+    // Window = the box spanned by the four corner samples (first / last pixel on the first / last plane: a projective map is
+    // monotone in pixel and in depth, so they bound the 64 footprints in all but a few tiles), cut to 16 x 4 cells.  A
+    // sample whose footprint is not inside it is simply marked (bit 0 of its tap word) and takes its cells from featT.
+    int xmin, ymin, ncol, nrow;            // wave-uniform
+    {
+      // (both coordinates of a corner travel in one word: four lane reads instead of eight; bordered coordinates are >= 0)
+      const int cc = (yb << 16) | xb;
+      const int ca = __builtin_amdgcn_readlane(cc, 0), cb = __builtin_amdgcn_readlane(cc, 7);
+      const int cd = __builtin_amdgcn_readlane(cc, 56), ce = __builtin_amdgcn_readlane(cc, 63);
+      const int xa = ca & 0xffff, xc = cb & 0xffff, xd = cd & 0xffff, xe = ce & 0xffff;
+      const int ya = ca >> 16, yc = cb >> 16, yd = cd >> 16, ye = ce >> 16;
+      xmin = min(min(xa, xc), min(xd, xe));
+      ymin = min(min(ya, yc), min(yd, ye));
+      ncol = max(max(xa, xc), max(xd, xe)) - xmin + 2 > 8 ? kWinCols : 8;
+      nrow = min(max(max(ya, yc), max(yd, ye)) - ymin + 2, kWinRows);
+    }
+    const int base_cell = __builtin_amdgcn_readfirstlane(s_base[e % kMaxE]);
+    const unsigned dx = (unsigned)(xb - xmin), dy = (unsigned)(yb - ymin);
+    const bool inwin = dx <= (unsigned)(ncol - 2) && dy <= (unsigned)(nrow - 2);
+    // tap word: byte offset of the nw cell in the window, or in featT with bit 0 set (cells are 128-byte aligned)
+    const unsigned so = inwin ? (dy * kWinCols + dx) * CB : ((unsigned)(base_cell + yb * Wp + xb) * CB | 1u);
+    s_w[lane] = wq;
+    s_slot[lane] = so;
+    // does ANY pixel change its footprint on plane k (bit group k of the ballot)?  plane 0 always loads
+    const unsigned prev = (unsigned)__builtin_amdgcn_ds_bpermute(((lane - 8) & 63) * 4, (int)so);
+    const unsigned long long chg = __ballot(lane < 8 || so != prev);
+    // copy the window: nrow rows of 8 or 16 cells from (xmin, ymin) (runs past the last needed column stay inside the bordered
+    // maps + tail); lane l moves bytes [16 l, 16 l + 16) of each 1 KB run
+    {
+      const char* src = fb + ((size_t)(unsigned)(base_cell + ymin * Wp + xmin) * CB + (unsigned)lane * 16u);
+      for (int rr = 0; rr < (V3D_PSVW_ABLATE == 3 ? 0 : nrow); ++rr) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)rr * Wp * CB),
+                                         (__attribute__((address_space(3))) void*)(s_win + rr * kWinCols * C), 16, 0, 0);
+        if (ncol > 8)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)rr * Wp * CB + 8 * CB),
+                                           (__attribute__((address_space(3))) void*)(s_win + rr * kWinCols * C + 8 * C), 16, 0, 0);
+      }
+    }
+#ifndef V3D_PSV_NOPIPE
+    if (e + 1 < ne) {
+      if ((e + 1) % kMaxE == 0) {
+        psv_wave_sync<WPB>();
+        load_cams(e + 1);
+        psv_wave_sync<WPB>();
+      }
+      project(e + 1, xb, yb, wq);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the window has landed, the tap records are written
+    psv_wave_sync<WPB>();
+    // deliberately not initialised: the first plane of a pass always loads them
+    f32x4 t00, t01, t10, t11;
+    f32x4 wn = s_w[gpx];
+    unsigned sn = s_slot[gpx];
+#pragma unroll
+    for (int pl = 0; pl < kRDB; ++pl) {
+      const f32x4 w = wn;
+      const unsigned so_pl = sn;
+      if (pl + 1 < kRDB) {               // next plane's record: in flight during this plane's blend
+        wn = s_w[(pl + 1) * kRPix + gpx];
+        sn = s_slot[(pl + 1) * kRPix + gpx];
+      }
+      if (((chg >> (8 * pl)) & 0xffull) && (V3D_PSVW_ABLATE != 2 || (pl == 0 && e == 0))) {      // wave-uniform: all pixels reload together (a load costs the same masked or not)
+        if (V3D_PSVW_ABLATE != 6 && (so_pl & 1u)) {
+          const unsigned b00 = so_pl - 1u;
+          t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + cgb));
+          t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + cgb) + CB);
+          t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + rowb));
+          t11 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + rowb) + CB);
+        } else {
+          const char* a = wb + (so_pl + cgb);
+          t00 = *reinterpret_cast<const f32x4*>(a);
+          t01 = *reinterpret_cast<const f32x4*>(a + CB);
+          t10 = *reinterpret_cast<const f32x4*>(a + kWinCols * CB);
+          t11 = *reinterpret_cast<const f32x4*>(a + kWinCols * CB + CB);
+        }
+      }
+      V3D_PSV_BLEND(pl, w);
+    }
+  }
+#undef V3D_PSV_BLEND
+
+  // ---- variance -> stores (as in the reuse kernel) -------------------------------------------------------------
+  psv_wave_sync<WPB>();
+  const float cnt = (float)max(ne, 1);        // torch_scatter mean: sum / clamp(count, 1)
+  const bool cnt_pow2 = (max(ne, 1) & (max(ne, 1) - 1)) == 0;
+  const float cnt_inv = 1.f / cnt;
+  const int cg = lane & 7;
+  if constexpr (SPLIT) {
+    const int chunk = cg >> 1, half = cg & 1;
+    u32x4* const out = reinterpret_cast<u32x4*>(p.var);
+    const int gp = ptile * kRPix + gpx;
+    // x / cnt is an IEEE division; for a power-of-two count x * (1 / cnt) is the same number exactly.  ONE wave-uniform
+    // branch around the whole epilogue (the reuse kernel tests it per value: 64 branches)
+#define V3D_PSV_EMIT(MEAN)                                                                                              \
+  _Pragma("unroll") for (int pl = 0; pl < kRDB; ++pl) {                                                                 \
+    float v[4];                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                     \
+      const float avg = MEAN(acc_s[pl][k]);                                                                             \
+      const float avg_sq = MEAN(acc_q[pl][k]);                                                                          \
+      v[k] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));                    /* mvsnet.py:216 */                         \
+    }                                                                                                                   \
+    const unsigned h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);                                        \
+    const unsigned l01 = pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));     \
+    const unsigned l23 = pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));     \
+    const unsigned s0 = half ? h01 : l01, s1 = half ? h23 : l23;             /* what the partner lane stores */          \
+    const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, true);   /* quad_perm [1,0,3,2] */   \
+    const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, true);                              \
+    const u32x4 slot = half ? (u32x4){r0, r1, l01, l23} : (u32x4){h01, h23, r0, r1};                                    \
+    const int d = dchunk * kRDB + pl;                                                                                   \
+    if (gp < P && d < p.D && (V3D_PSVW_ABLATE != 5 || slot[0] == 0x12345u))                                             \
+      __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);                 \
+  }
+#define V3D_MEAN_MUL(x) ((x) * cnt_inv)
+#define V3D_MEAN_DIV(x) ((x) / cnt)
+    if (cnt_pow2) { V3D_PSV_EMIT(V3D_MEAN_MUL) } else { V3D_PSV_EMIT(V3D_MEAN_DIV) }
+#undef V3D_PSV_EMIT
+#undef V3D_MEAN_MUL
+#undef V3D_MEAN_DIV
+  } else {
+    constexpr int NPX = WPB * kRPix;
+    float (*const s_out)[C][NPX + 1] = reinterpret_cast<float (*)[C][NPX + 1]>(&s_win_[0][0]);
+    auto mean = [&](float x) __attribute__((always_inline)) { return cnt_pow2 ? x * cnt_inv : x / cnt; };
+    const int gp0 = (ptile - wv) * kRPix;             // first pixel of the workgroup
+#pragma unroll
+    for (int round = 0; round < kRDB / kOutPl; ++round) {
+      __syncthreads();                                 // every wave is done with its window / the previous round is stored
+#pragma unroll
+      for (int q = 0; q < kOutPl; ++q) {
+        const int pl = round * kOutPl + q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float avg = mean(acc_s[pl][k]);
+          const float avg_sq = mean(acc_q[pl][k]);
+          s_out[q][cg * 4 + k][wv * kRPix + gpx] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));   // mvsnet.py:216
+        }
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < kOutPl * C * NPX; i += 64 * WPB) {
+        const int q = i / (C * NPX), c = (i / NPX) % C, px = i % NPX;
+        const int gp = gp0 + px, d = dchunk * kRDB + round * kOutPl + q;
+        if (gp < P && d < p.D) __builtin_nontemporal_store(s_out[q][c][px], &p.var[(((size_t)r * C + c) * p.D + d) * P + gp]);
+      }
+    }
+  }
+}
+
 // Diagnostic twin of the warp kernels' projection (v3d_psv_sample_positions_f32): one thread per (edge, plane, pixel)
 // runs the SAME device functions (v3d::world_point / v3d::sample_position) and stores the un-normalised sample position,
 // so a test can compare the coordinates the kernels use with the reference's, bit for bit.
@@ -677,9 +979,9 @@ int v3d::transpose_channel_last(const float* feat, float* featT, int n_img, int 
   return 0;
 }
 
-// bordered channel-last feature maps: n_img x (Hf + 2) x (Wf + 2) cells + a zero row of Wf + 3 cells behind them
+// bordered channel-last feature maps: n_img x (Hf + 2) x (Wf + 2) cells + the tail of zero cells behind them
 static size_t psv_feat_bytes(int n_img, int C, int Hf, int Wf) {
-  return ((size_t)n_img * (Hf + 2) * (Wf + 2) + (Wf + 3)) * C * sizeof(float);
+  return ((size_t)n_img * (Hf + 2) * (Wf + 2) + kTailCells(Wf)) * C * sizeof(float);
 }
 
 extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
@@ -706,6 +1008,7 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && Hf > 0 && Wf > 0 && H > 1 && W > 1 &&
                   D > 0 && h > 0 && w > 0,
               V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: bad shape");
+  V3D_REQUIRE(Hf < 32760 && Wf < 32760, V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: feature maps larger than 32759 cells per axis");
   V3D_REQUIRE(psv_feat_bytes(n_img, C, Hf, Wf) < (size_t)1 << 32, V3D_ERR_BAD_SHAPE,
               "v3d_psv_variance_f32: bordered feature maps exceed 4 GB (32-bit byte offsets)");
   V3D_REQUIRE(workspace_bytes >= v3d_psv_workspace_bytes(n_img, C, Hf, Wf),
@@ -756,11 +1059,15 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
       const long long rblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * ((h * w + kRPix - 1) / kRPix);
       V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
       p.n_ptile = (h * w + kRPix - 1) / kRPix;
-      if (split) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
-      else {      // four 8-pixel tiles per workgroup
+      static const bool no_window = getenv("V3D_PSV_REUSE") != nullptr || kRDB != 8;   // developer A/B switch: round-2 kernel
+      if (split) {
+        if (no_window) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
+        else psv_variance_window_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
+      } else {      // four 8-pixel tiles per workgroup
         p.n_ptile = (p.n_ptile + 3) / 4;
         const long long fblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * p.n_ptile;
-        psv_variance_reuse_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
+        if (no_window) psv_variance_reuse_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
+        else psv_variance_window_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
       }
     } else if (split) V3D_PSV(32, true);
     else if (C == 32) V3D_PSV(32, false);

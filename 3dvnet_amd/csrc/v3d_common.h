@@ -174,10 +174,13 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
   const float zb = add_rn(fabsf(qz), 1e-8f);
   float u, v;
   div2_shared(qx, qy, zb, u, v);
-  const float gx = sub_rn(mul_rn(div_uniform(u, Wm1, rWm1), 2.f), 1.f);
-  const float gy = sub_rn(mul_rn(div_uniform(v, Hm1, rHm1), 2.f), 1.f);
-  ix = mul_rn(mul_rn(add_rn(gx, 1.f), 0.5f), Wfm1);
-  iy = mul_rn(mul_rn(add_rn(gy, 1.f), 0.5f), Hfm1);
+  // g = 2 q - 1: doubling is exact, so fma(q, 2, -1) rounds once, exactly where the reference's (q * 2) - 1 does;
+  // ((g + 1) * 0.5) * (Wf - 1): halving is exact as well, so it is folded into the (exactly halved) feature extent --
+  // the same single rounding of the same real product (3 instructions per coordinate instead of 5; same bits)
+  const float gx = __builtin_fmaf(div_uniform(u, Wm1, rWm1), 2.f, -1.f);
+  const float gy = __builtin_fmaf(div_uniform(v, Hm1, rHm1), 2.f, -1.f);
+  ix = mul_rn(add_rn(gx, 1.f), mul_rn(0.5f, Wfm1));
+  iy = mul_rn(add_rn(gy, 1.f), mul_rn(0.5f, Hfm1));
 }
 
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip

@@ -73,13 +73,20 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                   group=None, gather_depth=True, upsample=False, init_depth_override=None):
     """Returns the refined depth maps [n_ref, h, w] (all views when gather_depth, else this rank's).
 
+    ``n_src_on_either_side``: the reference's k (eval/main.py:36; window ref-k .. ref+k, 2k+1 edges per reference view), or
+    a pair ``(n_before, n_after)`` for the one-sided windows of SURVEY.md 8d (cfg2-4: ref-4 .. ref+3 = 1 ref + 7 src); the
+    image halo of a chunk of reference views is n_before images in front of it and n_after behind it.
     ``batch``: images (or precomputed ``features_quarter`` [+ ``features_half`` for ``upsample``]), rotmats, tvecs, K,
     ref_src_edges for the whole scene with the reference's edge convention (dsets/dataset.py:133-137).
     ``init_depth_override`` (benchmark hook, [n_ref, h, w]): stage 1 still runs, then its depths are replaced by
     these (bench.py uses surface-like depths because random synthetic features give noise depths)."""
     depth_config = depth_config or DEPTH_CONFIG
     offsets_list = offsets_list or OFFSETS_LIST
-    k = n_src_on_either_side
+    if isinstance(n_src_on_either_side, (tuple, list)):
+        k, ka = int(n_src_on_either_side[0]), int(n_src_on_either_side[1])
+    else:
+        k = ka = int(n_src_on_either_side)
+    halo = k + ka          # images a chunk of reference views needs beyond its own (2k in the reference)
     with torch.no_grad():
         ref_idx = torch.unique(batch.ref_src_edges[0])
         n_ref_imgs = len(ref_idx)
@@ -87,14 +94,14 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         n_local = r1 - r0
         has_feats = getattr(batch, 'features_quarter', None) is not None
         all_depth = torch.empty((n_local, *depth_config['size']), dtype=torch.float32, device=device)
-        feats_local = None          # quarter features of images [r0, r1 + 2k)
+        feats_local = None          # quarter features of images [r0, r1 + halo)
         half_local = None           # half-resolution features of the same images (stage 3 only, eval-3dvnet.py:36,62)
 
         # ---- stage 1: initial depth, chunks of init_depth_batch reference views (:41-63) ----------
         for c0 in range(r0, r1, init_depth_batch):
             c1 = min(c0 + init_depth_batch, r1)
             ref_idx_start, ref_idx_end = c0 + k, c1 + k
-            idx_start, idx_end = c0, c1 + 2 * k
+            idx_start, idx_end = c0, c1 + halo
             edges = utils.slice_edges(batch.ref_src_edges, ref_idx_start, ref_idx_end, 0) - idx_start
             sl = Batch(None if batch.images is None else batch.images[idx_start:idx_end],
                        batch.rotmats[idx_start:idx_end], batch.tvecs[idx_start:idx_end],
@@ -108,7 +115,7 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             pred, _, feats_half, feats_quarter, _, _ = net.make_initial_depth_predictions(sl, depth_config)
             all_depth[c0 - r0:c1 - r0] = pred
             if feats_local is None:
-                feats_local = torch.empty((n_local + 2 * k,) + tuple(feats_quarter.shape[1:]),
+                feats_local = torch.empty((n_local + halo,) + tuple(feats_quarter.shape[1:]),
                                           dtype=torch.float32, device=device)
             feats_local[idx_start - r0:idx_end - r0] = feats_quarter
             if upsample:
@@ -118,16 +125,16 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                     raise ValueError('process_scene(upsample=True) needs half-resolution features: a backbone on '
                                      'net.mvsnet or batch.features_half')
                 if half_local is None:
-                    half_local = torch.empty((n_local + 2 * k,) + tuple(feats_half.shape[1:]),
+                    half_local = torch.empty((n_local + halo,) + tuple(feats_half.shape[1:]),
                                              dtype=torch.float32, device=device)
                 half_local[idx_start - r0:idx_end - r0] = feats_half
         if init_depth_override is not None:
             all_depth = init_depth_override[r0:r1].to(device=device, dtype=torch.float32).clone()
 
         # ---- stage 2: volumetric refinement (:65-99) ------------------------------------------------
-        rot = batch.rotmats[r0:r1 + 2 * k].to(device)
-        tv = batch.tvecs[r0:r1 + 2 * k].to(device)
-        K = batch.K[r0:r1 + 2 * k].to(device)
+        rot = batch.rotmats[r0:r1 + halo].to(device)
+        tv = batch.tvecs[r0:r1 + halo].to(device)
+        K = batch.K[r0:r1 + halo].to(device)
         edges_local = (utils.slice_edges(batch.ref_src_edges, r0 + k, r1 + k, 0) - r0).to(device)
         depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
         n_pix = depth_config['size'][0] * depth_config['size'][1]
@@ -147,8 +154,8 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                 for b0, b1, e, csr in chunks:
                     kw = {} if csr is None else {'csr': csr}
                     all_depth[b0:b1] += net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
-                                                          feats_local[b0:b1 + 2 * k], rot[b0:b1 + 2 * k],
-                                                          tv[b0:b1 + 2 * k], K[b0:b1 + 2 * k], e, offset, 3,
+                                                          feats_local[b0:b1 + halo], rot[b0:b1 + halo],
+                                                          tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3,
                                                           **kw)
         if upsample:
             # ---- stage 3 (:101-125): plane grid -> 1/4 -> 1/2 -> full resolution, guided by the quarter /

@@ -47,10 +47,13 @@ def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges
 class PL3DVNet(nn.Module):
     """Reference ``PL3DVNet`` (lightningmodel.py:14-43), inference surface only."""
 
-    def __init__(self, depth_train, depth_test, edge_len, feat_dim=16, img_size=(256, 320), hyp_ksize=3,
+    def __init__(self, depth_train, depth_test, edge_len, feat_dim=32, img_size=(256, 320), hyp_ksize=3,
                  hyp_pad=1, lr=1e-3, lr_step=100, lr_gamma=0.1, finetune=False, feat_extractor=None,
                  feat_shrinker=None, precision='split_bf16', backbone=False):
-        """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20).  Extra keywords:
+        """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20), except the DEFAULT of ``feat_dim``: the
+        reference's signature says 16, but its config (mv3d/config.py:42) and the hparams of every released checkpoint say
+        32, the only width the HIP kernels are specialised for -- so ``PL3DVNet(depth_train, depth_test, edge_len)`` builds
+        the network the reference actually ships, and an explicit ``feat_dim=16`` raises.  Extra keywords:
         ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
         ('split_bf16' | 'fp32') selects the MFMA operand precision of every matrix-core kernel (include/v3d.h)."""

@@ -362,6 +362,7 @@ class MVSNet(nn.Module):
         self.cnn_3d = CostRegNet(feat_dim, 8, precision=precision)
         self._ws = _Workspace()
         self._depth_vals = {}
+        self.last_csr = None
 
     def depth_values(self, depth_start, depth_interval, n_planes, device):
         """torch.linspace(depth_start, depth_end, n_planes) built on the CPU then moved, exactly
@@ -381,6 +382,11 @@ class MVSNet(nn.Module):
         (identical depth, no conversion pass in conv0)."""
         precision = precision or self.cnn_3d.precision
         split = not return_intermediates and features_quarter.shape[1] == 32 and precision == 'split_bf16'
+        if csr is None:
+            # kept on the module: `check_edges()` reads the device builder's status word (a wrong n_ref gives an EMPTY edge
+            # table, i.e. a zero variance volume and a plausible-looking depth, not an exception)
+            csr = edges_to_csr(batch.ref_src_edges.to(features_quarter.device), n_ref=n_ref, n_img=features_quarter.shape[0])
+        self.last_csr = csr
         var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
                                    batch.ref_src_edges, depth_start, depth_interval, n_planes,
                                    self.img_size, depth_img_size, workspace=self._ws, csr=csr,
@@ -390,6 +396,13 @@ class MVSNet(nn.Module):
             depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True, precision=precision)
             return depth, var, reg
         return self.cnn_3d.regularize_depth(var, vals, precision=precision)
+
+    def check_edges(self):
+        """Raise if the edge tables of the most recent forward were rejected by the device builder (``n_ref`` did not match
+        the edge list, or an image index was out of range).  Synchronises; the torch-built tables cannot fail."""
+        if getattr(self, 'last_csr', None) is not None:
+            self.last_csr.check()
+        return self
 
     def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size, n_ref=None):
         if self.feat_extractor is not None:
@@ -431,9 +444,26 @@ class CostVolumeGraph:
                 net.cost_volume_depth(features_quarter, batch, *self._args, **self._kw)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # the edge list is validated once, eagerly: inside the graph nobody reads the builder's status word
+        edges_to_csr(batch.ref_src_edges, n_ref=int(n_ref), n_img=features_quarter.shape[0]).check()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.depth = net.cost_volume_depth(features_quarter, batch, *self._args, **self._kw)
+        # The captured launches carry raw device addresses.  Everything they point to is pinned here: the module's scratch
+        # buffers (a later, larger eager call REPLACES the entries of the grow-only workspaces -- the tensors held below stay
+        # alive and the graph keeps its own), the cached plane depths, and the identity of the packed weight image, which
+        # `packed_handle()` frees as soon as a parameter of the regulariser changes: replay() refuses to run on a stale one.
+        self._pinned = list(net._ws._bufs.values()) + list(net.cnn_3d._ws._bufs.values()) + list(net._depth_vals.values())
+        self._weights_key = net.cnn_3d._packed_key
+        self._weights_handle = net.cnn_3d._handle.value if net.cnn_3d._handle is not None else None
+
+    def stale(self):
+        """True when the regulariser's packed weight image the graph was captured with is gone: a parameter or buffer of
+        ``net.cnn_3d`` was modified, replaced or moved (or the image was re-packed for another device) since capture."""
+        c = self.net.cnn_3d
+        cur = c._handle.value if c._handle is not None else None
+        return cur != self._weights_handle or c._packed_key != self._weights_key or \
+            c._packed_key != (c._packed_key[0],) + module_state_key(c)
 
     def update(self, features_quarter=None, rotmats=None, tvecs=None, K=None, ref_src_edges=None):
         if features_quarter is not None:
@@ -441,8 +471,12 @@ class CostVolumeGraph:
         for name, val in (('rotmats', rotmats), ('tvecs', tvecs), ('K', K), ('ref_src_edges', ref_src_edges)):
             if val is not None:
                 getattr(self.batch, name).copy_(val)
+        if ref_src_edges is not None:      # a new edge list must still hold exactly n_ref reference images
+            edges_to_csr(self.batch.ref_src_edges, n_ref=self._kw['n_ref'], n_img=self.features_quarter.shape[0]).check()
 
     def replay(self):
+        if self.stale():
+            raise RuntimeError('CostVolumeGraph: the weights of net.cnn_3d changed after capture (the packed weight image '
+                               'the graph points to was released); capture a new graph')
         self.graph.replay()
         return self.depth
-

@@ -199,6 +199,13 @@ class SparseLevel:
                                       _lib.stream_ptr(coords.device)), 'v3d_hash_build')
         self.feats = None
 
+    def check(self):
+        """Raise if ``v3d_hash_build`` dropped rows (a coordinate outside the table's 16-bit key range): such voxels would
+        silently lose their neighbours / interpolation corners.  Reads the table's status word (synchronises)."""
+        _lib.check(_lib.load().v3d_hash_status(self.table.data_ptr(), self.n, _lib.stream_ptr(self.coords.device)),
+                   'v3d_hash_build (stride %d)' % self.stride)
+        return self
+
     def neighbors(self, out_coords, step):
         """[27, n_out] int32 row map: row of out_coords[p] + step * o_k in this level (or -1)."""
         lib = _lib.load()
@@ -321,6 +328,8 @@ class SparseUNet(nn.Module):
 
         out_info = []
         n_batches = int(torch.max(batch).item()) + 1                                   # scenemodeling.py:221
+        for lv in levels:       # the host is synchronised here anyway: surface rows the hash tables refused (range check)
+            lv.check()
         for lv, xf in out:
             x_idx = lv.coords[:, 1:].type_as(batch)
             x_batch = lv.coords[:, 0].type_as(batch)

@@ -18,6 +18,10 @@ Configurations (BASELINE.json `configs`):
         one scene.  cfg4 = cfg3 with the reference views sharded over the ranks and the feature-rich point cloud
         all-gathered over RCCL once per outer iteration (strong scaling of one scene).
 
+The default invocation (cfg2, one GPU) also runs cfg5 (8 views) and the cfg3 scene once each, shorter, and appends their
+figures as compact objects under "extra" (value, ms_per_step, dominant-kernel roofline, depth error against the oracle), so
+that every configuration's number is in the driver-run line; `--no-extra` skips them.
+
 Prints ONE JSON line on rank 0, including
   "value_fp32_exact": the same batch with exact-fp32 MFMA operands (precision='fp32'); `value` uses split-bf16 operands
   "roofline":     achieved vs peak for the dominant kernel (HIP events recorded by the library on the launch stream)
@@ -42,7 +46,7 @@ PEAK_HBM_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # dense fp32 MFMA == fp32 vector peak
 DTYPE = 'f32 storage/accumulate; MFMA operands split-bf16x3 (hi*hi+hi*lo+lo*hi, 16 mantissa bits); warp/variance f32 VALU'
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
 
 # (Cin, Cout, divisor of D*h*w giving the voxel count the 27*Cin*Cout MACs are spent on): output voxels
 # for the convs, INPUT voxels for the stride-2 transposed convs (SURVEY.md §8a row A5 MAC table)
@@ -242,24 +246,27 @@ def bench_costvolume(args, rank, world, dev, dist):
                                         inp['edges'][:, v0 * per:v1 * per], sd, d0, dd, D, inp['img_size'],
                                         inp['plane_size'], pinned=pinned)[0]
         n_s = max(1, min(args.cpu_refs, refs))
+        timing = getattr(args, 'cpu_timing', True)      # the "extra" legs only use the oracle as the checker
         # SURVEY §8d protocol: n = os.cpu_count() threads, 2 warm-ups, median of 5, plus a 1-thread figure.  PyTorch's
         # CPU kernels do not scale to every hardware thread of a big host (256 threads ran 6x SLOWER than one thread
         # on the round-2 box), so a few intermediate counts are probed too (1 view, 1 warm-up, median of 3) and the
         # protocol is repeated at the fastest one: `value` is the best figure (the most favourable to the CPU), `cores`
         # its thread count, `by_threads` lists everything that was measured.
-        by_threads = {}
-        torch.set_num_threads(ncpu)
-        by_threads[ncpu] = n_s / _median_time(lambda: cpu_run(0, n_s), 2, 5)
-        probe = {}
-        for nt in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
-            torch.set_num_threads(nt)
-            probe[nt] = 1.0 / _median_time(lambda: cpu_run(0, 1), 1, 3)
-        best_nt = max(probe, key=probe.get)
-        by_threads[1] = probe[1]
-        if best_nt not in (1, ncpu):
-            torch.set_num_threads(best_nt)
-            by_threads[best_nt] = n_s / _median_time(lambda: cpu_run(0, n_s), 2, 5)
-        cores = max(by_threads, key=by_threads.get)
+        by_threads, probe = {}, {}
+        if timing:
+            torch.set_num_threads(ncpu)
+            by_threads[ncpu] = n_s / _median_time(lambda: cpu_run(0, n_s), 2, 5)
+            for nt in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
+                torch.set_num_threads(nt)
+                probe[nt] = 1.0 / _median_time(lambda: cpu_run(0, 1), 1, 3)
+            best_nt = max(probe, key=probe.get)
+            by_threads[1] = probe[1]
+            if best_nt not in (1, ncpu):
+                torch.set_num_threads(best_nt)
+                by_threads[best_nt] = n_s / _median_time(lambda: cpu_run(0, n_s), 2, 5)
+            cores = max(by_threads, key=by_threads.get)
+        else:
+            best_nt = cores = min(32, ncpu)
         # accuracy of the timed GPU batch against the oracle: every view of the step (or --check-refs of them).  The
         # checker is the oracle with the pinned evaluation orders of the reference run behind the goldens
         # (oracle/pinned.py): torch.bmm's last bits depend on the host BLAS, and one ulp of a sample coordinate is worth
@@ -272,22 +279,26 @@ def bench_costvolume(args, rank, world, dev, dist):
         d_gpu, d_gpu32 = depth[:n_chk].cpu(), depth32[:n_chk].cpu()
         rel = float(((d_gpu - d_cpu).abs() / d_cpu).max())
         rel32 = float(((d_gpu32 - d_cpu).abs() / d_cpu).max())
-        n_host = min(4, n_chk)
-        d_host = cpu_run(0, n_host)
+        # ... and the plain torch oracle of this host (its BLAS's own evaluation order) on the same views: all of them at
+        # cfg2 (a few seconds each at the best thread count), --host-check-refs of them otherwise
+        n_host = n_chk if args.host_check_refs < 0 else min(args.host_check_refs, n_chk)
+        d_host = torch.cat([cpu_run(v, min(v + chunk, n_host)) for v in range(0, n_host, chunk)])
         rel_host = float(((d_gpu[:n_host] - d_host).abs() / d_host).max())
+        rel_host32 = float(((d_gpu32[:n_host] - d_host).abs() / d_host).max())
         abs_rel = float(((d_gpu - d_cpu).abs() / (d_cpu + 1e-7)).mean())   # eval/metricfunctions.py:41 with gt := oracle
-        cpu_baseline = dict(value=by_threads[cores], unit='depth maps/s', cores=cores, kind='port',
+        cpu_baseline = dict(value=by_threads.get(cores), unit='depth maps/s', cores=cores, kind='port',
                             sample='%d reference view(s) of the same %s batch (oracle: torch CPU grid_sample + '
                                    'scatter-mean + Conv3d), 2 warm-ups, median of 5' % (n_s, cfg),
                             by_threads={str(k): round(v, 4) for k, v in sorted(by_threads.items())},
                             probe_1view_by_threads={str(k): round(v, 4) for k, v in sorted(probe.items())},
-                            value_1thread=by_threads[1], value_all_threads=by_threads[ncpu], host_threads=ncpu,
+                            value_1thread=by_threads.get(1), value_all_threads=by_threads.get(ncpu), host_threads=ncpu,
                             cpu_model=cpu_info(),
                             parallel_info=' '.join(torch.__config__.parallel_info().split())[:400],
                             checked_views=n_chk, max_rel_depth_err_gpu_vs_cpu=rel,
                             max_rel_depth_err_gpu_fp32_exact_vs_cpu=rel32, abs_rel_gpu_vs_cpu=abs_rel,
                             checker='oracle with pinned evaluation orders (oracle/pinned.py)',
-                            max_rel_depth_err_gpu_vs_host_blas_oracle=rel_host, host_blas_checked_views=n_host)
+                            max_rel_depth_err_gpu_vs_host_blas_oracle=rel_host,
+                            max_rel_depth_err_gpu_fp32_exact_vs_host_blas_oracle=rel_host32, host_blas_checked_views=n_host)
 
     if rank != 0:
         return None
@@ -324,26 +335,37 @@ def bench_scene(args, rank, world, dev, dist):
     Batch = importlib.import_module('3dvnet_amd.batch').Batch
     refs = args.refs or 64
     cfg = syn.CONFIGS['cfg3']
-    k = 2                                                   # eval: 2 src on either side (eval/main.py:36)
-    edges, n_img = syn.make_edges(refs, k, k)
-    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=1237, yaw_step_deg=360.0 / n_img)
-    b = Batch(None, rot, tv, K, None, edges)
-    b.features_quarter = syn.make_features(n_img, 32, *cfg['feat_size'], seed=1237)
+    # cfg3/4 use 1 ref + 7 src = 8 edges per reference view (ref-4 .. ref+3), as cfg2 does.  (The reference's own
+    # eval script runs its driver with 2 src on either side = 5 edges, eval/main.py:36: `--scene-window 2,2`.)
+    nb, na = (int(v) for v in args.scene_window.split(','))
+    win = (nb, na)
+
+    def make(n_ref, seed):
+        edges, n_img = syn.make_edges(n_ref, nb, na)
+        rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=seed, yaw_step_deg=360.0 / max(n_img, 60))
+        bb = Batch(None, rot, tv, K, None, edges)
+        bb.features_quarter = syn.make_features(n_img, 32, *cfg['feat_size'], seed=seed)
+        # Random synthetic features give noise depths => a volume-filling point cloud.  Stage 1 runs and is timed, but
+        # its output is then replaced by surface-like depths (analytic wall depth of the box room + 2 cm seeded noise,
+        # SURVEY §8d) so that the scene model and the point-flow sweeps see a ScanNet-like voxel count.
+        gt = syn.ray_box_depth(rot[nb:nb + n_ref], tv[nb:nb + n_ref], K[nb:nb + n_ref], cfg['img_size'],
+                               drv.DEPTH_CONFIG['size'])
+        gt = gt + 0.02 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(7))
+        return bb, gt
+    b, gt = make(refs, 1237)
+    gt = gt.to(dev)
+    sds = dict(cr=syn.costregnet_weights(seed=0, sharpen=200.0), pn=syn.pointnet_weights(), un=syn.sparse_unet_weights(),
+               dec=syn.decoder_weights(sharpen=50.0))
     net = lm.PL3DVNet(None, drv.DEPTH_CONFIG, cfg['edge_len'], feat_dim=32, img_size=cfg['img_size']).eval()
-    net.mvsnet.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
-    net.pointnet.load_state_dict(syn.pointnet_weights())
-    net.sparse_conv.load_state_dict(syn.sparse_unet_weights())
-    net.decoder.load_state_dict(syn.decoder_weights(sharpen=50.0), strict=False)
+    net.mvsnet.cnn_3d.load_state_dict(sds['cr'], strict=False)
+    net.pointnet.load_state_dict(sds['pn'])
+    net.sparse_conv.load_state_dict(sds['un'])
+    net.decoder.load_state_dict(sds['dec'], strict=False)
     net = net.to(dev)
-    # Random synthetic features give noise depths => a volume-filling point cloud.  Stage 1 runs and is timed, but
-    # its output is then replaced by surface-like depths (analytic wall depth of the box room + 2 cm seeded noise,
-    # SURVEY §8d) so that the scene model and the point-flow sweeps see a ScanNet-like voxel count.
-    gt = syn.ray_box_depth(rot[k:k + refs], tv[k:k + refs], K[k:k + refs], cfg['img_size'], drv.DEPTH_CONFIG['size'])
-    gt = (gt + 0.02 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(7))).to(dev)
     group = None
 
     def step():
-        return drv.process_scene(b, net, k, dev, rank=rank, world=world, group=group, gather_depth=False,
+        return drv.process_scene(b, net, win, dev, rank=rank, world=world, group=group, gather_depth=False,
                                  init_depth_override=gt)
 
     def fence():
@@ -385,8 +407,22 @@ def bench_scene(args, rank, world, dev, dist):
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             roofline = dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak, kernel=dom,
                             avg_ms=st[dom][0] / st[dom][1], traffic=None)
-    if dist is not None:
-        pass
+    # ---- parity of the refinement leg: a 4-view scene of the same shapes / weights through the same driver, HIP against the
+    # oracle-backed net (CPU; rows A1-A4 with the pinned orders), final depths after 2 x (scene model + 3 sweeps)
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.net import OracleNet          # checker only
+        n_chk = 4
+        bs, gts = make(n_chk, 77)
+        with torch.no_grad():
+            d_hip = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev)).cpu()
+            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            onet = OracleNet(sds['cr'], sds['pn'], sds['un'], sds['dec'], cfg['img_size'], cfg['edge_len'], pinned=True)
+            d_cpu = drv.process_scene(bs, onet, win, torch.device('cpu'), init_depth_override=gts)
+        parity = dict(checked_views=n_chk, checker='oracle-backed scene driver (oracle/net.py: oracle/costvolume.py + '
+                      'oracle/scene.py), same driver code, CPU',
+                      max_rel_depth_err_gpu_vs_cpu=float(((d_hip - d_cpu).abs() / d_cpu).max()),
+                      max_abs_refinement_m=float((d_cpu - gts).abs().max()))
     if rank != 0:
         return None
     return {
@@ -394,15 +430,40 @@ def bench_scene(args, rank, world, dev, dist):
         'value': value, 'unit': 'depth maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
-        'config': {'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, 5 edges/ref (2 src either '
-                               'side), 96 planes, 56x56 plane grid, 4 cm voxels; stage A (timed) -> its depths replaced '
+        'config': {'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, %d edges/ref (ref-%d .. ref+%d), '
+                               '96 planes, 56x56 plane grid, 4 cm voxels; stage A (timed) -> its depths replaced '
                                'by analytic wall depth + 2 cm noise -> 2 x (scene model + 3 point-flow sweeps)'
-                               % (args.config, refs),
-                   'refs_per_scene': refs, 'refs_per_gpu': refs // world,
+                               % (args.config, refs, nb + na + 1, nb, na),
+                   'refs_per_scene': refs, 'refs_per_gpu': refs // world, 'edges_per_ref': nb + na + 1,
                    'parallelism': ('ref-view sharding + RCCL all-gather of the feature-rich point cloud per outer '
-                                   'iteration' if world > 1 else 'single GPU'),
+                                   'iteration (the communicating mode)' if world > 1 else 'single GPU'),
                    'ranks_seen': world if dist is None else dist.get_world_size()},
-        'roofline': roofline, 'cpu_baseline': None, 'kernels': kernels}
+        'roofline': roofline, 'cpu_baseline': None, 'parity': parity, 'kernels': kernels}
+
+
+def compact(line):
+    """The figures of a full bench line that go into the default line's "extra" object."""
+    out = {k: line[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'value_fp32_exact',
+                                'ms_per_step_fp32_exact') if k in line}
+    out['workload'] = line['config']['workload']
+    for k in ('refs_per_step_per_gpu', 'refs_per_scene', 'edges_per_ref'):
+        if k in line['config']:
+            out[k] = line['config'][k]
+    out['roofline'] = line.get('roofline')
+    cb = line.get('cpu_baseline') or line.get('parity') or {}
+    out['parity'] = {k: cb[k] for k in ('checked_views', 'checker', 'max_rel_depth_err_gpu_vs_cpu',
+                                        'max_rel_depth_err_gpu_fp32_exact_vs_cpu', 'abs_rel_gpu_vs_cpu',
+                                        'max_rel_depth_err_gpu_vs_host_blas_oracle', 'host_blas_checked_views',
+                                        'max_abs_refinement_m') if k in cb}
+    top = sorted(line.get('kernels', {}).items(), key=lambda kv: -kv[1].get('share', 0))[:4]
+    out['top_kernels'] = {k: {kk: v[kk] for kk in ('avg_ms', 'total_ms', 'share', 'frac') if kk in v} for k, v in top}
+    return out
+
+
+def rank_command(n, port, argv):
+    """Command line that re-runs this script as n ranks on this node (what the driver itself uses for N > 1)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def spawn_ranks(n):
@@ -410,10 +471,50 @@ def spawn_ranks(n):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(rank_command(n, port, sys.argv[1:]), env=env)
+
+
+def bench_dry_run(args, rank, world):
+    """`--dry-run`: the multi-rank plumbing of this script without a GPU (gloo, CPU tensors, a no-op step): rendezvous from
+    the launcher's environment, barrier-bracketed timing, max over ranks, every rank counted, ONE JSON line from rank 0.
+    Exercised by tests/test_driver.py so that a future `bench.py --gpus 8` cannot die on plumbing."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    refs = args.refs or 64
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (1 + rank))            # uneven ranks: the reported time must be the slowest rank's
+    fence()
+    el = time.perf_counter() - t0
+    seen = 1
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        cnt = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(cnt)
+        seen = int(cnt.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no GPU work)', 'value': None, 'unit': 'depth maps/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE,
+                          'data': 'none', 'dry_run': True,
+                          'config': {'workload': 'dry run of the rank plumbing', 'refs_per_step_per_gpu': refs,
+                                     'parallelism': 'ref-view sharding, no collective' if world > 1 else 'single process',
+                                     'ranks_seen': seen}}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -427,7 +528,14 @@ def main():
     ap.add_argument('--cpu-refs', type=int, default=1, help='reference views in the timed CPU-baseline sample')
     ap.add_argument('--check-refs', type=int, default=-1, help='views of the timed GPU batch compared with the '
                     'oracle (-1 = all)')
+    ap.add_argument('--host-check-refs', type=int, default=-1, help='views also compared with the plain torch oracle of '
+                    'this host (-1 = all checked views)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scene-window', default='4,3', help='cfg3/cfg4: source views before,after each reference view '
+                    '(4,3 = SURVEY 8d: 1 ref + 7 src; 2,2 = the reference eval script)')
+    ap.add_argument('--no-extra', action='store_true', help='default cfg2 run: do not append the cfg5 / cfg3 figures')
+    ap.add_argument('--extra', action='store_true', help='append the cfg5 / cfg3 figures also when --refs is given')
+    ap.add_argument('--dry-run', action='store_true', help='rank plumbing only (gloo, no GPU, no-op step): see bench_dry_run')
     ap.add_argument('--graph', action='store_true', help='time HIP-graph replays of the step instead of eager launches (cfg2 / cfg5)')
     args = ap.parse_args()
 
@@ -436,8 +544,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback on the product path)'
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d' % (args.gpus, world)
+    if args.dry_run:
+        return bench_dry_run(args, rank, world)
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback on the product path)'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -451,6 +561,23 @@ def main():
         line = bench_scene(args, rank, world, dev, dist)
     else:
         line = bench_costvolume(args, rank, world, dev, dist)
+        if args.config == 'cfg2' and world == 1 and not args.no_extra and (args.extra or not args.refs):
+            # every configuration's figure in the driver-run line: cfg5 (8 views per step) and the cfg3 scene, fewer steps,
+            # the oracle only as the checker (its timing legs belong to the headline configuration)
+            import copy
+            extra = {}
+            a5 = copy.copy(args)
+            a5.config, a5.refs, a5.steps, a5.warmup = 'cfg5', 8, min(args.steps, 10), 2
+            a5.check_refs, a5.host_check_refs, a5.cpu_timing, a5.graph = 1, 1, False, False
+            extra['cfg5'] = compact(bench_costvolume(a5, rank, world, dev, dist))
+            a3 = copy.copy(args)
+            a3.config, a3.refs, a3.steps, a3.warmup = 'cfg3', 64, min(args.steps, 5), 1
+            extra['cfg3'] = compact(bench_scene(a3, rank, world, dev, dist))
+            line['extra'] = extra
+            line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '
+                                                'scaling: reference views are independent units); the communicating mode is '
+                                                '`--config cfg4 --gpus N` (one scene sharded by reference view, one RCCL '
+                                                'all-gather of the point cloud per outer iteration)')
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -70,8 +70,11 @@ int v3d_timing_collect(int max_entries, char* names_host, int name_stride, float
  *   edge_src  [n_edges]    out: edges[1] grouped per reference, original edge order inside a group
  *   workspace >= v3d_edges_csr_workspace_bytes(n_img, n_ref)
  * If n_ref is not the number of distinct references, or an index is outside [0, n_img), the kernel writes an empty CSR
- * (all offsets 0: the consumers stay inside their buffers) and sets the workspace's error word;
- * v3d_edges_csr_status copies it to the host (synchronises) -> V3D_ERR_BAD_SHAPE.
+ * (all n_ref + 1 offsets 0 AND all n_ref entries of ref_img 0: the consumers read ref_img[r] and that image's camera block
+ * even for a reference without edges, so both tables keep them inside their buffers; the result is a zero variance
+ * volume) and sets the workspace's error word; v3d_edges_csr_status copies it to the host (synchronises) ->
+ * V3D_ERR_BAD_SHAPE.  Nothing downstream reads that word: callers check it once per edge list (Python: EdgeCsr.check(),
+ * MVSNet.check_edges(); CostVolumeGraph checks at capture and on update(ref_src_edges=)).
  * ------------------------------------------------------------------------------------------ */
 size_t v3d_edges_csr_workspace_bytes(int n_img, int n_ref);
 int v3d_edges_csr(const int64_t* edges, int n_edges, int n_img, int n_ref, int32_t* ref_img, int32_t* edge_ofs,

@@ -107,18 +107,24 @@ def bilinear_sample(fmap, ix, iy):
 
 
 def warp_variance(feat, R, t, K, edges, depth_start, depth_interval, n_planes, img_size, plane_size,
-                  fused_square=False):
+                  fused_square=False, voxel_index=None):
     """Rows A1-A4 (mvsnet.py:176-216): [n_ref, C, D, h, w] float32 tensor.  fused_square=False squares with a rounding
-    before the sum (the reference: x_vox ** 2, then the scatter mean); True = fma(x, x, acc), what the HIP kernels do."""
+    before the sum (the reference: x_vox ** 2, then the scatter mean); True = fma(x, x, acc), what the HIP kernels do.
+    ``voxel_index`` (1-D long tensor of flat voxel indices d*h*w + y*w + x): evaluate only those voxels and return
+    [n_ref, C, len(voxel_index)] -- every voxel is independent, so this is a sub-sample of the full result, bit for bit
+    (used to check full-size volumes such as cfg5 without materialising them)."""
     feat, R, t, K = _t(feat), _t(R), _t(t), _t(K)
     edges = torch.as_tensor(np.asarray(edges) if not torch.is_tensor(edges) else edges)
     refs = torch.unique(edges[0]).tolist()
     _, P = camera_blocks(K, R, t)
     C, Hf, Wf = feat.shape[1:]
     h, w = plane_size
-    out = torch.zeros((len(refs), C, n_planes * h * w), dtype=torch.float32)
+    n_out = n_planes * h * w if voxel_index is None else int(voxel_index.numel())
+    out = torch.zeros((len(refs), C, n_out), dtype=torch.float32)
     for r, ref in enumerate(refs):
         X = world_points(K, R, t, ref, depth_start, depth_interval, n_planes, img_size, plane_size)
+        if voxel_index is not None:
+            X = X[:, voxel_index]
         s = torch.zeros((C, X.shape[1]), dtype=torch.float32)
         q = torch.zeros_like(s)
         srcs = edges[1][edges[0] == ref].tolist()
@@ -130,4 +136,4 @@ def warp_variance(feat, R, t, K, edges, depth_start, depth_interval, n_planes, i
         cnt = float(max(len(srcs), 1))
         avg, avg_sq = s / cnt, q / cnt
         out[r] = avg_sq - avg * avg
-    return out.reshape(len(refs), C, n_planes, h, w)
+    return out if voxel_index is not None else out.reshape(len(refs), C, n_planes, h, w)

@@ -102,3 +102,31 @@ def test_mvsnet_forward_from_images(cuda):
     # planes on a 1e-5 difference of the regularised volume, so the depth is checked on all but a handful of pixels
     rel = (depth.cpu() - depth_o).abs() / depth_o
     assert float((rel < 1e-4).float().mean()) > 0.995
+
+
+@pytest.mark.gpu
+def test_backbone_device_arithmetic_matches_cpu(cuda):
+    """The only pin available for row 8f-3 without torchvision: the backbone's arithmetic on the device (MIOpen / rocBLAS
+    through stock PyTorch modules) against the same modules on the CPU, seeded weights and images, at the cfg2 image size:
+    all five FPN outputs within 1e-5 of their range (fp32 convolutions, summation order differs)."""
+    bb, syn = v3d('backbone'), v3d('synthetic')
+    fe, fs = bb.build_backbone(32)
+    sd_e, sd_s = syn.backbone_weights(32, seed=6)
+    assert not fe.load_state_dict(sd_e, strict=False).unexpected_keys
+    fs.load_state_dict(sd_s)
+    fe, fs = fe.eval(), fs.eval()
+    img = syn.make_images(3, (256, 320), seed=4)
+    with torch.no_grad():
+        cpu_maps = fe(img)
+        cpu_out = fs(*cpu_maps)
+        fe_d, fs_d = fe.to(cuda), fs.to(cuda)
+        dev_maps = fe_d(img.to(cuda))
+        dev_out = fs_d(*dev_maps)
+    assert [tuple(o.shape) for o in dev_out] == [tuple(o.shape) for o in cpu_out]
+    assert tuple(dev_out[1].shape) == (3, 32, 64, 80)                 # the quarter-resolution map the cost volume consumes
+    for name, a, b in [('C%d' % (i + 1), x, y) for i, (x, y) in enumerate(zip(dev_maps, cpu_maps))] + \
+                      [('P%d' % (i + 1), x, y) for i, (x, y) in enumerate(zip(dev_out, cpu_out))]:
+        scale = float(b.abs().max())
+        assert scale > 1e-3 and torch.isfinite(a).all(), name
+        err = float((a.cpu() - b).abs().max()) / scale
+        assert err < 1e-5, '%s: device vs CPU %.2e of range' % (name, err)

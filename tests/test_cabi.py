@@ -78,10 +78,13 @@ def test_edges_to_csr_matches_unique_semantics():
     assert src.tolist() == [1, 3, 0, 2, 5, 4]
 
 
-def test_pl3dvnet_rejects_unsupported_feat_dim():
-    """The reference's signature default feat_dim=16 is not what its config uses (32, mv3d/config.py:42); the HIP path
-    supports 32 only and says so at construction time instead of failing on an assert deep inside SparseUNet."""
+def test_pl3dvnet_default_construction_and_unsupported_feat_dim():
+    """The reference's default construction PL3DVNet(depth_train, depth_test, edge_len) works and builds the 32-channel
+    network its config and checkpoints use (mv3d/config.py:42; the signature default of 16 is not a shipped
+    configuration); an explicit feat_dim=16 is rejected at construction time instead of failing on an assert deep inside
+    SparseUNet."""
     lm = v3d('lightningmodel')
+    net = lm.PL3DVNet(None, {'size': (8, 8)}, 0.08)
+    assert net.hparams.feat_dim == 32 and net.sparse_conv.dims == (64, 128, 128)
     with pytest.raises(ValueError, match='feat_dim'):
-        lm.PL3DVNet(None, {'size': (8, 8)}, 0.08)
-    assert lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=32).sparse_conv.dims == (64, 128, 128)
+        lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=16)

@@ -59,6 +59,31 @@ def test_chunk_sizes_do_not_change_results():
     assert float((ref - 0.5).abs().max()) > 0.1 and torch.isfinite(ref).all()
 
 
+def test_one_sided_window_chunking():
+    """process_scene with a (before, after) window (SURVEY 8d's ref-4 .. ref+3 convention, here 2 / 1): chunked stage 1 and
+    chunked sweeps with their one-sided image halo give the unchunked result."""
+    syn, drv = v3d('synthetic'), v3d('eval_3dvnet')
+    Batch = v3d('batch').Batch
+
+    def scene(nb, na, n_ref=5):
+        edges, n_img = syn.make_edges(n_ref, nb, na)
+        rot, tv, K = syn.make_cameras(n_img, IMG, seed=43)
+        b = Batch(None, rot, tv, K, None, edges)
+        b.features_quarter = syn.make_features(n_img, 32, *FEAT, seed=43)
+        return b
+
+    def run(win, **kw):
+        net = OracleNet(*weights(), IMG, 0.16)
+        return drv.process_scene(scene(*win), net, win, torch.device('cpu'), CFG, OFFSETS, **kw)
+    ref = run((2, 1), init_depth_batch=18, offset_batch=16)
+    np.testing.assert_allclose(run((2, 1), init_depth_batch=2, offset_batch=3).numpy(), ref.numpy(), rtol=1e-5, atol=0)
+    assert ref.shape[0] == 5 and torch.isfinite(ref).all()
+    # the one-sided halo is what the chunks slice: the same call with the reference views shifted by one image (a
+    # (1, 2) window on the same images) is a different problem with different depths
+    other = run((1, 2), init_depth_batch=2, offset_batch=3)
+    assert other.shape == ref.shape and float((other - ref).abs().max()) > 1e-3
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -176,9 +201,33 @@ def test_hip_driver_matches_oracle_driver(cuda):
     net.sparse_conv.load_state_dict(un)
     net.decoder.load_state_dict(dec, strict=False)
     net = net.to(cuda)
-    out = drv.process_scene(make_scene(), net, 1, cuda, CFG, OFFSETS, 2, 3)
+    scene = make_scene()
+    out = drv.process_scene(scene, net, 1, cuda, CFG, OFFSETS, 2, 3)
     ref = run_oracle()
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=0)
+    # Row 8f-4 on the device path: the HIP depths written as the reference's preds.npz record (eval/main.py:74-101),
+    # reloaded, and fed to the reference's 2D metrics with the oracle's depths as ground truth.
+    import tempfile
+    res = v3d('results')
+    scene.images = torch.zeros((scene.rotmats.shape[0], 3) + IMG)           # only the image SIZE enters (K rescale)
+    ref_idx = torch.unique(scene.ref_src_edges[0])
+    img_idx = np.arange(100, 100 + scene.rotmats.shape[0])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'preds.npz')
+        res.write_preds(path, '/data/scans/scene0000_00', out.cpu().numpy(), scene, ref_idx, img_idx)
+        rec = dict(np.load(path))
+    assert sorted(rec) == ['K', 'depth_preds', 'img_idx', 'rotmats', 'scene', 'tvecs']
+    assert str(rec['scene']) == 'scene0000_00' and rec['depth_preds'].shape == (5,) + CFG['size']
+    assert np.array_equal(rec['depth_preds'], out.cpu().numpy()) and rec['depth_preds'].dtype == np.float32
+    assert np.array_equal(rec['img_idx'], img_idx[ref_idx.numpy()])
+    assert np.array_equal(rec['rotmats'], scene.rotmats[ref_idx].numpy()) and np.array_equal(rec['tvecs'], scene.tvecs[ref_idx].numpy())
+    K0 = scene.K[ref_idx].numpy()
+    sx, sy = CFG['size'][1] / IMG[1], CFG['size'][0] / IMG[0]
+    np.testing.assert_allclose(rec['K'][:, 0], K0[:, 0] * sx, rtol=1e-6)
+    np.testing.assert_allclose(rec['K'][:, 1], K0[:, 1] * sy, rtol=1e-6)
+    assert np.array_equal(rec['K'][:, 2], K0[:, 2])
+    m = res.depth_metrics_2d(torch.from_numpy(rec['depth_preds']), ref)
+    assert float(m['abs_rel']) < 2e-5 and float(m['d_125']) == pytest.approx(1.0) and float(m['rmse']) < 1e-4
 
 
 @pytest.mark.gpu
@@ -207,3 +256,62 @@ def test_bench_line_schema_and_checks(cuda):
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1
     assert cb['max_rel_depth_err_gpu_vs_cpu'] < 1e-4 and cb['max_rel_depth_err_gpu_fp32_exact_vs_cpu'] < 2e-5
     assert abs(sum(v['avg_ms'] for v in d['kernels'].values()) / d['ms_per_step'] - 1) < 0.5
+    assert 'extra' not in d                   # --refs without --extra: the headline configuration only
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_cfg5_and_cfg3_figures(cuda):
+    """The default `bench.py` line also reports cfg5 (8 views) and the cfg3 scene under "extra", each with a value, the time
+    per step, the dominant kernel and a depth error against the oracle inside the 1e-4 gate (here forced with --extra on a
+    small headline batch so that the test stays short)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--refs', '4',
+                        '--cpu-refs', '1', '--check-refs', '1', '--host-check-refs', '1', '--extra'],
+                       capture_output=True, text=True, timeout=1800, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    e5, e3 = d['extra']['cfg5'], d['extra']['cfg3']
+    assert e5['value'] > 0 and e5['value_fp32_exact'] > 0 and e5['refs_per_step_per_gpu'] == 8 and e5['edges_per_ref'] == 11
+    assert e5['roofline']['kernel'] in e5['top_kernels'] and 0 < e5['roofline']['frac'] < 1
+    assert e5['parity']['checked_views'] >= 1 and e5['parity']['max_rel_depth_err_gpu_vs_cpu'] < 1e-4
+    assert e3['value'] > 0 and e3['refs_per_scene'] == 64 and e3['edges_per_ref'] == 8
+    assert e3['parity']['checked_views'] == 4 and e3['parity']['max_rel_depth_err_gpu_vs_cpu'] < 1e-4
+    assert e3['parity']['max_abs_refinement_m'] > 0.01       # the sweeps really moved the depths
+    assert 'replicas' in d['config']['multi_gpu_note']
+
+
+def test_bench_rank_plumbing_dry_run():
+    """`bench.py --gpus 2 --dry-run` on CPU: the script spawns its own two ranks through torch.distributed.run (the command
+    line the driver uses), they rendezvous on 127.0.0.1 (gloo), only rank 0 prints, ONE JSON line, both ranks counted, and
+    the reported time is the slower rank's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.rank_command(8, 29511, ['--gpus', '8', '--steps', '5'])
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[cmd.index('--master-port') + 1] == '29511' and cmd[-4:] == ['--gpus', '8', '--steps', '5']
+    assert os.path.basename(cmd[cmd.index('29511') + 1]) == 'bench.py'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '1',
+                        '--dry-run'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['dry_run'] and d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['steps'] == 20
+    assert d['ms_per_step'] >= 2.0          # rank 1 sleeps 2 ms per step, rank 0 1 ms: max over ranks
+    # under an external launcher (the driver's form) the script must not spawn again
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    r = subprocess.run(bench.rank_command(2, port, ['--gpus', '2', '--steps', '3', '--warmup', '0', '--dry-run']),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['config']['ranks_seen'] == 2

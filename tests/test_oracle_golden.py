@@ -109,3 +109,22 @@ def test_pinned_oracle_reproduces_golden_variance_bitwise_cfg(name, cfg, sub):
                                inp['img_size'], inp['plane_size'])
     assert np.array_equal(var.numpy()[sub], g['var_sub'])
     assert abs(float(var.double().sum()) - float(g['var_sum'])) < 1e-6
+
+
+def test_pinned_oracle_reproduces_golden_variance_bitwise_cfg5():
+    """The same bit-for-bit check at BASELINE config 5 (480x640, 192 planes, 11 edges, IEEE division by 11): the pinned
+    oracle evaluated on exactly the voxels the reference-generated golden sub-samples (planes ::7, rows ::11, columns ::13,
+    channels ::4) -- voxels are independent, so no full 472 MB volume is needed."""
+    from oracle import pinned
+    g = load_golden('A_cfg5')
+    inp = v3d('synthetic').make_costvolume_inputs('cfg5', n_ref=1)
+    assert abs(float(inp['feat'].double().sum()) - float(g['feat_checksum'])) < 1e-6
+    d0, dd, D = inp['depth']
+    h, w = inp['plane_size']
+    dz, yy, xx = torch.meshgrid(torch.arange(0, D, 7), torch.arange(0, h, 11), torch.arange(0, w, 13), indexing='ij')
+    index = ((dz * h + yy) * w + xx).reshape(-1)
+    var = pinned.warp_variance(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], d0, dd, D,
+                               inp['img_size'], inp['plane_size'], voxel_index=index)
+    sub = var[:, ::4].reshape((1, 8) + tuple(dz.shape)).numpy()
+    assert sub.shape == g['var_sub'].shape
+    assert np.array_equal(sub, g['var_sub'])

@@ -298,17 +298,47 @@ def test_device_edge_csr_equals_torch_unique_and_stable_sort(case, cuda):
 
 
 def test_device_edge_csr_reports_a_wrong_reference_count(cuda):
-    """A wrong n_ref (or an index outside [0, n_img)) must not pass silently: the tables come back empty (all offsets 0, so
-    the warp kernel stays inside its buffers) and .check() raises."""
+    """A wrong n_ref (or an index outside [0, n_img)) must not pass silently: the tables come back empty -- all offsets 0 and
+    every reference slot naming image 0, also the slots beyond the references actually found, which the builder never wrote
+    (the output tensors are poisoned first) -- so the warp kernel stays inside its buffers, and .check() raises.  The module
+    keeps the tables of its last forward: MVSNet.check_edges() raises too."""
     mvs = v3d('mvsnet')
     edges = torch.tensor([[0, 0, 2, 2, 5], [1, 2, 0, 3, 4]], dtype=torch.int64, device=cuda)
     ok = mvs.edges_to_csr(edges, n_ref=3, n_img=6).check()
     assert ok[1].tolist() == [0, 2, 5] and ok[2].tolist() == [0, 2, 4, 5] and ok[3].tolist() == [1, 2, 0, 3, 4]
-    for n_ref, n_img in ((2, 6), (4, 6), (3, 5)):
-        bad = mvs.edges_to_csr(edges, n_ref=n_ref, n_img=n_img)
-        assert int(bad[2].abs().sum()) == 0
+    real_empty = torch.empty
+
+    def poisoned_empty(*a, **k):
+        t = real_empty(*a, **k)
+        if t.dtype == torch.int32:
+            t.fill_(0x7fffffff)
+        return t
+    for n_ref, n_img in ((2, 6), (4, 6), (3, 5), (6, 6)):
+        torch.empty = poisoned_empty
+        try:
+            bad = mvs.edges_to_csr(edges, n_ref=n_ref, n_img=n_img)
+        finally:
+            torch.empty = real_empty
+        assert bad[2].shape[0] == n_ref + 1 and int(bad[2].abs().sum()) == 0
+        assert bad[1].shape[0] == n_ref and int(bad[1].abs().sum()) == 0
         with pytest.raises(RuntimeError):
             bad.check()
+    # the product path: a wrong reference count yields a finite, all-zero variance volume and check_edges() raises
+    syn = v3d('synthetic')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=5)
+    d0, dd, D = inp['depth']
+    net = mvs.MVSNet(32, inp['img_size']).eval().to(cuda)
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    with torch.no_grad():
+        _, var, _ = net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'], return_intermediates=True,
+                                          n_ref=4)
+    assert var.shape[0] == 4 and float(var.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        net.check_edges()
+    with torch.no_grad():
+        net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'], n_ref=3)
+    net.check_edges()
 
 
 def test_cost_volume_depth_with_reference_count_hint_is_bit_identical(cuda):
@@ -353,3 +383,45 @@ def test_cost_volume_graph_replay_equals_eager_and_follows_updates(cuda):
         eager2 = net.cost_volume_depth(inp2['feat'].to(cuda), b2, d0, dd, D, inp['plane_size'], n_ref=3)
     assert not torch.equal(eager2, eager)
     assert torch.equal(g.replay(), eager2)
+
+
+def test_cost_volume_graph_survives_workspace_growth_and_refuses_stale_weights(cuda):
+    """The captured launches carry raw addresses.  (i) A later, LARGER eager call replaces the module's grow-only scratch
+    buffers: the graph keeps its own alive and still replays the captured step bit for bit.  (ii) Changing a regulariser
+    parameter releases the packed weight image the graph points to: replay() raises instead of running on freed memory, and a
+    freshly captured graph works.  (iii) update(ref_src_edges=) with an edge list that no longer holds n_ref references
+    raises."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=5)
+    d0, dd, D = inp['depth']
+    net = mvs.MVSNet(32, inp['img_size']).eval()
+    net.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
+    net = net.to(cuda)
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    feat = inp['feat'].to(cuda).clone()
+    g = mvs.CostVolumeGraph(net, feat, b, d0, dd, D, inp['plane_size'], n_ref=3)
+    want = g.replay().clone()
+    old_ptrs = {k: v.data_ptr() for k, v in list(net._ws._bufs.items()) + list(net.cnn_3d._ws._bufs.items())}
+    big = syn.make_costvolume_inputs('cfg1', n_ref=7, seed=9)          # more views: every workspace grows
+    bb = Batch(None, big['rotmats'], big['tvecs'], big['K'], None, big['edges']).to(cuda)
+    with torch.no_grad():
+        net.cost_volume_depth(big['feat'].to(cuda), bb, d0, dd, D, big['plane_size'], n_ref=7)
+        junk = [torch.full((1 << 22,), float('nan'), device=cuda) for _ in range(8)]   # recycle whatever was freed
+    new_ptrs = {k: v.data_ptr() for k, v in list(net._ws._bufs.items()) + list(net.cnn_3d._ws._bufs.items())}
+    assert any(old_ptrs[k] != new_ptrs[k] for k in old_ptrs), 'the larger call was expected to replace a workspace'
+    assert torch.equal(g.replay(), want)
+    del junk
+    assert not g.stale()
+    with torch.no_grad():
+        net.cnn_3d.prob.bias.add_(0.25)
+    assert g.stale()
+    with pytest.raises(RuntimeError):
+        g.replay()
+    g2 = mvs.CostVolumeGraph(net, feat, b, d0, dd, D, inp['plane_size'], n_ref=3)
+    with torch.no_grad():
+        assert torch.equal(g2.replay(), net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'], n_ref=3))
+    with pytest.raises(RuntimeError):
+        e = b.ref_src_edges.clone()
+        e[0] = e[0, 0]                                                   # one reference image instead of three
+        g2.update(ref_src_edges=e)

@@ -235,14 +235,14 @@ def test_voxelize_exact_multiple_quirk_and_multibatch(cuda):
 
 
 def test_full_size_scene_properties_cfg3(cuda):
-    """BASELINE config-3 shapes (56x56 maps, 32-ch 64x80 features, 4 cm voxels), 12 views, two batch elements:
-    size-independent properties at full size -- finite outputs, offsets inside the hypothesis range, probabilities
+    """BASELINE config-3 at FULL size: all 64 reference views of the scene (68 images with the +-2 halo, 56x56 maps, 32-ch
+    64x80 features, 4 cm voxels, 200 704 points), two batch elements: size-independent properties -- finite outputs, offsets inside the hypothesis range, probabilities
     sum to one, chunked point-flow bit-identical to one call, queries far outside the scene interpolate to zero."""
     syn, lm, ut = v3d('synthetic'), v3d('lightningmodel'), v3d('utils')
     cfg = syn.CONFIGS['cfg3']
-    n_ref, k = 12, 2
+    n_ref, k = 64, 2
     edges, n_img = syn.make_edges(n_ref, k, k)
-    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=5)
+    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=5, yaw_step_deg=360.0 / n_img)
     feat = syn.make_features(n_img, 32, *cfg['feat_size'], seed=5).to(cuda)
     depth = syn.ray_box_depth(rot[k:k + n_ref], tv[k:k + n_ref], K[k:k + n_ref], cfg['img_size'], (56, 56))
     depth = (depth + 0.02 * torch.randn(depth.shape, generator=torch.Generator().manual_seed(1))).to(cuda)
@@ -258,12 +258,12 @@ def test_full_size_scene_properties_cfg3(cuda):
         xs, pts = net.model_scene(depth, dbatch, feat, rot, tv, K, edges, return_pts=True)
         assert pts.shape == (n_ref * 3136, 3) and [x['stride'] for x in xs] == [4, 2, 1]
         assert all(torch.isfinite(x['feats']).all() for x in xs)
-        assert xs[2]['feats'].shape[0] > 5000 and set(xs[2]['batch'].unique().tolist()) == {0, 1}
+        assert xs[2]['feats'].shape[0] > 20000 and set(xs[2]['batch'].unique().tolist()) == {0, 1}
         off = net.run_pointflow(xs, depth, dbatch, feat, rot, tv, K, edges, 0.05, 3)
         assert torch.isfinite(off).all() and float(off.abs().max()) <= 0.15 + 1e-6
         parts = []
-        for r0 in range(0, n_ref, 5):
-            r1 = min(r0 + 5, n_ref)
+        for r0 in range(0, n_ref, 16):                              # eval-3dvnet.py:13 offset batch size
+            r1 = min(r0 + 16, n_ref)
             e = ut.slice_edges(edges, r0 + k, r1 + k, 0) - r0
             parts.append(net.run_pointflow(xs, depth[r0:r1], dbatch[r0:r1], feat[r0:r1 + 2 * k], rot[r0:r1 + 2 * k],
                                            tv[r0:r1 + 2 * k], K[r0:r1 + 2 * k], e, 0.05, 3))
@@ -273,3 +273,95 @@ def test_full_size_scene_properties_cfg3(cuda):
         assert float(f.abs().max()) == 0.0
         preds = net.decoder.decode(f)
         assert torch.allclose(preds.sum(1), torch.ones(4, device=cuda), atol=1e-6)
+
+
+def _surface_scene(img, featsz, grid, n_ref, k, seed, radius, noise):
+    syn = v3d('synthetic')
+    edges, n_img = syn.make_edges(n_ref, k, k)
+    rot, tv, K = syn.make_cameras(n_img, img, seed=seed, radius=radius)
+    feat = syn.make_features(n_img, 32, *featsz, seed=seed)
+    depth = syn.ray_box_depth(rot[k:k + n_ref], tv[k:k + n_ref], K[k:k + n_ref], img, grid)
+    depth = depth + noise * torch.randn(depth.shape, generator=torch.Generator().manual_seed(seed + 1))
+    return dict(depth=depth, depth_batch=torch.zeros(n_ref, dtype=torch.long), feat=feat, rotmats=rot, tvecs=tv, K=K,
+                edges=edges)
+
+
+def test_small_scene_2cm_voxels_matches_oracle(cuda):
+    """BASELINE config 5 names 2 cm voxels.  A scene small enough for the oracle, dense enough for 2 cm cells to have
+    neighbours (cameras 0.5-1 m from the walls, samples ~1.5 cm apart: 9 216 points -> ~6 300 / 2 300 / 350 voxels on the
+    three levels): back-projection, voxelisation, PointNet, sparse U-Net, interpolation + decoder and the offset expectation
+    at edge_len = 0.02 against the oracle, same tolerances as the 16 cm scene above."""
+    syn, lm = v3d('synthetic'), v3d('lightningmodel')
+    img = (120, 160)
+    c = _surface_scene(img, (30, 40), (48, 64), n_ref=3, k=1, seed=21, radius=2.0, noise=0.01)
+    sd = dict(pn=syn.pointnet_weights(seed=1), un=syn.sparse_unet_weights(seed=2), dec=syn.decoder_weights(seed=3, sharpen=50.0))
+    xs_o, pts_o = osc.model_scene(c['depth'], c['depth_batch'], c['feat'], c['rotmats'], c['tvecs'], c['K'], c['edges'],
+                                  0.02, sd['pn'], sd['un'], img)
+    off_o = osc.run_pointflow(xs_o, c['depth'], c['depth_batch'], c['feat'], c['rotmats'], c['tvecs'], c['K'], c['edges'],
+                              0.025, 3, sd['dec'], img)
+    assert xs_o[2]['feats'].shape[0] > 4000 and xs_o[0]['feats'].shape[0] > 100
+    net = lm.PL3DVNet(None, {'size': (48, 64)}, 0.02, feat_dim=32, img_size=img).eval()
+    net.pointnet.load_state_dict(sd['pn'])
+    net.sparse_conv.load_state_dict(sd['un'])
+    net.decoder.load_state_dict(sd['dec'], strict=False)
+    net = net.to(cuda)
+    d = {k: v.to(cuda) for k, v in c.items()}
+    with torch.no_grad():
+        xs, pts = net.model_scene(d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'],
+                                  return_pts=True)
+        off = net.run_pointflow(xs, d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'],
+                                0.025, 3)
+    _close(pts.cpu(), pts_o, atol=2e-5)
+    for x, r in zip(xs, xs_o):
+        assert torch.equal(x['sparse'].coords.cpu().long(), r['coords'])
+        _close(x['pts'].cpu(), r['pts'], atol=1e-5)
+        _close(x['feats'].cpu(), r['feats'], rel=2e-4)
+    _close(off.cpu(), off_o, atol=2e-5)
+    assert float(off_o.abs().max()) > 0.01
+
+
+def test_full_size_scene_properties_cfg5_2cm(cuda):
+    """BASELINE config 5's refinement leg at full size: 480x640 images, 32-ch 120x160 features, 120x160 depth maps, 8
+    reference views + 5 source views either side (18 images), **2 cm voxels** (153 600 points): scene model + one 7-hypothesis
+    point-flow sweep.  Size-independent properties -- finite outputs, voxel counts of a surface (coarser levels shrink ~4x),
+    every range check of the fixed-size device tables clean (voxelize status, hash-table status of all three levels),
+    offsets inside the hypothesis range, chunked sweep bit-identical to one call, the stride-1 voxel centres within half a
+    cell diagonal of some point."""
+    syn, lm, ut = v3d('synthetic'), v3d('lightningmodel'), v3d('utils')
+    cfg = syn.CONFIGS['cfg5']
+    assert cfg['edge_len'] == 0.02
+    n_ref, k = 8, cfg['window'][0]
+    c = _surface_scene(cfg['img_size'], cfg['feat_size'], cfg['plane_size'], n_ref=n_ref, k=k, seed=9, radius=0.8, noise=0.01)
+    d = {kk: v.to(cuda) for kk, v in c.items()}
+    net = lm.PL3DVNet(None, {'size': cfg['plane_size']}, cfg['edge_len'], feat_dim=32, img_size=cfg['img_size']).eval()
+    net.pointnet.load_state_dict(syn.pointnet_weights())
+    net.sparse_conv.load_state_dict(syn.sparse_unet_weights())
+    net.decoder.load_state_dict(syn.decoder_weights(sharpen=50.0), strict=False)
+    net = net.to(cuda)
+    P = cfg['plane_size'][0] * cfg['plane_size'][1]
+    with torch.no_grad():
+        xs, pts = net.model_scene(d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'],
+                                  return_pts=True)                  # voxelize + the three hash tables check their status words
+        assert pts.shape == (n_ref * P, 3) and [x['stride'] for x in xs] == [4, 2, 1]
+        for x in xs:
+            x['sparse'].check()
+            assert torch.isfinite(x['feats']).all()
+        n4, n2, n1 = (x['feats'].shape[0] for x in xs)
+        assert n_ref * P >= n1 > 40000 and n1 / 2.5 > n2 > n1 / 6 and n2 / 2.5 > n4 > n2 / 6, (n1, n2, n4)
+        # every stride-1 voxel holds at least one point: its centre is within half a cell diagonal of the cloud
+        a_pts, a_idx, a_batch, a_edges = ut.voxelize(pts, torch.zeros(pts.shape[0], dtype=torch.long, device=cuda), 0.02)
+        assert a_pts.shape[0] == n1
+        dist = (pts[a_edges[1]] - a_pts[a_edges[0]]).abs().max()
+        assert float(dist) <= 0.01 + 1e-5
+        off = net.run_pointflow(xs, d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'],
+                                0.025, 3)
+        assert off.shape == (n_ref,) + tuple(cfg['plane_size'])
+        assert torch.isfinite(off).all() and float(off.abs().max()) <= 0.075 + 1e-6 and float(off.abs().max()) > 0.01
+        parts = []
+        for r0 in range(0, n_ref, 3):
+            r1 = min(r0 + 3, n_ref)
+            e = ut.slice_edges(d['edges'], r0 + k, r1 + k, 0) - r0
+            parts.append(net.run_pointflow(xs, d['depth'][r0:r1], d['depth_batch'][r0:r1], d['feat'][r0:r1 + 2 * k],
+                                           d['rotmats'][r0:r1 + 2 * k], d['tvecs'][r0:r1 + 2 * k], d['K'][r0:r1 + 2 * k],
+                                           e, 0.025, 3))
+        assert torch.equal(torch.cat(parts), off)
