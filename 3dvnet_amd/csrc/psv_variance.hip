@@ -654,10 +654,14 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
 // there (ds_read_b128, a quarter of the L1 path's price per KB, tens instead of hundreds of cycles of latency).  Whether any
 // pixel changes its footprint on plane k is known after the projection (one ballot): the reload branch is scalar and all
 // lanes reload together.  A sample whose footprint lies outside the window (near planes with long epipolar slides, exotic
-// camera pairs, the few tiles whose corners are not extreme) carries a flag in its tap word and reads its four cells from
+// camera pairs, the few tiles whose corners are not extreme) carries a flag in its tap word (the sign bit) and reads its four cells from
 // featT as the reuse kernel does, inside the same step.  Arithmetic and accumulation order are those of the other two
 // kernels: bit-identical output.
 constexpr int kWinCols = 16, kWinRows = 4;                 // window: 16 x 4 cells x 128 B = 8 KB per wave
+
+// scalar min / max of wave-uniform values (the compiler picks v_min3 / v_max3 + v_readfirstlane for these otherwise)
+__device__ __forceinline__ int psv_smin(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int psv_smax(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
 
 #ifndef V3D_PSVW_ABLATE
 #define V3D_PSVW_ABLATE 0    // developer ablations of the window kernel: 1 no blend, 2 no footprint reads, 3 no window copy, 5 no store, 6 no out-of-window path
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   constexpr int C = 32, WPB = SPLIT ? 1 : 4;
   constexpr unsigned CB = 4 * C;                            // bytes per cell
   constexpr int kOutPl = 4;                                 // planes staged per round of the fp32 epilogue
-  static_assert(kRDB == 8 && kRE == 1, "the window kernel projects one edge per pass: 8 planes x 8 pixels = 64 lanes");
+  static_assert(kWinCols == 16 && kRDB == 8 && kRE == 1, "the window kernel projects one edge per pass: 8 planes x 8 pixels = 64 lanes");
   __shared__ __attribute__((aligned(16))) float s_win_[WPB][kWinRows * kWinCols * C];
   __shared__ __attribute__((aligned(16))) f32x4 s_w_[WPB][kRDB * kRPix];      // nw, ne, sw, se weights per (plane, pixel)
   __shared__ unsigned s_slot_[WPB][kRDB * kRPix];           // byte offset of the nw cell: in the window / in featT
@@ -720,8 +724,12 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   const int gpx = lane >> 3;
   const unsigned cgb = (lane & 7) * 16;
   const unsigned rowb = (unsigned)Wp * CB + cgb;
+  const unsigned lane16 = (unsigned)lane * 16u;
   const char* const fb = reinterpret_cast<const char*>(p.featT);
   const char* const wb = reinterpret_cast<const char*>(s_win);
+  // LDS byte address of this wave's window (what M0 carries for global_load_lds)
+  const unsigned win_lds = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)s_win);
   f32x4 acc_s[kRDB], acc_q[kRDB];
 #pragma unroll
   for (int k = 0; k < kRDB; ++k) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -800,16 +808,18 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
       const int cd = __builtin_amdgcn_readlane(cc, 56), ce = __builtin_amdgcn_readlane(cc, 63);
       const int xa = ca & 0xffff, xc = cb & 0xffff, xd = cd & 0xffff, xe = ce & 0xffff;
       const int ya = ca >> 16, yc = cb >> 16, yd = cd >> 16, ye = ce >> 16;
-      xmin = min(min(xa, xc), min(xd, xe));
-      ymin = min(min(ya, yc), min(yd, ye));
-      ncol = max(max(xa, xc), max(xd, xe)) - xmin + 2 > 8 ? kWinCols : 8;
-      nrow = min(max(max(ya, yc), max(yd, ye)) - ymin + 2, kWinRows);
+      xmin = psv_smin(psv_smin(xa, xc), psv_smin(xd, xe));
+      ymin = psv_smin(psv_smin(ya, yc), psv_smin(yd, ye));
+      ncol = psv_smax(psv_smax(xa, xc), psv_smax(xd, xe)) - xmin + 2 > 8 ? kWinCols : 8;
+      nrow = psv_smin(psv_smax(psv_smax(ya, yc), psv_smax(yd, ye)) - ymin + 2, kWinRows);
     }
     const int base_cell = __builtin_amdgcn_readfirstlane(s_base[e % kMaxE]);
     const unsigned dx = (unsigned)(xb - xmin), dy = (unsigned)(yb - ymin);
     const bool inwin = dx <= (unsigned)(ncol - 2) && dy <= (unsigned)(nrow - 2);
-    // tap word: byte offset of the nw cell in the window, or in featT with bit 0 set (cells are 128-byte aligned)
-    const unsigned so = inwin ? (dy * kWinCols + dx) * CB : ((unsigned)(base_cell + yb * Wp + xb) * CB | 1u);
+    // tap word: byte offset of the nw cell in the window, or -- sign bit set -- in featT (< 2 GB, checked by the host)
+    const unsigned so_win = ((dy << 4) | dx) * CB;
+    const unsigned so_ext = ((unsigned)(base_cell + __mul24(yb, Wp) + xb) * CB) | 0x80000000u;
+    const unsigned so = inwin ? so_win : so_ext;
     s_w[lane] = wq;
     s_slot[lane] = so;
     // does ANY pixel change its footprint on plane k (bit group k of the ballot)?  plane 0 always loads
@@ -818,13 +828,22 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     // copy the window: nrow rows of 8 or 16 cells from (xmin, ymin) (runs past the last needed column stay inside the bordered
     // maps + tail); lane l moves bytes [16 l, 16 l + 16) of each 1 KB run
     {
-      const char* src = fb + ((size_t)(unsigned)(base_cell + ymin * Wp + xmin) * CB + (unsigned)lane * 16u);
+      // wave-uniform row address (SGPR pair) + the lane's 16 bytes (one constant VGPR): no per-lane address arithmetic.  The
+      // copies are written in assembly (hipcc forms 64-bit per-lane addresses for the builtin): M0 = LDS byte address of the
+      // run, saved and restored around each copy; the wave waits for them itself (vmcnt below).
+      const char* rowp = fb + (size_t)((unsigned)(base_cell + ymin * Wp + xmin) * CB);
+      unsigned dst = win_lds;
+      asm volatile("s_nop 4" ::: "memory");            // SGPRs written by v_readlane may feed the first copy's address
+#pragma unroll 1
       for (int rr = 0; rr < (V3D_PSVW_ABLATE == 3 ? 0 : nrow); ++rr) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)rr * Wp * CB),
-                                         (__attribute__((address_space(3))) void*)(s_win + rr * kWinCols * C), 16, 0, 0);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(rowp), "s"(dst) : "memory");
         if (ncol > 8)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)rr * Wp * CB + 8 * CB),
-                                           (__attribute__((address_space(3))) void*)(s_win + rr * kWinCols * C + 8 * C), 16, 0, 0);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(lane16), "s"(rowp), "s"(dst) : "memory");   // the instruction offset moves BOTH addresses
+        rowp += (size_t)Wp * CB;
+        dst += kWinCols * CB;
       }
     }
 #ifndef V3D_PSV_NOPIPE
@@ -852,8 +871,8 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
         sn = s_slot[(pl + 1) * kRPix + gpx];
       }
       if (((chg >> (8 * pl)) & 0xffull) && (V3D_PSVW_ABLATE != 2 || (pl == 0 && e == 0))) {      // wave-uniform: all pixels reload together (a load costs the same masked or not)
-        if (V3D_PSVW_ABLATE != 6 && (so_pl & 1u)) {
-          const unsigned b00 = so_pl - 1u;
+        if (V3D_PSVW_ABLATE != 6 && (int)so_pl < 0) {
+          const unsigned b00 = so_pl & 0x7fffffffu;
           t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + cgb));
           t01 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + cgb) + CB);
           t10 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + rowb));
@@ -903,7 +922,9 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
       __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);                 \
   }
 #define V3D_MEAN_MUL(x) ((x) * cnt_inv)
-#define V3D_MEAN_DIV(x) ((x) / cnt)
+    // any other count: the correctly rounded quotient from the correctly rounded reciprocal (v3d::div_uniform, Markstein;
+    // 4 instructions instead of the 11 of the IEEE sequence, twice per output value); v_div_fixup restores the special cases
+#define V3D_MEAN_DIV(x) __builtin_amdgcn_div_fixupf(v3d::div_uniform((x), cnt, cnt_inv), cnt, (x))
     if (cnt_pow2) { V3D_PSV_EMIT(V3D_MEAN_MUL) } else { V3D_PSV_EMIT(V3D_MEAN_DIV) }
 #undef V3D_PSV_EMIT
 #undef V3D_MEAN_MUL
@@ -911,7 +932,9 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   } else {
     constexpr int NPX = WPB * kRPix;
     float (*const s_out)[C][NPX + 1] = reinterpret_cast<float (*)[C][NPX + 1]>(&s_win_[0][0]);
-    auto mean = [&](float x) __attribute__((always_inline)) { return cnt_pow2 ? x * cnt_inv : x / cnt; };
+    auto mean = [&](float x) __attribute__((always_inline)) {
+      return cnt_pow2 ? x * cnt_inv : __builtin_amdgcn_div_fixupf(v3d::div_uniform(x, cnt, cnt_inv), cnt, x);
+    };
     const int gp0 = (ptile - wv) * kRPix;             // first pixel of the workgroup
 #pragma unroll
     for (int round = 0; round < kRDB / kOutPl; ++round) {
@@ -1059,7 +1082,9 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
       const long long rblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * ((h * w + kRPix - 1) / kRPix);
       V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
       p.n_ptile = (h * w + kRPix - 1) / kRPix;
-      static const bool no_window = getenv("V3D_PSV_REUSE") != nullptr || kRDB != 8;   // developer A/B switch: round-2 kernel
+      static const bool reuse_env = getenv("V3D_PSV_REUSE") != nullptr || kRDB != 8;   // developer A/B switch: round-2 kernel
+      // the window kernel's tap words keep their sign bit as a flag: feature maps beyond 2 GB take the reuse kernel
+      const bool no_window = reuse_env || psv_feat_bytes(n_img, C, Hf, Wf) >= ((size_t)1 << 31);
       if (split) {
         if (no_window) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
         else psv_variance_window_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);

@@ -23,6 +23,22 @@ def test_uniform_division_by_reciprocal_is_exact():
         assert np.array_equal(q1, (x / c32).astype(np.float32)), c
 
 
+def test_view_count_mean_by_reciprocal_is_exact():
+    """The window warp kernel's mean over a view count that is not a power of two (cfg5: 11 edges) is the same Markstein
+    sequence with c = the count: q0 = x * rc, q = fma(fma(-q0, c, x), rc, q0), rc = RN(1 / c) -- equal to the IEEE quotient
+    x / c (what torch_scatter's mean computes) for every normal-range sum; checked for counts 3 .. 31 on sums and sums of
+    squares spanning 1e-12 .. 1e8 (zeros included: 0 / c = 0 either way)."""
+    rng = np.random.default_rng(2)
+    for c in [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 19, 21, 23, 27, 31]:
+        c32 = np.float32(c)
+        rc = np.float32(1.0) / c32
+        x = (rng.standard_normal(300_000) * rng.choice([1e-12, 1e-6, 1e-3, 1.0, 11.0, 300.0, 1e4, 1e8], 300_000)).astype(np.float32)
+        x[::1000] = 0.0
+        q0 = (x * rc).astype(np.float32)
+        q1 = _fma32(_fma32(-q0, np.full_like(x, c32), x), np.full_like(x, rc), q0)
+        assert np.array_equal(q1, (x / c32).astype(np.float32)), c
+
+
 def test_power_of_two_mean_is_a_multiplication():
     """torch_scatter mean = sum / count; for a power-of-two count the kernels multiply by 1 / count instead."""
     rng = np.random.default_rng(1)
