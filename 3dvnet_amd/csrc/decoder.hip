@@ -1,6 +1,8 @@
 // Row C2b tail + C3 of SURVEY.md §8a: the hypothesis decoder's last Conv1d(h_dim -> 1, k3, pad 1, bias)
 // along the hypothesis axis, softmax over the hypotheses (refinement.py:24,43) and, optionally, the
 // expected depth offset sum_i p_i * vals_i (lightningmodel.py:238-241).  One wave per point.
+#include <cstdlib>
+
 #include "gemm_weights.h"
 #include "sparse_hash.h"
 
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 // this path: split-bf16 operands (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16), fp32 accumulation; weights are the
 // split images of v3d_gemm_pack (A fragments go from L2 straight to registers, one tap ahead).
 // LDS: two activation buffers of 33 KB (the second doubles as staging tile + corner table during layer 1).
-// STATUS: correct and parity-tested, but SLOWER than the unfused chain (cfg3: 33 ms against 23 ms per scene) -- see kFLdsBytes
-// below; it is therefore opt-in (HypothesisDecoder.fused) and the default path stays v3d_sparse_interp_f32 +
-// v3d_gemm_gather_f32 x 3 + v3d_decoder_head_f32.
+// STATUS (round 3): the default decoder whenever the configuration allows (HypothesisDecoder.can_fuse): two workgroups per CU,
+// 3.1 ms per 64-view sweep against 3.7 ms for v3d_sparse_interp_f32 + v3d_gemm_gather_f32 x 3 + v3d_decoder_head_f32 (see
+// kFLdsBytes below for the occupancy bug of round 2).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
@@ -91,11 +93,25 @@ constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap,
 constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
 constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
 constexpr size_t kFUsedLdsBytes = 2 * kFActBytes;
-// Requested LDS: more than half of the CU's 160 KB, so that ONE workgroup runs per CU.  With two co-resident workgroups
-// (the 65 KB the kernel actually uses would allow it) the results were nondeterministic on MI355X / ROCm 7.2 in ways no
-// barrier, wait or LDS-overlap check explained; one workgroup per CU is deterministic and matches the
-// unfused chain to 5e-7.
-constexpr size_t kFLdsBytes = 96 * 1024;
+// Requested LDS: 80 KB = two workgroups per CU (two waves per SIMD: the kernel's 186 VGPRs + 50 AGPRs allow exactly that).
+//
+// The round-2 nondeterminism at two workgroups per CU, diagnosed in round 3 (scripts/micro/fused_decoder_stress.py dumps the
+// layer-1 input rows a workgroup commits and compares them with v3d_sparse_interp_f32):
+//   * it is not a race in this source: wrong rows appear in ~10 % of the workgroups on EVERY launch, always rows 6, 7 (mod 8)
+//     of a wave's staging rows -- lanes 48..63 -- in single channels, as partial corner sums; workgroups at LDS base 0 and at
+//     base 80 KB are hit alike; drains (vmcnt(0) + s_sleep), extra barriers and padded register allocations change nothing;
+//   * it needs matrix instructions in flight on the SIMD (a build that reads the B fragments but issues no MFMA is clean) and
+//     two waves per SIMD (any build whose register count admits one wave per SIMD is clean);
+//   * it follows ONE code-generation choice: at -O2 / -O3 hipcc merges the eight consecutive corner weights a thread reads
+//     from the LDS corner table into two ds_read_b128 (register tuples v[66:69], v[134:137]: even, not 4-aligned); -O1 emits
+//     ds_read2_b32 and is clean, and so is -O3 with those reads kept scalar -- 300 launches beside a GEMM on a second stream.
+// So the corner table is laid out corner-major ([corner][level][row]): the eight values a thread needs are 768 bytes apart,
+// every read is a ds_read_b32 / ds_read2st64_b32 with an immediate offset and nothing can be merged into a 16-byte read
+// (keeping the row-major table and reading it through volatile pointers also works, but every volatile access carries a full
+// s_waitcnt, which serialises the gathers: 3.7 instead of 3.1 ms per sweep).  The GPU suite runs the repeated-launch
+// determinism check at this occupancy.
+constexpr size_t kFLdsBytes = 80 * 1024;
+__device__ __forceinline__ int fused_corner_index(int r, int l, int corner) { return (corner * 3 + l) * 64 + r; }
 static_assert(kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "staging tile + corner table alias the second buffer");
 static_assert((size_t)kFRows * kFH * 4 <= kFActBytes, "fp32 output of the last layer aliases the first buffer");
 
@@ -120,6 +136,10 @@ struct FusedParams {
   const float* vals;      // [n_hyp] offset values or null
   float* preds;           // [n_pts, n_hyp]
   float* expect;          // [n_pts] or null
+#ifdef V3D_FUSED_DEBUG
+  float* dbg_x;           // developer build: [n_pts * n_hyp, K1] the interpolated layer-1 input as committed to the staging tile
+  unsigned* dbg_wg;       // developer build: per workgroup [4]: HW_REG_LDS_ALLOC, HW_REG_HW_ID, XCC id, 0
+#endif
 };
 
 __device__ __forceinline__ unsigned fused_pack_bf16x2(float a, float b) {
@@ -134,12 +154,15 @@ __device__ __forceinline__ void fused_split4(const float (&v)[4], u32x2& hi, u32
                fused_pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
 }
 
-__global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
+#ifndef V3D_FUSED_LB
+#define V3D_FUSED_LB 1
+#endif
+__global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const actA = reinterpret_cast<u32x4*>(smem);                               // [2][kFRT][16]
   u32x4* const actB = reinterpret_cast<u32x4*>(smem + kFActBytes);                  // [2][kFRT][16]
   u32x4* const xq = actB;                                                           // layer 1: [2][kFRT][4]
-  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + kFStageBytes);       // layer 1: [64 rows][3 levels][8]
+  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + kFStageBytes);       // layer 1: [8 corners][3 levels][64 rows]
   float* const cw = reinterpret_cast<float*>(crow + kFRows * 24);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -150,6 +173,13 @@ __global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
   const long long q0 = (long long)pt0 * n_hyp;                       // first global (point, hypothesis) row of the tile
   const long long n_q = (long long)p.n_pts * n_hyp;
 
+#ifdef V3D_FUSED_DEBUG
+  if (p.dbg_wg && tid == 0) {
+    p.dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);     // HW_REG_LDS_ALLOC
+    p.dbg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+    p.dbg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
+  }
+#endif
   // ---- zero rows; corner table: 8 hash probes per (row, level), as interp_corners_kernel (sparse.hip) -----------------
   if (tid < 2 * 16) actA[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
   if (tid < 2 * 4) xq[((tid >> 2) * kFRT + kFZero) * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
@@ -185,69 +215,82 @@ __global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
           row = v3dhash::hash_find(L.table, v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2));
       }
       // an absent corner (or a padding row) reads feature row 0 with weight 0: the gathers below are unconditional
-      crow[(r * 3 + l) * 8 + corner] = row < 0 ? 0 : row;
-      cw[(r * 3 + l) * 8 + corner] = row < 0 ? 0.f : w;
+      crow[fused_corner_index(r, l, corner)] = row < 0 ? 0 : row;
+      cw[fused_corner_index(r, l, corner)] = row < 0 ? 0.f : w;
     }
   }
 
   // ---- layer 1: K = 3 taps x (C0 + C1 + C2 + c_feat) channels, produced chunk by chunk ----------------------------------
   const int srow = tid >> 3, sc4 = (tid & 7) * 4;
   const int cb1 = p.lv[0].C, cb2 = cb1 + p.lv[1].C, cb3 = cb2 + p.lv[2].C;
-  f32x4 xr[2][8];
+  // Gather registers: the level chunks (8 corner rows per staging row) and the per-point feature chunks (one row) have their
+  // own registers and their own loops below -- with one conditional producer the compiler routed the gathers through
+  // temporaries and waited for ALL of them before the chunk's first MFMA (no overlap).
+  f32x4 xr[2][8], xf[2];
+  const int nkc_lv = cb3 / 32;             // chunks produced by interpolation; chunks nkc_lv .. nkc1 - 1 copy pts_feat
   // level of a 32-channel chunk: wave-uniform (chunk boundaries are multiples of 32)
   auto level_of = [&](int kc) __attribute__((always_inline)) {
     const int c = kc * 32;
-    return c < cb1 ? 0 : c < cb2 ? 1 : c < cb3 ? 2 : 3;
+    return c < cb1 ? 0 : c < cb2 ? 1 : 2;
   };
-  auto issue_x = [&](int kc) __attribute__((always_inline)) {
+  auto issue_lv = [&](int kc) __attribute__((always_inline)) {
     const int l = level_of(kc);
-    if (l < 3) {
-      const float* const feats = l == 0 ? p.lv[0].feats : l == 1 ? p.lv[1].feats : p.lv[2].feats;
-      const int C = l == 0 ? p.lv[0].C : l == 1 ? p.lv[1].C : p.lv[2].C;
-      const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
+    const float* const feats = l == 0 ? p.lv[0].feats : l == 1 ? p.lv[1].feats : p.lv[2].feats;
+    const int C = l == 0 ? p.lv[0].C : l == 1 ? p.lv[1].C : p.lv[2].C;
+    const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int r = srow + 32 * ps;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int r = srow + 32 * ps;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int cr = crow[(r * 3 + l) * 8 + k];
-          xr[ps][k] = *reinterpret_cast<const f32x4*>(feats + (size_t)cr * C + lc);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int r = srow + 32 * ps;
-        xr[ps][0] = (p.pts_feat && r < rows && q0 + r < n_q)
-                        ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
-                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 8; ++k) {
+        const int cr = crow[fused_corner_index(r, l, k)];
+        xr[ps][k] = *reinterpret_cast<const f32x4*>(feats + (size_t)cr * C + lc);
       }
     }
   };
-  auto commit_x = [&](int kc) __attribute__((always_inline)) {
+  auto issue_feat = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int r = srow + 32 * ps;
+      xf[ps] = (r < rows && q0 + r < n_q)
+                   ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
+                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // split one staging row's 4 channels and commit them to the staging tile the MFMAs read
+  auto commit_row = [&](int kc, int r, const float (&v)[4]) __attribute__((always_inline)) {
+#ifdef V3D_FUSED_DEBUG
+    if (p.dbg_x && r < rows && q0 + r < n_q)
+      *reinterpret_cast<f32x4*>(p.dbg_x + (size_t)(q0 + r) * (p.nkc1 * 32) + kc * 32 + sc4) = (f32x4){v[0], v[1], v[2], v[3]};
+#endif
+    u32x2 hi, lo;
+    fused_split4(v, hi, lo);
+    const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+    const int slot = kg ^ (((r >> 3) & 1) * 3);
+    u32x2* x2 = reinterpret_cast<u32x2*>(xq);
+    x2[(r * 4 + slot) * 2 + half] = hi;
+    x2[((kFRT + r) * 4 + slot) * 2 + half] = lo;
+  };
+  auto commit_lv = [&](int kc) __attribute__((always_inline)) {
     const int l = level_of(kc);
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int r = srow + 32 * ps;
-      float v[4];
-      if (l < 3) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
-          const float w = cw[(r * 3 + l) * 8 + k];
-          a = __builtin_elementwise_fma(xr[ps][k], (f32x4){w, w, w, w}, a);
-        }
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-      } else {
-        v[0] = xr[ps][0].x; v[1] = xr[ps][0].y; v[2] = xr[ps][0].z; v[3] = xr[ps][0].w;
+      for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
+        const float w = cw[fused_corner_index(r, l, k)];
+        a = __builtin_elementwise_fma(xr[ps][k], (f32x4){w, w, w, w}, a);
       }
-      u32x2 hi, lo;
-      fused_split4(v, hi, lo);
-      const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
-      const int slot = kg ^ (((r >> 3) & 1) * 3);
-      u32x2* x2 = reinterpret_cast<u32x2*>(xq);
-      x2[(r * 4 + slot) * 2 + half] = hi;
-      x2[((kFRT + r) * 4 + slot) * 2 + half] = lo;
+      const float v[4] = {a.x, a.y, a.z, a.w};
+      commit_row(kc, r, v);
+    }
+  };
+  auto commit_feat = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const float v[4] = {xf[ps].x, xf[ps].y, xf[ps].z, xf[ps].w};
+      commit_row(kc, srow + 32 * ps, v);
     }
   };
 
@@ -276,6 +319,10 @@ __global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
       for (int m = 0; m < kFMBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   auto mfma_block = [&](const bf16x8 b_hi, const bf16x8 b_lo, int nb) __attribute__((always_inline)) {
+#ifdef V3D_FUSED_NOMFMA      // developer experiment: B fragments are read, no matrix instruction is issued
+    asm volatile("" : : "v"(b_hi), "v"(b_lo));
+    return;
+#endif
 #pragma unroll
     for (int m = 0; m < kFMBW; ++m) {
       const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a_cur[m]), a_lo = __builtin_bit_cast(bf16x8, a_cur[kFMBW + m]);
@@ -306,16 +353,9 @@ __global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
     }
   };
 
-  zero_acc();
-  __syncthreads();                         // corner table ready
-  issue_x(0);
-  load_a(a_cur, p.w[0], p.nkc1, 0, 0);
-#pragma unroll 1
-  for (int kc = 0; kc < p.nkc1; ++kc) {
-    __syncthreads();                       // the previous chunk's MFMAs are done with the staging tile
-    commit_x(kc);
-    __syncthreads();
-    if (kc + 1 < p.nkc1) issue_x(kc + 1);
+  // the three taps of chunk kc: MFMAs on the staging tile, A fragments one tap ahead (the last tap fetches the next chunk's /
+  // the next layer's first fragments)
+  auto mfma_chunk = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t < 2) load_a(a_nxt, p.w[0], p.nkc1, t + 1, kc);
@@ -331,6 +371,28 @@ __global__ __launch_bounds__(256, 1) void decoder_fused_kernel(FusedParams p) {
 #pragma unroll
       for (int m = 0; m < 2 * kFMBW; ++m) a_cur[m] = a_nxt[m];
     }
+  };
+
+  zero_acc();
+  __syncthreads();                         // corner table ready
+  issue_lv(0);
+  load_a(a_cur, p.w[0], p.nkc1, 0, 0);
+#pragma unroll 1
+  for (int kc = 0; kc < nkc_lv; ++kc) {
+    __syncthreads();                       // the previous chunk's MFMAs are done with the staging tile
+    commit_lv(kc);
+    __syncthreads();
+    if (kc + 1 < nkc_lv) issue_lv(kc + 1);          // the next chunk's gathers fly during this chunk's MFMAs
+    else if (nkc_lv < p.nkc1) issue_feat(nkc_lv);
+    mfma_chunk(kc);
+  }
+#pragma unroll 1
+  for (int kc = nkc_lv; kc < p.nkc1; ++kc) {
+    __syncthreads();
+    commit_feat(kc);
+    __syncthreads();
+    if (kc + 1 < p.nkc1) issue_feat(kc + 1);
+    mfma_chunk(kc);
   }
   store_act(actA, p.bias[0]);
   __syncthreads();        // act1 complete; staging tile / corner table (aliasing the second buffer) no longer needed
@@ -442,6 +504,13 @@ extern "C" int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int 
   return V3D_OK;
 }
 
+#ifdef V3D_FUSED_DEBUG
+static float* g_fused_dbg_x = nullptr;
+static unsigned* g_fused_dbg_wg = nullptr;
+extern "C" void v3d_debug_fused_dump(float* x) { g_fused_dbg_x = x; }
+extern "C" void v3d_debug_fused_dump_wg(unsigned* x) { g_fused_dbg_wg = x; }
+#endif
+
 extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const float* head_weight,
                                      const float* head_bias, const void* const* level_table_host,
                                      const int* level_n_host, const float* const* level_feats_host,
@@ -482,17 +551,24 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   p.pts = pts; p.pts_batch = (const long long*)pts_batch; p.pts_feat = pts_feat; p.c_feat = c_feat;
   p.n_pts = n_pts; p.n_hyp = n_hyp;
   p.head_w = head_weight; p.head_b = head_bias; p.vals = offset_vals; p.preds = preds; p.expect = expect;
+#ifdef V3D_FUSED_DEBUG
+  p.dbg_x = g_fused_dbg_x;
+  p.dbg_wg = g_fused_dbg_wg;
+#endif
   if (n_pts == 0) return V3D_OK;
   hipStream_t s = (hipStream_t)stream;
+  // developer switch (scripts/micro/fused_decoder_stress.py): dynamic LDS request in KB
+  static const size_t lds_bytes = getenv("V3D_FUSED_LDS_KB") ? (size_t)atoi(getenv("V3D_FUSED_LDS_KB")) * 1024 : kFLdsBytes;
+  V3D_REQUIRE(lds_bytes >= kFUsedLdsBytes && lds_bytes <= 160 * 1024, V3D_ERR_BAD_ARG, "V3D_FUSED_LDS_KB out of range");
   static bool attr_set = false;
   if (!attr_set) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)kFLdsBytes));
+                                      (int)lds_bytes));
     attr_set = true;
   }
   {
     v3d::TimedScope ts("decoder_fused", s);
-    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, 256, kFLdsBytes, s>>>(p);
+    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, 256, lds_bytes, s>>>(p);
   }
   V3D_CHECK_LAUNCH("decoder_fused_kernel");
   return V3D_OK;

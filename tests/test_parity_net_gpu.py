@@ -256,12 +256,12 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         dec.load_state_dict(syn.decoder_weights(in_dim=in_dim, h_dim=128, seed=seed, sharpen=float(g['sharpen'])),
                             strict=False)
         dec = dec.to(cuda)
-        dec.fused = True                                        # opt-in path (off by default: slower than the chain)
+        assert dec.fused                                        # the default since round 3
         pf = None if in_dim == 320 else torch.rand((667, 7, 32), generator=torch.Generator().manual_seed(1)).to(cuda) * 0.1
         assert dec.can_fuse(xs, pts, pf)
         p_f, e_f = dec.decode_fused(xs, pts, pf, pts_batch, vals)
         p_f2, _ = dec.decode_fused(xs, pts, pf, pts_batch, vals)
-        assert torch.equal(p_f, p_f2)                           # deterministic (one workgroup per CU, see decoder.hip)
+        assert torch.equal(p_f, p_f2)                           # deterministic (see the repeated-launch test below)
         p_u, e_u = dec.decode(dec.features(xs, pts, pf, pts_batch), vals)
         torch.cuda.synchronize()
         assert float(p_u.max()) > 0.5                      # peaked softmax: the comparison is not vacuous
@@ -269,9 +269,52 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         np.testing.assert_allclose(e_f.cpu().numpy(), e_u.cpu().numpy(), rtol=0, atol=2e-5)
         if in_dim == 320:
             np.testing.assert_allclose(p_f.cpu().numpy(), g['preds'][:667], rtol=0, atol=2e-4)
+        assert torch.equal(dec(xs, pts, pf, pts_batch), p_f)   # forward() takes the fused kernel by default
         dec.fused = False
         assert not dec.can_fuse(xs, pts, pf)
         assert torch.equal(dec(xs, pts, pf, pts_batch), p_u)
+
+
+def test_fused_decoder_is_deterministic_at_two_workgroups_per_cu(cuda):
+    """Round 2 shipped the fused decoder behind a 96 KB LDS request because results changed from launch to launch with two
+    workgroups per CU.  Round 3 traced that to vectorised (ds_read_b128) reads of the LDS corner table under co-resident
+    matrix instructions and keeps those reads scalar (decoder.hip, kFLdsBytes); the kernel now requests 80 KB = two workgroups
+    per CU.  Here: a 6-view cfg3-shaped scene (18 816 query points = 2 352 workgroups, > 4 per CU), 60 launches while a GEMM
+    runs on a second stream: every launch bit-identical to the first and within 2e-6 of the unfused chain."""
+    syn, lm = v3d('synthetic'), v3d('lightningmodel')
+    cfg = syn.CONFIGS['cfg3']
+    n_ref, k = 6, 2
+    edges, n_img = syn.make_edges(n_ref, k, k)
+    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=5)
+    feat = syn.make_features(n_img, 32, *cfg['feat_size'], seed=5).to(cuda)
+    depth = syn.ray_box_depth(rot[k:k + n_ref], tv[k:k + n_ref], K[k:k + n_ref], cfg['img_size'], (56, 56))
+    depth = (depth + 0.02 * torch.randn(depth.shape, generator=torch.Generator().manual_seed(1))).to(cuda)
+    rot, tv, K, edges = rot.to(cuda), tv.to(cuda), K.to(cuda), edges.to(cuda)
+    db = torch.zeros(n_ref, dtype=torch.long, device=cuda)
+    net = lm.PL3DVNet(None, {'size': (56, 56)}, 0.04, feat_dim=32, img_size=cfg['img_size']).eval()
+    net.pointnet.load_state_dict(syn.pointnet_weights())
+    net.sparse_conv.load_state_dict(syn.sparse_unet_weights())
+    net.decoder.load_state_dict(syn.decoder_weights(sharpen=50.0), strict=False)
+    net = net.to(cuda)
+    with torch.no_grad():
+        xs = net.model_scene(depth, db, feat, rot, tv, K, edges)
+        pts_hyp, pts_feat = lm.backproject_variance(depth, feat, rot, tv, K, edges, cfg['img_size'], offset=0.05, n=3)
+        pb = db.unsqueeze(1).expand(n_ref, 3136).reshape(-1)
+        vals = torch.linspace(-0.15, 0.15, 7).to(cuda)
+        assert net.decoder.can_fuse(xs, pts_hyp, pts_feat)
+        p_u, e_u = net.decoder.decode(net.decoder.features(xs, pts_hyp, pts_feat, pb), vals)
+        side = torch.cuda.Stream()
+        junk = torch.randn(2048, 2048, device=cuda)
+        first = None
+        for i in range(60):
+            with torch.cuda.stream(side):
+                junk = (junk @ junk).tanh_()
+            p_f, e_f = net.decoder.decode_fused(xs, pts_hyp, pts_feat, pb, vals)
+            torch.cuda.synchronize()
+            if first is None:
+                first = (p_f.clone(), e_f.clone())
+            assert torch.equal(p_f, first[0]) and torch.equal(e_f, first[1]), 'launch %d differs from launch 0' % i
+        assert float((first[0] - p_u).abs().max()) < 2e-6 and float((first[1] - e_u).abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize('case', range(7))
