@@ -5,7 +5,7 @@
 CFG=${1:-cfg2}; REFS=${2:-64}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/profile_$CFG; T=/tmp/v3dprof_$CFG; rm -rf $T; mkdir -p $O $T; cd /tmp
-B="python $R/bench.py --config $CFG --no-cpu-baseline"
+B="python $R/bench.py --config $CFG --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats -d $T/kt -o r -- $B --steps 10 --warmup 2 > $O/bench_under_rocprof.log 2>&1
 python $R/profiles/summarize_rocpd.py stats $T/kt/r_results.db $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
