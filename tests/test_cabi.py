@@ -37,7 +37,8 @@ def test_host_side_argument_validation():
     lib = lib_mod.load()
     # zero-bordered channel-last copy of the features ((Hf + 2) x (Wf + 2) cells per image + a zero row of Wf + 3 cells behind
     # the last one) + one 36-float camera block per image, each 256-byte aligned
-    assert lib.v3d_psv_workspace_bytes(8, 32, 64, 80) == (8 * 66 * 82 + 83) * 32 * 4 + 128 + 1280      # 128 = padding to the next 256-byte boundary
+    # bordered maps + the zero tail (two bordered rows + 16 cells: the window kernel copies whole 8-cell runs) + camera blocks
+    assert lib.v3d_psv_workspace_bytes(8, 32, 64, 80) == (8 * 66 * 82 + 2 * 82 + 16) * 32 * 4 + 1280
     rc = lib.v3d_psv_variance_f32(None, None, None, None, None, None, None, 1, 1, 1, 32, 4, 4, 8, 8,
                                   0.5, 0.05, 8, 8, 8, None, None, 0, None)
     assert rc == -2 and b'null' in lib.v3d_last_error()
