@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 // + softmax (:24,43) -> expected offset (lightningmodel.py:237-241).  The [Nq, 352, 7] feature tensor (30.9 MB per
 // reference view and sweep) and the three [Nq*7, 128] activations never reach HBM.
 //
-// One 256-thread workgroup = kFPts query points = kFPts * n_hyp (<= 64) GEMM columns; whole hypothesis groups, so no conv
+// One workgroup (4 waves) = kFPts = 8 query points = kFPts * n_hyp (<= 64) GEMM columns; whole hypothesis groups, so no conv
 // tap crosses the tile.  Layer 1 consumes its 352 input channels in 32-wide chunks that are PRODUCED on the fly: every
 // thread blends the 8 corner rows (hash-probed once per tile into an LDS corner table) of its (row, 4 channels) and commits
 // the split-bf16 values to the staging tile the MFMAs read; the next chunk's gathers are in flight during the MFMAs of the
@@ -83,12 +83,19 @@ typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kFPts = 8;            // query points per workgroup
-constexpr int kFRows = 64;          // MFMA columns per workgroup (kFPts * n_hyp <= 64)
-constexpr int kFZero = 64;               // index of the all-zero activation row (conv padding)
+#ifndef V3D_FUSED_PTS
+#define V3D_FUSED_PTS 8
+#endif
+constexpr int kFPts = V3D_FUSED_PTS;          // query points per workgroup: 8 (4 waves, two workgroups per CU; 3.0 ms per 64-view
+                                              // sweep) or 16 (8 waves, one per CU: 3.6 ms -- the barriers span twice the waves)
+constexpr int kFRows = kFPts * 8;             // MFMA columns per workgroup (kFPts * n_hyp <= kFRows)
+constexpr int kFWaves = kFRows / 16;          // waves per workgroup: wave = (row quarter, column half): 32 channels x 64 columns each
+constexpr int kFThreads = 64 * kFWaves;
+constexpr int kFNBT = kFRows / 16;            // column blocks of the workgroup
+constexpr int kFZero = kFRows;           // index of the all-zero activation row (conv padding)
 constexpr int kFRT = kFZero + 1;         // rows per LDS activation array
 constexpr int kFH = 128;            // hidden width of the decoder
-constexpr int kFNB = kFRows / 16, kFMBW = 2, kFMB = 4 * kFMBW;
+constexpr int kFNB = 4, kFMBW = 2, kFMB = 4 * kFMBW;      // per wave: 4 column blocks x 2 row blocks
 constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap, K chunk) of a layer's weight image
 constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
 constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
@@ -110,8 +117,8 @@ constexpr size_t kFUsedLdsBytes = 2 * kFActBytes;
 // (keeping the row-major table and reading it through volatile pointers also works, but every volatile access carries a full
 // s_waitcnt, which serialises the gathers: 3.7 instead of 3.1 ms per sweep).  The GPU suite runs the repeated-launch
 // determinism check at this occupancy.
-constexpr size_t kFLdsBytes = 80 * 1024;
-__device__ __forceinline__ int fused_corner_index(int r, int l, int corner) { return (corner * 3 + l) * 64 + r; }
+constexpr size_t kFLdsBytes = kFPts == 8 ? 80 * 1024 : kFUsedLdsBytes;      // 8 points: two workgroups per CU; 16: one (132 KB)
+__device__ __forceinline__ int fused_corner_index(int r, int l, int corner) { return (corner * 3 + l) * kFRows + r; }
 static_assert(kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "staging tile + corner table alias the second buffer");
 static_assert((size_t)kFRows * kFH * 4 <= kFActBytes, "fp32 output of the last layer aliases the first buffer");
 
@@ -157,7 +164,7 @@ __device__ __forceinline__ void fused_split4(const float (&v)[4], u32x2& hi, u32
 #ifndef V3D_FUSED_LB
 #define V3D_FUSED_LB 1
 #endif
-__global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedParams p) {
+__global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const actA = reinterpret_cast<u32x4*>(smem);                               // [2][kFRT][16]
   u32x4* const actB = reinterpret_cast<u32x4*>(smem + kFActBytes);                  // [2][kFRT][16]
@@ -166,7 +173,9 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
   float* const cw = reinterpret_cast<float*>(crow + kFRows * 24);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_id & 3;            // row quarter: output channels 32 wave .. 32 wave + 31
+  const int cb0 = (wave_id >> 2) * kFNB;   // first of this wave's 4 column blocks
   const int kq = lane >> 4, jn = lane & 15;
   const int pt0 = blockIdx.x * kFPts;
   const int n_hyp = p.n_hyp, rows = kFPts * n_hyp;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
 #pragma unroll
   for (int l = 0; l < 3; ++l) {
     const FusedLevel L = p.lv[l];
-    for (int j = tid; j < kFRows * 8; j += 256) {
+    for (int j = tid; j < kFRows * 8; j += kFThreads) {
       const int r = j >> 3, corner = j & 7;
       int row = -1;
       float w = 0.f;
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
     const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + 32 * ps;
+      const int r = srow + (kFRows / 2) * ps;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int cr = crow[fused_corner_index(r, l, k)];
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
   auto issue_feat = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + 32 * ps;
+      const int r = srow + (kFRows / 2) * ps;
       xf[ps] = (r < rows && q0 + r < n_q)
                    ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
                    : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
     const int l = level_of(kc);
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + 32 * ps;
+      const int r = srow + (kFRows / 2) * ps;
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const float v[4] = {xf[ps].x, xf[ps].y, xf[ps].z, xf[ps].w};
-      commit_row(kc, srow + 32 * ps, v);
+      commit_row(kc, srow + (kFRows / 2) * ps, v);
     }
   };
 
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
   unsigned tapmask = 0;
 #pragma unroll
   for (int nb = 0; nb < kFNB; ++nb) {
-    const int hh = (nb * 16 + jn) % n_hyp;
+    const int hh = ((cb0 + nb) * 16 + jn) % n_hyp;
     tapmask |= (hh >= 1 ? 1u : 0u) << (2 * nb);
     tapmask |= (hh + 1 < n_hyp ? 1u : 0u) << (2 * nb + 1);
   }
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
     u32x2* d2 = reinterpret_cast<u32x2*>(dst);
 #pragma unroll
     for (int nb = 0; nb < kFNB; ++nb) {
-      const int r = nb * 16 + jn;
+      const int r = (cb0 + nb) * 16 + jn;
 #pragma unroll
       for (int mw = 0; mw < kFMBW; ++mw) {
         const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
 #pragma unroll
       for (int nb = 0; nb < kFNB; ++nb) {
         const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
-        const int R = inside ? nb * 16 + jn + t - 1 : kFZero;
+        const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
         const int slot = R * 4 + (kq ^ (((R >> 3) & 1) * 3));
         mfma_block(__builtin_bit_cast(bf16x8, xq[slot]), __builtin_bit_cast(bf16x8, xq[kFRT * 4 + slot]), nb);
       }
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
 #pragma unroll
         for (int nb = 0; nb < kFNB; ++nb) {
           const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
-          const int R = inside ? nb * 16 + jn + t - 1 : kFZero;
+          const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
           const int slot = R * 16 + ((kc * 4 + kq) ^ (R & 15));
           mfma_block(__builtin_bit_cast(bf16x8, src[slot]), __builtin_bit_cast(bf16x8, src[kFRT * 16 + slot]), nb);
         }
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256, V3D_FUSED_LB) void decoder_fused_kernel(FusedP
           f32x4 v;
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + p.bias[2][co0 + k], 0.f);
-          *reinterpret_cast<f32x4*>(of + (nb * 16 + jn) * kFH + co0) = v;
+          *reinterpret_cast<f32x4*>(of + ((cb0 + nb) * 16 + jn) * kFH + co0) = v;
         }
     }
     __syncthreads();
@@ -568,7 +577,7 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   }
   {
     v3d::TimedScope ts("decoder_fused", s);
-    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, 256, lds_bytes, s>>>(p);
+    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, kFThreads, lds_bytes, s>>>(p);
   }
   V3D_CHECK_LAUNCH("decoder_fused_kernel");
   return V3D_OK;

@@ -658,6 +658,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
 // featT as the reuse kernel does, inside the same step.  Arithmetic and accumulation order are those of the other two
 // kernels: bit-identical output.
 constexpr int kWinCols = 16, kWinRows = 4;                 // window: 16 x 4 cells x 128 B = 8 KB per wave
+typedef float psv_f32x2 __attribute__((ext_vector_type(2)));
 
 // scalar min / max of wave-uniform values (the compiler picks v_min3 / v_max3 + v_readfirstlane for these otherwise)
 __device__ __forceinline__ int psv_smin(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
@@ -742,7 +743,16 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     f32x4 sv_ = t00 * (w_)[0];                                                                       \
     sv_ = __builtin_elementwise_fma(t01, (f32x4){(w_)[1], (w_)[1], (w_)[1], (w_)[1]}, sv_);          \
     sv_ = __builtin_elementwise_fma(t10, (f32x4){(w_)[2], (w_)[2], (w_)[2], (w_)[2]}, sv_);          \
-    sv_ = __builtin_elementwise_fma(t11, (f32x4){(w_)[3], (w_)[3], (w_)[3], (w_)[3]}, sv_);          \
+    /* fourth tap: hipcc copies w[3] into the low half of a register pair first (one v_mov per plane); written by hand  \
+       the packed FMA takes the HIGH half of the (w[2], w[3]) pair for both result lanes (op_sel) -- same arithmetic */ \
+    {                                                                                                \
+      psv_f32x2 lo_ = {sv_[0], sv_[1]}, hi_ = {sv_[2], sv_[3]};                                      \
+      const psv_f32x2 w23_ = {(w_)[2], (w_)[3]};                                                     \
+      const psv_f32x2 tl_ = {t11[0], t11[1]}, th_ = {t11[2], t11[3]};                                \
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(lo_) : "v"(tl_), "v"(w23_));  \
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(hi_) : "v"(th_), "v"(w23_));  \
+      sv_ = (f32x4){lo_[0], lo_[1], hi_[0], hi_[1]};                                                 \
+    }                                                                                                \
     acc_s[pl_] += sv_;                                                                               \
     acc_q[pl_] = __builtin_elementwise_fma(sv_, sv_, acc_q[pl_]);                                    \
     /* finish this plane before the next one starts (see the reuse kernel) */                        \

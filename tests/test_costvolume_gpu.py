@@ -229,21 +229,24 @@ def test_psv_ragged_edges_and_odd_grid(D, cuda):
 
 
 def test_psv_kernel_variants_bit_identical(cuda):
-    """The default plane-reuse warp kernel (footprints kept in registers, reciprocal-based uniform divisions) and the
-    plain gather kernel (V3D_PSV_GATHER=1, IEEE divisions) must produce the same bits: the switch is read once per
-    process, so each variant hashes a few seeded volumes in its own interpreter (scripts/psv_hash.py)."""
+    """The three warp kernels -- window (default: LDS-staged footprint windows), reuse (V3D_PSV_REUSE=1: footprints in
+    registers, masked gathers) and the plain gather kernel (V3D_PSV_GATHER=1, IEEE divisions) -- must produce the same bits,
+    also for camera pairs whose footprints do not fit the window (zoomed / rolled / far-off sources: the out-of-window path),
+    partial tiles, 13 planes, 7 edges (division path of the mean), fp32 and split output.  The switches are read once per
+    process, so each variant hashes the volumes in its own interpreter (scripts/psv_hash.py)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra in ({}, {'V3D_PSV_GATHER': '1'}):
+    for extra in ({}, {'V3D_PSV_REUSE': '1'}, {'V3D_PSV_GATHER': '1'}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'psv_hash.py')], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(('cfg', '7-edge'))])
-    assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(('cfg', '7-edge', 'exotic'))])
+    assert len(outs[0]) == 6 and outs[0] == outs[1] == outs[2], outs
+    assert 'nan' not in ' '.join(outs[0])
 
 
 def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
