@@ -78,6 +78,9 @@ SIGNATURES = {
     'v3d_edges_csr_workspace_bytes': (c_size_t, [c_int, c_int]),
     'v3d_edges_csr': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'v3d_edges_csr_status': (c_int, [c_void_p, c_size_t, c_void_p]),
+    'v3d_segment_csr_workspace_bytes': (c_size_t, [c_int]),
+    'v3d_segment_csr': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_segment_max_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'v3d_sort_unique_workspace_bytes': (c_size_t, [c_int]),
     'v3d_sort_unique_u64': (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p, c_size_t, c_void_p]),
     'v3d_strided_keys': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .mvsnet import _Workspace
 
 _NEG_INF = float('-inf')
 
@@ -116,6 +117,7 @@ class PointNet(nn.Module):
         self.fc4 = nn.Linear(2 * hidden_dim, hidden_dim)
         self.fc_out = nn.Linear(hidden_dim, out_dim)
         self._cache = _PackCache(self)
+        self._ws = _Workspace()
 
     def _build(self):
         def lin(m, n_seg):
@@ -136,20 +138,28 @@ class PointNet(nn.Module):
         idx32 = idx.to(torch.int32).contiguous()
         stream = _lib.stream_ptr(dev)
 
-        def new_pool():
+        # Max-pool over the points of a voxel (scatter(x, idx, reduce='max'), :131,135,139): the rows are grouped by voxel once
+        # (device radix sort -> row list + offsets), each layer's stored output is then reduced per voxel by
+        # v3d_segment_max_f32 -- no atomics (the gather-GEMM's fused scatter-max was 80 % of a layer's time; csrc/segment.hip).
+        perm = torch.empty(Np, dtype=torch.int32, device=dev)
+        offs = torch.empty(n_idx + 1, dtype=torch.int32, device=dev)
+        wb = lib.v3d_segment_csr_workspace_bytes(Np)
+        ws = self._ws.get('segcsr', wb, dev)
+        _lib.check(lib.v3d_segment_csr(idx32.data_ptr(), Np, int(n_idx), perm.data_ptr(), offs.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), stream), 'v3d_segment_csr')
+
+        def pooled(x):
             pool = torch.empty((n_idx, H), dtype=torch.float32, device=dev)
-            _lib.check(lib.v3d_fill_f32(pool.data_ptr(), pool.numel(), _NEG_INF, stream), 'v3d_fill_f32')
+            _lib.check(lib.v3d_segment_max_f32(x.data_ptr(), x.stride(0), perm.data_ptr(), offs.data_ptr(), int(n_idx), H,
+                                               pool.data_ptr(), H, stream), 'v3d_segment_max_f32')
             return pool
 
         h = g['fc_pos'](Np, [pts], precision=pr)                              # fc_pos(pts)
-        pool = new_pool()
-        x = g['fc1'](Np, [h], relu_in=True, pool=pool, pool_idx=idx32, precision=pr)   # fc1(relu(.)) + max-pool
+        x = g['fc1'](Np, [h], relu_in=True, precision=pr)                     # fc1(relu(.))
+        pool = pooled(x)
         for name in ('fc2', 'fc3', 'fc4'):
-            nxt = new_pool()
-            last = name == 'fc4'
-            x = g[name](Np, [x, pool], idxs=[None, idx32], relu_in=True, pool=nxt, pool_idx=idx32,
-                        out=None if last else True, precision=pr)             # fcK(relu(cat(x, pool[idx])))
-            pool = nxt
+            x = g[name](Np, [x, pool], idxs=[None, idx32], relu_in=True, precision=pr)   # fcK(relu(cat(x, pool[idx])))
+            pool = pooled(x)
         return g['fc_out'](n_idx, [pool], relu_in=True, precision=pr)
 
 

@@ -262,6 +262,15 @@ int v3d_sparse_interp_f32(const void* table, int n_in, const float* feats, int C
  *                        `workspace` must be the buffer v3d_voxel_keys filled; half_edge = edge_len / 2
  *   v3d_strided_keys / v3d_unpack_coords   packed keys of floor(c / 2ts) * 2ts and back to int32 [n,4]
  * ------------------------------------------------------------------------------------------ */
+/* Row B4's max-pooling over the points of a voxel (scenemodeling.py:129-141, torch_scatter.scatter(reduce='max')) without
+ * atomics: v3d_segment_csr groups the rows by segment id once (perm [n]: row indices sorted by id, stable; offsets [n_seg+1]),
+ * v3d_segment_max_f32 reduces every segment's rows of src [n, ld] to out [n_seg, ld_out] (first N columns; an empty segment
+ * yields -inf, the initial value of the atomic version's pool).  Ids must lie in [0, n_seg). */
+size_t v3d_segment_csr_workspace_bytes(int n);
+int v3d_segment_csr(const int32_t* seg_id, int n, int n_seg, int32_t* perm, int32_t* offsets, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int v3d_segment_max_f32(const float* src, int ld, const int32_t* perm, const int32_t* offsets, int n_seg, int N, float* out,
+                        int ld_out, void* stream);
 size_t v3d_sort_unique_workspace_bytes(int n);
 int v3d_sort_unique_u64(const uint64_t* keys_in, int n, uint64_t* keys_out, int* n_unique_host,
                         void* workspace, size_t workspace_bytes, void* stream);

@@ -468,3 +468,35 @@ def test_cost_volume_graph_survives_workspace_growth_and_refuses_stale_weights(c
         e = b.ref_src_edges.clone()
         e[0] = e[0, 0]                                                   # one reference image instead of three
         g2.update(ref_src_edges=e)
+
+
+@pytest.mark.parametrize('n,n_seg,N', [(1000, 37, 128), (20000, 3000, 128), (513, 600, 64), (4097, 5, 256)])
+def test_segment_csr_and_max_equal_scatter_amax(n, n_seg, N, cuda):
+    """v3d_segment_csr + v3d_segment_max_f32 (PointNet's max-pool without atomics) against torch's scatter amax: the row list
+    is the stable sort of the rows by segment id, the offsets delimit every segment (empty ones included), the pooled rows
+    are bit-identical (max is order independent) and empty segments stay at -inf."""
+    libm = v3d('_lib')
+    lib = libm.load()
+    gen = torch.Generator().manual_seed(n)
+    seg = torch.randint(0, n_seg, (n,), generator=gen).int()
+    if n_seg > 3:
+        seg[seg == 2] = 1                                         # segment 2 is empty
+    x = torch.randn((n, N + 4), generator=gen)                    # row stride > N
+    segd, xd = seg.to(cuda), x.to(cuda)
+    perm = torch.empty(n, dtype=torch.int32, device=cuda)
+    offs = torch.empty(n_seg + 1, dtype=torch.int32, device=cuda)
+    ws = torch.empty(lib.v3d_segment_csr_workspace_bytes(n), dtype=torch.uint8, device=cuda)
+    st = libm.stream_ptr(cuda)
+    libm.check(lib.v3d_segment_csr(segd.data_ptr(), n, n_seg, perm.data_ptr(), offs.data_ptr(), ws.data_ptr(), ws.numel(), st),
+               'v3d_segment_csr')
+    order = torch.sort(seg.long(), stable=True).indices
+    assert torch.equal(perm.cpu().long(), order)
+    counts = torch.bincount(seg.long(), minlength=n_seg)
+    assert torch.equal(offs.cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0))))
+    out = torch.full((n_seg, N), 7.0, device=cuda)
+    libm.check(lib.v3d_segment_max_f32(xd.data_ptr(), xd.stride(0), perm.data_ptr(), offs.data_ptr(), n_seg, N,
+                                       out.data_ptr(), N, st), 'v3d_segment_max_f32')
+    ref = torch.full((n_seg, N), float('-inf')).scatter_reduce_(0, seg.long().view(-1, 1).expand(-1, N), x[:, :N], 'amax')
+    assert torch.equal(out.cpu(), ref)
+    if n_seg > 3:
+        assert bool(torch.isinf(out[2]).all())
