@@ -107,6 +107,7 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                        batch.rotmats[idx_start:idx_end], batch.tvecs[idx_start:idx_end],
                        batch.K[idx_start:idx_end], None, edges)
             sl.images_batch = torch.zeros(idx_end - idx_start, dtype=torch.long)
+            sl.n_ref = c1 - c0               # every image in [c0 + k, c1 + k) is a reference view of this chunk
             if has_feats:
                 sl.features_quarter = batch.features_quarter[idx_start:idx_end]
                 if getattr(batch, 'features_half', None) is not None:

@@ -88,11 +88,17 @@ class PL3DVNet(nn.Module):
 
     def make_initial_depth_predictions(self, batch, depth_config):
         """lightningmodel.py:124-130."""
+        # `batch.n_ref` (optional, set by the scene driver, which knows how many reference views a chunk holds): the edge
+        # tables are then built on the device and torch.unique -- a host synchronisation -- is not needed twice per chunk
+        n_ref = getattr(batch, 'n_ref', None)
         depth_pred, feats_half, feats_quarter, features_eighth = self.mvsnet(
             batch, depth_config['depth_start'], depth_config['depth_interval'], depth_config['n_intervals'],
-            depth_config['size'])
-        ref_idx = torch.unique(batch.ref_src_edges[0])
-        depth_batch = batch.images_batch[ref_idx]
+            depth_config['size'], n_ref=n_ref)
+        if n_ref is not None and self.mvsnet.last_csr is not None:
+            ref_idx = self.mvsnet.last_csr[0]                    # ascending distinct reference images = torch.unique's output
+        else:
+            ref_idx = torch.unique(batch.ref_src_edges[0])
+        depth_batch = batch.images_batch.to(ref_idx.device)[ref_idx]
         return depth_pred, depth_batch, feats_half, feats_quarter, features_eighth, ref_idx
 
     def construct_feature_rich_pointcloud(self, depth_pred, depth_batch, img_feats, rotmats, tvecs, K,

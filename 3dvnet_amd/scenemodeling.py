@@ -4,7 +4,8 @@ structures and ``state_dict`` keys (MinkowskiEngine parameter naming: ``.kernel`
 MinkowskiEngine is replaced by hash-indexed neighbour tables + the matrix-core gather-GEMM of
 ``lib3dvnet_hip.so`` (csrc/sparse.hip, csrc/gemm_gather.hip; fp32 storage and accumulation, MFMA operands per
 the module's ``precision``: 'split_bf16' = three bf16 products per fp32 product (default), 'fp32' = exact-fp32
-MFMA); torch_scatter's max is fused into the GEMM epilogue.  No CPU fallback.
+MFMA); torch_scatter's max is a per-voxel segment reduction (csrc/segment.hip; the GEMM epilogue's fused
+scatter-max remains available through ``PackedGemm(pool=...)``).  No CPU fallback.
 """
 import ctypes
 
@@ -340,14 +341,17 @@ class SparseUNet(nn.Module):
         n_batches = int(torch.max(batch).item()) + 1                                   # scenemodeling.py:221
         for lv in levels:       # the host is synchronised here anyway: surface rows the hash tables refused (range check)
             lv.check()
+        # scenemodeling.py:222-231 per batch element b: pts_min = pts[batch == b][0] - idx[batch == b][0] * res and
+        # x_pts = x_idx * res + pts_min -- the same numbers without a boolean-mask gather (and its host synchronisation) per
+        # level and batch element: the first row of every batch element by a scatter-min of the row index
+        rows = torch.arange(batch.shape[0], device=batch.device)
+        first = torch.full((n_batches,), batch.shape[0], dtype=rows.dtype, device=batch.device) \
+            .scatter_reduce_(0, batch.to(rows.dtype), rows, 'amin')
+        pts_min = pts[first] - idx[first] * res                                        # [n_batches, 3]
         for lv, xf in out:
             x_idx = lv.coords[:, 1:].type_as(batch)
             x_batch = lv.coords[:, 0].type_as(batch)
-            x_pts = torch.empty((lv.n, 3), dtype=torch.float, device=pts.device)
-            for b in range(n_batches):
-                bin_, bout = batch == b, x_batch == b
-                pts_min = pts[bin_][0] - (idx[bin_][0] * res)
-                x_pts[bout] = x_idx[bout] * res + pts_min
+            x_pts = x_idx * res + pts_min[x_batch]
             lv.feats = xf
             out_info.append({'feats': xf, 'pts': x_pts, 'res': lv.stride * res, 'batch': x_batch,
                              'idx': x_idx, 'stride': lv.stride, 'sparse': lv})
