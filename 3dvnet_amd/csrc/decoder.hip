@@ -2,6 +2,7 @@
 // along the hypothesis axis, softmax over the hypotheses (refinement.py:24,43) and, optionally, the
 // expected depth offset sum_i p_i * vals_i (lightningmodel.py:238-241).  One wave per point.
 #include <cstdlib>
+#include <vector>
 
 #include "gemm_weights.h"
 #include "sparse_hash.h"
@@ -89,17 +90,23 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kFPts = V3D_FUSED_PTS;          // query points per workgroup: 8 (4 waves, two workgroups per CU; 3.0 ms per 64-view
                                               // sweep) or 16 (8 waves, one per CU: 3.6 ms -- the barriers span twice the waves)
 constexpr int kFRows = kFPts * 8;             // MFMA columns per workgroup (kFPts * n_hyp <= kFRows)
-constexpr int kFWaves = kFRows / 16;          // waves per workgroup: wave = (row quarter, column half): 32 channels x 64 columns each
+#ifndef V3D_FUSED_NB
+#define V3D_FUSED_NB 4
+#endif
+constexpr int kFNB = V3D_FUSED_NB;            // column blocks (16 columns) per wave: 4, or 2 (twice the waves at half the accumulators)
+constexpr int kFWaves = 4 * (kFRows / 16 / kFNB);   // waves per workgroup: wave = (row quarter, column group): 32 channels x 16 kFNB columns
 constexpr int kFThreads = 64 * kFWaves;
+constexpr int kFStageRows = kFRows * 8 / kFThreads;     // staging rows per thread (8 threads x 4 channels per row and chunk)
 constexpr int kFNBT = kFRows / 16;            // column blocks of the workgroup
 constexpr int kFZero = kFRows;           // index of the all-zero activation row (conv padding)
 constexpr int kFRT = kFZero + 1;         // rows per LDS activation array
 constexpr int kFH = 128;            // hidden width of the decoder
-constexpr int kFNB = 4, kFMBW = 2, kFMB = 4 * kFMBW;      // per wave: 4 column blocks x 2 row blocks
+constexpr int kFMBW = 2, kFMB = 4 * kFMBW;      // per wave: kFNB column blocks x 2 row blocks
 constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap, K chunk) of a layer's weight image
 constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
 constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
-constexpr size_t kFUsedLdsBytes = 2 * kFActBytes;
+constexpr size_t kFConstBytes = (3 * 128 + 128 * 3 + 4) * 4;                // biases of the three layers, head weights, head bias
+constexpr size_t kFUsedLdsBytes = 2 * kFActBytes + kFConstBytes;
 // Requested LDS: 80 KB = two workgroups per CU (two waves per SIMD: the kernel's 186 VGPRs + 50 AGPRs allow exactly that).
 //
 // The round-2 nondeterminism at two workgroups per CU, diagnosed in round 3 (scripts/micro/fused_decoder_stress.py dumps the
@@ -119,7 +126,7 @@ constexpr size_t kFUsedLdsBytes = 2 * kFActBytes;
 // determinism check at this occupancy.
 constexpr size_t kFLdsBytes = kFPts == 8 ? 80 * 1024 : kFUsedLdsBytes;      // 8 points: two workgroups per CU; 16: one (132 KB)
 __device__ __forceinline__ int fused_corner_index(int r, int l, int corner) { return (corner * 3 + l) * kFRows + r; }
-static_assert(kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "staging tile + corner table alias the second buffer");
+static_assert(2 * kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "two staging tiles + corner table alias the second buffer");
 static_assert((size_t)kFRows * kFH * 4 <= kFActBytes, "fp32 output of the last layer aliases the first buffer");
 
 struct FusedLevel {
@@ -162,25 +169,63 @@ __device__ __forceinline__ void fused_split4(const float (&v)[4], u32x2& hi, u32
 }
 
 #ifndef V3D_FUSED_LB
-#define V3D_FUSED_LB 1
+#define V3D_FUSED_LB 2      // two waves per SIMD = two workgroups per CU: the register allocator must stay within 256
+#endif
+#ifdef V3D_PHASE_TIMING
+// developer build only (as in costreg.hip): wave 0 of every workgroup adds up the cycles between marks and writes them to
+// its own slot; phases: 0 corner table, 1 layer-1 commits (two barriers + blend + split), 2 layer-1 matrix phase, 3 activation
+// stores, 4 layer 2, 5 layer 3, 6 head
+constexpr int kFPhaseSlots = 1 << 15;
+__device__ unsigned long long g_fused_phase[8 * kFPhaseSlots];
+#define FPHASE_DECL long long ph_t = __builtin_readcyclecounter(); long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FPHASE_MARK(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
+#define FPHASE_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < kFPhaseSlots) for (int i_ = 0; i_ < 8; ++i_) g_fused_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_]; } while (0)
+#else
+#define FPHASE_DECL
+#define FPHASE_MARK(i)
+#define FPHASE_FLUSH
+#endif
+// -DV3D_PHASE_TIMING=2: the coarse marks collapse into slot 0 and the layer-1 chunk loop is resolved instead: 1 gather issue,
+// 2 / 3 / 4 the three taps, 5 commit (wait for the gathers, blend, split, LDS writes), 6 barrier
+#if defined(V3D_PHASE_TIMING) && V3D_PHASE_TIMING == 2
+#undef FPHASE_MARK
+#define FPHASE_MARK(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[0] += t_ - ph_t; ph_t = t_; } while (0)
+#define FPHASE_FINE(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define FPHASE_FINE(i)
+#endif
+#ifndef V3D_FUSED_ABLATE
+#define V3D_FUSED_ABLATE 0   // developer ablations (scripts/micro/fused_decoder_ablate.sh): 1 no matrix instructions, 2 no feature gathers
+                             // (corner rows read as row 0 ... of a 4 KB window), 3 weight fragments from a 2 KB window, 4 no hash probes,
+                             // 5 layer 1 only, 7 tiles interleaved over the XCDs, 8 a chunk's gathers in one burst
 #endif
 __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const actA = reinterpret_cast<u32x4*>(smem);                               // [2][kFRT][16]
   u32x4* const actB = reinterpret_cast<u32x4*>(smem + kFActBytes);                  // [2][kFRT][16]
-  u32x4* const xq = actB;                                                           // layer 1: [2][kFRT][4]
-  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + kFStageBytes);       // layer 1: [8 corners][3 levels][64 rows]
+  u32x4* const xq = actB;                                                           // layer 1: two staging tiles [2][kFRT][4]
+  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + 2 * kFStageBytes);   // layer 1: [8 corners][3 levels][rows]
   float* const cw = reinterpret_cast<float*>(crow + kFRows * 24);
+  constexpr int kFStageSlots = 2 * kFRT * 4;                                        // 16-byte slots of one staging tile
+  float* const cbias = reinterpret_cast<float*>(smem + 2 * kFActBytes);             // [3][128] folded BatchNorm biases
+  float* const chead = cbias + 3 * kFH;                                             // [128][3] head weights, then the head bias
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  // Per-lane indices.  They are re-derived from an opaque copy of threadIdx.x at the top of every tile (refresh_lane_ids): with
+  // plain loop invariants the compiler hoists every per-lane LDS / global address of every phase out of the tile loop and
+  // keeps them all alive across it (256 VGPRs + 144 AGPRs + scratch instead of ~220 registers).
+  int tid = threadIdx.x, lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave_id & 3;            // row quarter: output channels 32 wave .. 32 wave + 31
   const int cb0 = (wave_id >> 2) * kFNB;   // first of this wave's 4 column blocks
-  const int kq = lane >> 4, jn = lane & 15;
-  const int pt0 = blockIdx.x * kFPts;
+  int kq = lane >> 4, jn = lane & 15;
   const int n_hyp = p.n_hyp, rows = kFPts * n_hyp;
-  const long long q0 = (long long)pt0 * n_hyp;                       // first global (point, hypothesis) row of the tile
   const long long n_q = (long long)p.n_pts * n_hyp;
+  const int n_tiles = (p.n_pts + kFPts - 1) / kFPts;
+  // The workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host launches as many workgroups as the chip holds at
+  // once): everything that does not depend on the tile -- biases, head weights, the weight-fragment ring -- is set up once, and
+  // the corner table of the NEXT tile is looked up while the matrix pipe works on layers 2 and 3 of the current one.
+  int pt0 = 0;
+  long long q0 = 0;                        // first global (point, hypothesis) row of the current tile
 
 #ifdef V3D_FUSED_DEBUG
   if (p.dbg_wg && tid == 0) {
@@ -189,84 +234,177 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
     p.dbg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
   }
 #endif
-  // ---- zero rows; corner table: 8 hash probes per (row, level), as interp_corners_kernel (sparse.hip) -----------------
-  if (tid < 2 * 16) actA[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
-  if (tid < 2 * 4) xq[((tid >> 2) * kFRT + kFZero) * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
+  FPHASE_DECL;
+
+  // ---- corner table: 8 hash probes per (row, level), as interp_corners_kernel (sparse.hip) -------------------------------------
   // (the level index is kept wave-uniform everywhere: a per-lane index into the kernel-argument array p.lv[] makes the
   // compiler build a per-lane scratch copy of it)
+  // A thread owns one corner of kFProbeRows rows on all three levels.  The lookups are four stages of independent loads --
+  // (point, batch) of the rows; the levels' minimum corners; the first slot of every probe sequence, key and value together;
+  // resolve (+ the rare longer probe sequence) -- instead of six hash_find() calls in a row, each a chain of four dependent global
+  // loads.  Measured per workgroup (wave 0, -DV3D_PHASE_TIMING): 36 k of 128 k cycles when the table was built in front of every
+  // tile, whatever the load order -- the chain is latency under a loaded memory system, so the stages of the next tile are spread
+  // over the matrix phases of layers 2 and 3, where the gather registers are free.
+  constexpr int kFProbeRows = kFRows * 8 / kFThreads;
+  int corner = tid & 7;
+  // what survives from one tile to the next: feature row (-1 = absent) and weight of this thread's corner of its rows
+  int ct_row[3][kFProbeRows];
+  float ct_w[3][kFProbeRows];
+  // the lookups in flight: declared per tile (below) so that nothing but ct_row / ct_w is carried around the tile loop
+  struct Probe {
+    bool live[kFProbeRows], ok[3][kFProbeRows];
+    float px[kFProbeRows], py[kFProbeRows], pz[kFProbeRows], mn[3][kFProbeRows][3];
+    int bb[kFProbeRows], found[3][kFProbeRows];
+    unsigned long long key[3][kFProbeRows];
+    unsigned slot[3][kFProbeRows];
+  };
+  auto ct_points = [&](Probe& c, int tile) __attribute__((always_inline)) {
+    const int tp0 = tile * kFPts;
+    const long long tq0 = (long long)tp0 * n_hyp;
 #pragma unroll
-  for (int l = 0; l < 3; ++l) {
-    const FusedLevel L = p.lv[l];
-    for (int j = tid; j < kFRows * 8; j += kFThreads) {
-      const int r = j >> 3, corner = j & 7;
-      int row = -1;
-      float w = 0.f;
-      if (r < rows && q0 + r < n_q) {
-        const long long q = q0 + r;
-        const int b = (int)p.pts_batch[q / n_hyp];
-        const float ts = (float)L.ts;
-        float c0, c1, c2;
-        w = 1.f;
-        {
-          // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
-          const float qx = ((p.pts[(size_t)q * 3 + 0] - L.min_pts[b * 3 + 0]) / L.res) * ts;
-          const float qy = ((p.pts[(size_t)q * 3 + 1] - L.min_pts[b * 3 + 1]) / L.res) * ts;
-          const float qz = ((p.pts[(size_t)q * 3 + 2] - L.min_pts[b * 3 + 2]) / L.res) * ts;
-          c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
-          c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
-          c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
-          w *= 1.f - fabsf(qx - c0) / ts;
-          w *= 1.f - fabsf(qy - c1) / ts;
-          w *= 1.f - fabsf(qz - c2) / ts;
-        }
-        if (c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard && c0 <= 60000.f && c1 <= 60000.f &&
-            c2 <= 60000.f)
-          row = v3dhash::hash_find(L.table, v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2));
-      }
-      // an absent corner (or a padding row) reads feature row 0 with weight 0: the gathers below are unconditional
-      crow[fused_corner_index(r, l, corner)] = row < 0 ? 0 : row;
-      cw[fused_corner_index(r, l, corner)] = row < 0 ? 0.f : w;
+    for (int i = 0; i < kFProbeRows; ++i) {
+      const int r = (tid >> 3) + i * (kFThreads / 8);
+      c.live[i] = r < rows && tq0 + r < n_q;
+      const long long q = c.live[i] ? tq0 + r : tq0;
+      c.px[i] = p.pts[(size_t)q * 3 + 0]; c.py[i] = p.pts[(size_t)q * 3 + 1]; c.pz[i] = p.pts[(size_t)q * 3 + 2];
+      c.bb[i] = (int)p.pts_batch[tp0 + (c.live[i] ? (int)((unsigned)r / (unsigned)n_hyp) : 0)];      // = q / n_hyp
     }
-  }
+  };
+  auto ct_mins = [&](Probe& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int i = 0; i < kFProbeRows; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c.mn[l][i][a] = p.lv[l].min_pts[c.bb[i] * 3 + a];
+  };
+  auto ct_keys = [&](Probe& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const float ts = (float)p.lv[l].ts, res = p.lv[l].res;
+#pragma unroll
+      for (int i = 0; i < kFProbeRows; ++i) {
+        // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
+        const float qx = ((c.px[i] - c.mn[l][i][0]) / res) * ts;
+        const float qy = ((c.py[i] - c.mn[l][i][1]) / res) * ts;
+        const float qz = ((c.pz[i] - c.mn[l][i][2]) / res) * ts;
+        const float c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
+        const float c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
+        const float c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
+        float w = 1.f;
+        w *= 1.f - fabsf(qx - c0) / ts;
+        w *= 1.f - fabsf(qy - c1) / ts;
+        w *= 1.f - fabsf(qz - c2) / ts;
+        ct_w[l][i] = w;
+        c.ok[l][i] = c.live[i] && c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard &&
+                     c0 <= 60000.f && c1 <= 60000.f && c2 <= 60000.f;
+        // (a coordinate outside the key range is never looked up; clamping keeps the int conversions defined)
+        const float lo = -(float)v3dhash::kGuard, hi = 60000.f;
+        c.key[l][i] = v3dhash::pack_key(c.bb[i], (int)fminf(fmaxf(c0, lo), hi), (int)fminf(fmaxf(c1, lo), hi),
+                                        (int)fminf(fmaxf(c2, lo), hi));
+        c.slot[l][i] = V3D_FUSED_ABLATE == 4 ? (unsigned)i : v3dhash::hash_u64(c.key[l][i]) & p.lv[l].table.mask;
+        c.found[l][i] = -1;
+      }
+    }
+  };
+  // All probe sequences of the thread advance in lock step, two slots per round: a round is ONE memory round trip for the six
+  // lookups (in turn they cost the sum of their chain lengths: unsuccessful searches -- absent corners are the common case off the
+  // surface -- run to the first empty slot, and a wave waits for its longest chain: 39 k cycles per tile, measured).
+  auto ct_probe = [&](Probe& c) __attribute__((always_inline)) {
+    unsigned pending = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int i = 0; i < kFProbeRows; ++i) pending |= (c.ok[l][i] && V3D_FUSED_ABLATE != 4 ? 1u : 0u) << (l * kFProbeRows + i);
+    for (unsigned round = 0; __any(pending != 0) && round <= 0x40000000u; ++round) {
+      unsigned long long ka[3][kFProbeRows], kb[3][kFProbeRows];
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < kFProbeRows; ++i) {
+          // (a finished lookup re-reads its last slots: unconditional loads keep the six of them in one batch)
+          ka[l][i] = p.lv[l].table.keys[c.slot[l][i]];
+          kb[l][i] = p.lv[l].table.keys[(c.slot[l][i] + 1) & p.lv[l].table.mask];
+        }
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < kFProbeRows; ++i) {
+          const unsigned bit = 1u << (l * kFProbeRows + i);
+          if (pending & bit) {
+            const unsigned s0 = c.slot[l][i], s1 = (s0 + 1) & p.lv[l].table.mask;
+            if (ka[l][i] == c.key[l][i]) { c.found[l][i] = (int)s0; pending &= ~bit; }
+            else if (ka[l][i] == v3dhash::kEmpty) pending &= ~bit;
+            else if (kb[l][i] == c.key[l][i]) { c.found[l][i] = (int)s1; pending &= ~bit; }
+            else if (kb[l][i] == v3dhash::kEmpty) pending &= ~bit;
+            else c.slot[l][i] = (s1 + 1) & p.lv[l].table.mask;
+          }
+        }
+    }
+  };
+  auto ct_values = [&](Probe& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int i = 0; i < kFProbeRows; ++i) {
+        if (V3D_FUSED_ABLATE == 4) ct_row[l][i] = c.ok[l][i] ? (int)(c.key[l][i] >> 32) & 1023 : -1;
+        else ct_row[l][i] = c.found[l][i] >= 0 ? p.lv[l].table.vals[c.found[l][i]] : -1;
+      }
+  };
+  // an absent corner (or a padding row) reads feature row 0 with weight 0: the gathers below are unconditional
+  auto ct_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int i = 0; i < kFProbeRows; ++i) {
+        const int r = (tid >> 3) + i * (kFThreads / 8);
+        crow[fused_corner_index(r, l, corner)] = ct_row[l][i] < 0 ? 0 : ct_row[l][i];
+        cw[fused_corner_index(r, l, corner)] = ct_row[l][i] < 0 ? 0.f : ct_w[l][i];
+      }
+  };
 
   // ---- layer 1: K = 3 taps x (C0 + C1 + C2 + c_feat) channels, produced chunk by chunk ----------------------------------
-  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  int srow = tid >> 3, sc4 = (tid & 7) * 4;
   const int cb1 = p.lv[0].C, cb2 = cb1 + p.lv[1].C, cb3 = cb2 + p.lv[2].C;
   // Gather registers: the level chunks (8 corner rows per staging row) and the per-point feature chunks (one row) have their
   // own registers and their own loops below -- with one conditional producer the compiler routed the gathers through
   // temporaries and waited for ALL of them before the chunk's first MFMA (no overlap).
-  f32x4 xr[2][8], xf[2];
+  f32x4 xr[kFStageRows][8], xf[kFStageRows];
   const int nkc_lv = cb3 / 32;             // chunks produced by interpolation; chunks nkc_lv .. nkc1 - 1 copy pts_feat
   // level of a 32-channel chunk: wave-uniform (chunk boundaries are multiples of 32)
   auto level_of = [&](int kc) __attribute__((always_inline)) {
     const int c = kc * 32;
     return c < cb1 ? 0 : c < cb2 ? 1 : 2;
   };
-  auto issue_lv = [&](int kc) __attribute__((always_inline)) {
+  // part = -1: all gathers of the chunk; 0 / 1 / 2: a third of them (issued between the taps of the previous chunk: one burst of
+  // 16 x 1 KB per wave from all eight waves of the CU backs up the CU's single vector-memory path and the wave cannot issue its
+  // matrix instructions behind it -- measured 1.6 k cycles for the burst)
+  auto issue_lv = [&](int kc, int part) __attribute__((always_inline)) {
     const int l = level_of(kc);
     const float* const feats = l == 0 ? p.lv[0].feats : l == 1 ? p.lv[1].feats : p.lv[2].feats;
     const int C = l == 0 ? p.lv[0].C : l == 1 ? p.lv[1].C : p.lv[2].C;
     const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + (kFRows / 2) * ps;
+    for (int ps = 0; ps < kFStageRows; ++ps) {
+      const int r = srow + (kFThreads / 8) * ps;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int cr = crow[fused_corner_index(r, l, k)];
+        if (part >= 0 && ((ps * 8 + k) * 3) / (kFStageRows * 8) != part) continue;
+        const int cr = V3D_FUSED_ABLATE == 2 ? (crow[fused_corner_index(r, l, k)] & 7) : crow[fused_corner_index(r, l, k)];
         xr[ps][k] = *reinterpret_cast<const f32x4*>(feats + (size_t)cr * C + lc);
       }
     }
   };
   auto issue_feat = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + (kFRows / 2) * ps;
+    for (int ps = 0; ps < kFStageRows; ++ps) {
+      const int r = srow + (kFThreads / 8) * ps;
       xf[ps] = (r < rows && q0 + r < n_q)
                    ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
                    : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  // split one staging row's 4 channels and commit them to the staging tile the MFMAs read
+  // split one staging row's 4 channels and commit them to the staging tile of chunk kc (tile kc & 1)
   auto commit_row = [&](int kc, int r, const float (&v)[4]) __attribute__((always_inline)) {
 #ifdef V3D_FUSED_DEBUG
     if (p.dbg_x && r < rows && q0 + r < n_q)
@@ -276,15 +414,15 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
     fused_split4(v, hi, lo);
     const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
     const int slot = kg ^ (((r >> 3) & 1) * 3);
-    u32x2* x2 = reinterpret_cast<u32x2*>(xq);
+    u32x2* x2 = reinterpret_cast<u32x2*>(xq + (kc & 1) * kFStageSlots);
     x2[(r * 4 + slot) * 2 + half] = hi;
     x2[((kFRT + r) * 4 + slot) * 2 + half] = lo;
   };
   auto commit_lv = [&](int kc) __attribute__((always_inline)) {
     const int l = level_of(kc);
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + (kFRows / 2) * ps;
+    for (int ps = 0; ps < kFStageRows; ++ps) {
+      const int r = srow + (kFThreads / 8) * ps;
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
@@ -297,9 +435,9 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
   };
   auto commit_feat = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int ps = 0; ps < kFStageRows; ++ps) {
       const float v[4] = {xf[ps].x, xf[ps].y, xf[ps].z, xf[ps].w};
-      commit_row(kc, srow + (kFRows / 2) * ps, v);
+      commit_row(kc, srow + (kFThreads / 8) * ps, v);
     }
   };
 
@@ -311,9 +449,13 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
     tapmask |= (hh >= 1 ? 1u : 0u) << (2 * nb);
     tapmask |= (hh + 1 < n_hyp ? 1u : 0u) << (2 * nb + 1);
   }
-  u32x4 a_cur[2 * kFMBW], a_nxt[2 * kFMBW];
+  // Weight fragments: a ring of three tap steps.  The (layer, chunk, tap) steps form one cyclic sequence through all the tiles of
+  // the workgroup; the fragments of step g + 2 are requested when step g starts, so an L2 round trip has two steps' worth of
+  // matrix instructions (2 x 24 x 16 cycles of this wave alone) to hide behind.  Three taps per chunk = three ring slots: the
+  // slot of a tap is a compile-time constant.
+  u32x4 a_ring[3][2 * kFMBW];
   auto load_a = [&](u32x4 (&a)[2 * kFMBW], const float* wp, int nkc, int t, int kc) __attribute__((always_inline)) {
-    const u32x4* w = reinterpret_cast<const u32x4*>(wp + (size_t)(t * nkc + kc) * kFWslab) + lane;
+    const u32x4* w = reinterpret_cast<const u32x4*>(wp + (V3D_FUSED_ABLATE == 3 ? (size_t)0 : (size_t)(t * nkc + kc) * kFWslab)) + lane;
 #pragma unroll
     for (int m = 0; m < kFMBW; ++m) {
       a[m] = w[(wave * kFMBW + m) * 64];
@@ -327,8 +469,21 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
 #pragma unroll
       for (int m = 0; m < kFMBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
-  auto mfma_block = [&](const bf16x8 b_hi, const bf16x8 b_lo, int nb) __attribute__((always_inline)) {
-#ifdef V3D_FUSED_NOMFMA      // developer experiment: B fragments are read, no matrix instruction is issued
+  bool has_next = false;                   // another tile follows the current one (wave-uniform)
+  // the fragments of the step two after (layer, kc, t); layer 0 = the first Conv1d (nkc1 chunks), 1 and 2 = the 128 -> 128 ones;
+  // behind the last layer the sequence starts over for the next tile
+  auto prefetch_a = [&](u32x4 (&a)[2 * kFMBW], int layer, int kc, int t) __attribute__((always_inline)) {
+    int t2 = t + 2, kc2 = kc, l2 = layer;
+    if (t2 >= 3) { t2 -= 3; ++kc2; }
+    if (kc2 >= (layer == 0 ? p.nkc1 : 4)) { kc2 = 0; ++l2; }
+    if (l2 == 3) {
+      if (!has_next) return;
+      l2 = 0;
+    }
+    load_a(a, l2 == 0 ? p.w[0] : l2 == 1 ? p.w[1] : p.w[2], l2 == 0 ? p.nkc1 : 4, t2, kc2);
+  };
+  auto mfma_block = [&](const u32x4 (&a_cur)[2 * kFMBW], const bf16x8 b_hi, const bf16x8 b_lo, int nb) __attribute__((always_inline)) {
+#if defined(V3D_FUSED_NOMFMA) || V3D_FUSED_ABLATE == 1      // developer experiment: B fragments are read, no matrix instruction is issued
     asm volatile("" : : "v"(b_hi), "v"(b_lo));
     return;
 #endif
@@ -340,6 +495,11 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
       acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
     }
   };
+  // folded BatchNorm biases and head weights: tile-invariant, parked in LDS once (a global load in front of every activation
+  // store / head is an exposed L2 round trip per layer and tile; registers are what this kernel does not have)
+  for (int i = tid; i < 3 * kFH; i += kFThreads) cbias[i] = (i < kFH ? p.bias[0] : i < 2 * kFH ? p.bias[1] : p.bias[2])[i % kFH];
+  for (int i = tid; i < 3 * kFH; i += kFThreads) chead[i] = p.head_w[i];
+  if (tid == 0) chead[3 * kFH] = p.head_b[0];
   // bias + ReLU of this wave's 32 channels x 64 rows -> split -> LDS activation buffer (B-fragment order, 16-byte slots of 8
   // channels, slot index XOR-ed with the row so that the 16 row-lanes of a ds_read_b128 hit 16 different slots)
   auto store_act = [&](u32x4* dst, const float* bias) __attribute__((always_inline)) {
@@ -350,9 +510,10 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
 #pragma unroll
       for (int mw = 0; mw < kFMBW; ++mw) {
         const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + co0);
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bias[co0 + k], 0.f);
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bq[k], 0.f);
         u32x2 hi, lo;
         fused_split4(v, hi, lo);
         const int slot = (co0 >> 3) ^ (r & 15), half = (co0 >> 2) & 1;
@@ -362,79 +523,156 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
     }
   };
 
-  // the three taps of chunk kc: MFMAs on the staging tile, A fragments one tap ahead (the last tap fetches the next chunk's /
-  // the next layer's first fragments)
-  auto mfma_chunk = [&](int kc) __attribute__((always_inline)) {
+  // the three taps of chunk kc: MFMAs on its staging tile, A fragments two taps ahead
+  auto mfma_chunk = [&](int kc, auto tap_hook) __attribute__((always_inline)) {
+    const u32x4* const xs = xq + (kc & 1) * kFStageSlots;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      if (t < 2) load_a(a_nxt, p.w[0], p.nkc1, t + 1, kc);
-      else if (kc + 1 < p.nkc1) load_a(a_nxt, p.w[0], p.nkc1, 0, kc + 1);
-      else load_a(a_nxt, p.w[1], 4, 0, 0);                                     // first fragments of layer 2
+      prefetch_a(a_ring[(t + 2) % 3], 0, kc, t);
+      tap_hook(t);
 #pragma unroll
       for (int nb = 0; nb < kFNB; ++nb) {
         const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
         const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
         const int slot = R * 4 + (kq ^ (((R >> 3) & 1) * 3));
-        mfma_block(__builtin_bit_cast(bf16x8, xq[slot]), __builtin_bit_cast(bf16x8, xq[kFRT * 4 + slot]), nb);
+        mfma_block(a_ring[t], __builtin_bit_cast(bf16x8, xs[slot]), __builtin_bit_cast(bf16x8, xs[kFRT * 4 + slot]), nb);
       }
-#pragma unroll
-      for (int m = 0; m < 2 * kFMBW; ++m) a_cur[m] = a_nxt[m];
+      FPHASE_FINE(2 + t);
     }
   };
-
-  zero_acc();
-  __syncthreads();                         // corner table ready
-  issue_lv(0);
-  load_a(a_cur, p.w[0], p.nkc1, 0, 0);
-#pragma unroll 1
-  for (int kc = 0; kc < nkc_lv; ++kc) {
-    __syncthreads();                       // the previous chunk's MFMAs are done with the staging tile
-    commit_lv(kc);
-    __syncthreads();
-    if (kc + 1 < nkc_lv) issue_lv(kc + 1);          // the next chunk's gathers fly during this chunk's MFMAs
-    else if (nkc_lv < p.nkc1) issue_feat(nkc_lv);
-    mfma_chunk(kc);
-  }
-#pragma unroll 1
-  for (int kc = nkc_lv; kc < p.nkc1; ++kc) {
-    __syncthreads();
-    commit_feat(kc);
-    __syncthreads();
-    if (kc + 1 < p.nkc1) issue_feat(kc + 1);
-    mfma_chunk(kc);
-  }
-  store_act(actA, p.bias[0]);
-  __syncthreads();        // act1 complete; staging tile / corner table (aliasing the second buffer) no longer needed
-
-  // ---- layers 2 and 3: K = 3 taps x 128 channels read from LDS ------------------------------------------------------------
-#pragma unroll 1
-  for (int layer = 1; layer < 3; ++layer) {
-    const u32x4* const src = layer == 1 ? actA : actB;
-    if (layer == 1 && tid < 2 * 16) actB[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
-    zero_acc();
-    if (layer == 1) __syncthreads();       // zero row of the second buffer visible
+  // a 128 -> 128 layer on the activations in `src`; `hook(kc)` runs in front of every chunk (the next tile's corner-table stages)
+  auto dense_layer = [&](int layer, const u32x4* src, auto hook) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int kc = 0; kc < 4; ++kc) {
+      hook(kc);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const float* const wl = layer == 1 ? p.w[1] : p.w[2];
-        if (t < 2) load_a(a_nxt, wl, 4, t + 1, kc);
-        else if (kc + 1 < 4) load_a(a_nxt, wl, 4, 0, kc + 1);
-        else if (layer == 1) load_a(a_nxt, p.w[2], 4, 0, 0);
+        prefetch_a(a_ring[(t + 2) % 3], layer, kc, t);
 #pragma unroll
         for (int nb = 0; nb < kFNB; ++nb) {
           const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
           const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
           const int slot = R * 16 + ((kc * 4 + kq) ^ (R & 15));
-          mfma_block(__builtin_bit_cast(bf16x8, src[slot]), __builtin_bit_cast(bf16x8, src[kFRT * 16 + slot]), nb);
+          mfma_block(a_ring[t], __builtin_bit_cast(bf16x8, src[slot]), __builtin_bit_cast(bf16x8, src[kFRT * 16 + slot]), nb);
         }
-#pragma unroll
-        for (int m = 0; m < 2 * kFMBW; ++m) a_cur[m] = a_nxt[m];
       }
     }
-    if (layer == 1) {
-      store_act(actB, p.bias[1]);
-    } else {
+  };
+
+  int hpt = tid >> 5, hl32 = tid & 31, hc0 = hl32 * 4;       // head: 32 lanes per point, 4 channels per lane
+  auto refresh_lane_ids = [&]() __attribute__((always_inline)) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    tid = t; lane = t & 63; kq = lane >> 4; jn = lane & 15; corner = t & 7; srow = t >> 3; sc4 = (t & 7) * 4;
+    hpt = t >> 5; hl32 = t & 31; hc0 = hl32 * 4;
+  };
+
+  // Tile walk: workgroups are dealt round-robin to the 8 XCDs, so XCD x = blockIdx.x % 8 takes the x-th contiguous eighth of the
+  // tiles (consecutive tiles are neighbouring pixels of one view): the corner rows its workgroups gather then come from the part
+  // of the scene a few views see and stay in that XCD's 4 MB L2, instead of every XCD streaming all three feature tables.
+  const int n_xcd = V3D_FUSED_ABLATE != 7 && gridDim.x % 8 == 0 ? 8 : 1;
+  const int tiles_per_xcd = (n_tiles + n_xcd - 1) / n_xcd, tile_step = gridDim.x / n_xcd;
+  const int tile_end = min(n_tiles, ((int)blockIdx.x % n_xcd + 1) * tiles_per_xcd);
+  int tile = ((int)blockIdx.x % n_xcd) * tiles_per_xcd + (int)blockIdx.x / n_xcd;
+  if (tile >= tile_end) return;
+#ifdef V3D_FUSED_SKEW
+  // developer experiment: the second half of the grid starts V3D_FUSED_SKEW x 8 k cycles late, so that the two workgroups of a CU
+  // do not walk through the same phases at the same time
+  if (blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < V3D_FUSED_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+  {
+    Probe c;
+    ct_points(c, tile);
+    load_a(a_ring[0], p.w[0], p.nkc1, 0, 0);
+    load_a(a_ring[1], p.w[0], p.nkc1, 1, 0);
+    ct_mins(c);
+    ct_keys(c);
+    ct_probe(c);
+    ct_values(c);
+  }
+#pragma unroll 1
+  for (; tile < tile_end; tile += tile_step) {
+    refresh_lane_ids();
+    pt0 = tile * kFPts;
+    q0 = (long long)pt0 * n_hyp;
+    has_next = tile + tile_step < tile_end;
+    // every wave is past the barrier behind layer 3 of the previous tile: the second buffer (staging tiles, corner table) is free
+    if (tid < 2 * 2 * 4) xq[(tid >> 3) * kFStageSlots + (((tid >> 2) & 1) * kFRT + kFZero) * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
+    ct_store();
+    zero_acc();
+    __syncthreads();                         // corner table ready
+    FPHASE_MARK(0);
+    issue_lv(0, -1);
+    commit_lv(0);
+    __syncthreads();
+    FPHASE_MARK(1);
+    // chunk kc: its staging tile is complete; the next chunk's gathers fly during this chunk's MFMAs and are committed to the
+    // OTHER staging tile behind them (last read by chunk kc - 1, which every wave finished before the barrier in front of chunk
+    // kc): one barrier per chunk
+#pragma unroll 1
+    for (int kc = 0; kc < nkc_lv; ++kc) {
+#if V3D_FUSED_ABLATE == 8
+      if (kc + 1 < nkc_lv) issue_lv(kc + 1, -1);
+      else if (nkc_lv < p.nkc1) issue_feat(nkc_lv);
+      FPHASE_FINE(1);
+      mfma_chunk(kc, [&](int) __attribute__((always_inline)) {});
+#else
+      if (kc + 1 >= nkc_lv && nkc_lv < p.nkc1) issue_feat(nkc_lv);
+      FPHASE_FINE(1);
+      mfma_chunk(kc, [&](int t) __attribute__((always_inline)) {
+        if (kc + 1 < nkc_lv) issue_lv(kc + 1, t);
+      });
+#endif
+      FPHASE_MARK(2);
+      if (kc + 1 < nkc_lv) commit_lv(kc + 1);
+      else if (nkc_lv < p.nkc1) commit_feat(nkc_lv);
+      FPHASE_FINE(5);
+      __syncthreads();
+      FPHASE_FINE(6);
+      FPHASE_MARK(1);
+    }
+#pragma unroll 1
+    for (int kc = nkc_lv; kc < p.nkc1; ++kc) {
+      if (kc + 1 < p.nkc1) issue_feat(kc + 1);
+      FPHASE_FINE(1);
+      mfma_chunk(kc, [&](int) __attribute__((always_inline)) {});
+      FPHASE_MARK(2);
+      if (kc + 1 < p.nkc1) commit_feat(kc + 1);
+      FPHASE_FINE(5);
+      __syncthreads();
+      FPHASE_FINE(6);
+      FPHASE_MARK(1);
+    }
+    // (the fp32 output of the previous tile's last layer covered the zero row of the first buffer)
+    if (tid < 2 * 16) actA[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
+    store_act(actA, cbias);
+    if (tid < 2 * 16) actB[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();        // act1 complete; staging tiles / corner table (aliasing the second buffer) no longer needed
+    FPHASE_MARK(3);
+
+    // ---- layers 2 and 3: K = 3 taps x 128 channels read from LDS; the next tile's corner table is looked up on the side ------------
+    const int next_tile = tile + tile_step;
+    Probe c;
+    zero_acc();
+    dense_layer(1, actA, [&](int kc) __attribute__((always_inline)) {
+      if (has_next && kc == 0) ct_points(c, next_tile);
+      if (has_next && kc == 2) ct_mins(c);
+    });
+    FPHASE_MARK(4);
+    if (V3D_FUSED_ABLATE != 5) {
+      store_act(actB, cbias + kFH);
+      __syncthreads();
+      FPHASE_MARK(3);
+      zero_acc();
+      dense_layer(2, actB, [&](int kc) __attribute__((always_inline)) {
+        if (has_next && kc == 0) ct_keys(c);
+        if (has_next && kc == 1) ct_probe(c);
+        if (has_next && kc == 3) ct_values(c);
+      });
+      FPHASE_MARK(5);
+    }
+    {
       // last layer: fp32 [64 rows][128] into the first buffer (act1 is dead: every wave passed the barrier after layer 2)
       float* const of = reinterpret_cast<float*>(actA);
 #pragma unroll
@@ -442,59 +680,64 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
 #pragma unroll
         for (int mw = 0; mw < kFMBW; ++mw) {
           const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(cbias + 2 * kFH + co0);
           f32x4 v;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + p.bias[2][co0 + k], 0.f);
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bq[k], 0.f);
           *reinterpret_cast<f32x4*>(of + ((cb0 + nb) * 16 + jn) * kFH + co0) = v;
         }
     }
     __syncthreads();
-  }
+    FPHASE_MARK(3);
 
-  // ---- head: Conv1d(128 -> 1, k3, pad 1, bias) over the hypotheses, softmax, expectation (32 lanes per point) ----------------
-  {
-    const float* const of = reinterpret_cast<const float*>(actA);
-    const int pt = tid >> 5, l32 = tid & 31, c0 = l32 * 4;
-    float score[8];
+    // ---- head: Conv1d(128 -> 1, k3, pad 1, bias) over the hypotheses, softmax, expectation (32 lanes per point) ----------------
+    {
+      const float* const of = reinterpret_cast<const float*>(actA);
+      float score[8], hw0[4], hw1[4], hw2[4];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) score[h] = 0.f;
-    float w0[4], w1[4], w2[4];
+      for (int k = 0; k < 4; ++k) { hw0[k] = chead[(hc0 + k) * 3]; hw1[k] = chead[(hc0 + k) * 3 + 1]; hw2[k] = chead[(hc0 + k) * 3 + 2]; }
+      const float head_b = chead[3 * kFH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { w0[k] = p.head_w[(c0 + k) * 3]; w1[k] = p.head_w[(c0 + k) * 3 + 1]; w2[k] = p.head_w[(c0 + k) * 3 + 2]; }
+      for (int h = 0; h < 8; ++h) score[h] = 0.f;
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      if (h < n_hyp) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(of + (pt * n_hyp + h) * kFH + c0);
+      for (int h = 0; h < 8; ++h) {
+        if (h < n_hyp) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(of + ((hpt < kFPts ? hpt : 0) * n_hyp + h) * kFH + hc0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // out[h'] = sum_t in[h' + t - 1] w[t]  =>  in[h] feeds out[h+1] (t=0), out[h] (t=1), out[h-1] (t=2)
-          if (h + 1 < 8) score[h + 1] += x[k] * w0[k];
-          score[h] += x[k] * w1[k];
-          if (h > 0) score[h - 1] += x[k] * w2[k];
+          for (int k = 0; k < 4; ++k) {
+            // out[h'] = sum_t in[h' + t - 1] w[t]  =>  in[h] feeds out[h+1] (t=0), out[h] (t=1), out[h-1] (t=2)
+            if (h + 1 < 8) score[h + 1] += x[k] * hw0[k];
+            score[h] += x[k] * hw1[k];
+            if (h > 0) score[h - 1] += x[k] * hw2[k];
+          }
         }
       }
-    }
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float v = score[h];
+      for (int h = 0; h < 8; ++h) {
+        float v = score[h];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      score[h] = v + p.head_b[0];
-    }
-    if (l32 == 0 && pt0 + pt < p.n_pts) {
-      float m = -INFINITY;
-      for (int h = 0; h < n_hyp; ++h) m = fmaxf(m, score[h]);
-      float sum = 0.f;
-      for (int h = 0; h < n_hyp; ++h) sum += expf(score[h] - m);
-      float e = 0.f;
-      for (int h = 0; h < n_hyp; ++h) {
-        const float pr = expf(score[h] - m) / sum;
-        p.preds[(size_t)(pt0 + pt) * n_hyp + h] = pr;
-        if (p.vals) e += p.vals[h] * pr;
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        score[h] = v + head_b;
       }
-      if (p.expect) p.expect[pt0 + pt] = e;
+      if (hl32 == 0 && hpt < kFPts && pt0 + hpt < p.n_pts) {
+        float m = -INFINITY;
+        for (int h = 0; h < n_hyp; ++h) m = fmaxf(m, score[h]);
+        float sum = 0.f;
+        for (int h = 0; h < n_hyp; ++h) sum += expf(score[h] - m);
+        float e = 0.f;
+        for (int h = 0; h < n_hyp; ++h) {
+          const float pr = expf(score[h] - m) / sum;
+          p.preds[(size_t)(pt0 + hpt) * n_hyp + h] = pr;
+          if (p.vals) e += p.vals[h] * pr;
+        }
+        if (p.expect) p.expect[pt0 + hpt] = e;
+      }
     }
+    FPHASE_MARK(6);
+    // the next tile's first writes into the second buffer are safe (every wave passed the barrier behind layer 3); its writes into
+    // the first buffer (activation stores of layer 1) come several barriers after this tile's head reads
   }
+  FPHASE_FLUSH;
 }
 }  // namespace
 
@@ -512,6 +755,18 @@ extern "C" int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int 
   V3D_CHECK_LAUNCH("decoder_head_kernel");
   return V3D_OK;
 }
+
+#ifdef V3D_PHASE_TIMING
+extern "C" int v3d_debug_fused_phase_read(unsigned long long* out8_host, int n_blocks) {
+  V3D_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)8 * kFPhaseSlots);
+  V3D_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fused_phase), h.size() * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) out8_host[i] = 0;
+  for (int b = 0; b < n_blocks && b < kFPhaseSlots; ++b)
+    for (int i = 0; i < 8; ++i) out8_host[i] += h[(size_t)b * 8 + i];
+  return V3D_OK;
+}
+#endif
 
 #ifdef V3D_FUSED_DEBUG
 static float* g_fused_dbg_x = nullptr;
@@ -570,14 +825,22 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   static const size_t lds_bytes = getenv("V3D_FUSED_LDS_KB") ? (size_t)atoi(getenv("V3D_FUSED_LDS_KB")) * 1024 : kFLdsBytes;
   V3D_REQUIRE(lds_bytes >= kFUsedLdsBytes && lds_bytes <= 160 * 1024, V3D_ERR_BAD_ARG, "V3D_FUSED_LDS_KB out of range");
   static bool attr_set = false;
+  static int resident = 0;     // workgroups the device holds at once: the LDS request admits 160 KB / lds_bytes per CU
   if (!attr_set) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_bytes));
+    int dev = 0, n_cu = 0;
+    V3D_CHECK_HIP(hipGetDevice(&dev));
+    V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int per_cu = getenv("V3D_FUSED_WG_PER_CU") ? atoi(getenv("V3D_FUSED_WG_PER_CU")) : (int)(160 * 1024 / lds_bytes);
+    resident = n_cu * (per_cu > 0 ? per_cu : 1);
     attr_set = true;
   }
   {
+    // persistent tile walk: workgroup b takes tiles b, b + grid, ... (equal work per tile, so a static split is balanced)
+    const int n_tiles = (n_pts + kFPts - 1) / kFPts;
     v3d::TimedScope ts("decoder_fused", s);
-    decoder_fused_kernel<<<(n_pts + kFPts - 1) / kFPts, kFThreads, lds_bytes, s>>>(p);
+    decoder_fused_kernel<<<n_tiles < resident ? n_tiles : resident, kFThreads, lds_bytes, s>>>(p);
   }
   V3D_CHECK_LAUNCH("decoder_fused_kernel");
   return V3D_OK;

@@ -4,6 +4,7 @@ the fused decoder, per-kernel HIP-event times per sweep (V3D_FUSED_LDS_KB select
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 syn = importlib.import_module('3dvnet_amd.synthetic'); lm = importlib.import_module('3dvnet_amd.lightningmodel'); libm = importlib.import_module('3dvnet_amd._lib')
+if os.environ.get('V3D_LIB_OVERRIDE'): libm.LIB_PATH = os.environ['V3D_LIB_OVERRIDE']      # an ablated build (fused_decoder_ablate.sh)
 dev = torch.device('cuda:0'); cfg = syn.CONFIGS['cfg3']; n_ref, k = 64, 2
 edges, n_img = syn.make_edges(n_ref, k, k); rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=5, yaw_step_deg=360.0 / n_img)
 feat = syn.make_features(n_img, 32, *cfg['feat_size'], seed=5).to(dev)
@@ -16,7 +17,7 @@ net = net.to(dev)
 with torch.no_grad():
     xs = net.model_scene(depth, db, feat, rot, tv, K, edges)
     outs = {}
-    for fused in (False, True):
+    for fused in ((True,) if os.environ.get('V3D_TIME_FUSED_ONLY') else (False, True)):
         net.decoder.fused = fused
         def sweep():
             o = []
@@ -31,4 +32,9 @@ with torch.no_grad():
         tot = sum(ms for ms, c in st.values()) / 3
         print('LDS %s KB fused=%s: %.3f ms per 64-view sweep:' % (os.environ.get('V3D_FUSED_LDS_KB', 'default'), fused, tot),
               {k_: round(ms / 3, 3) for k_, (ms, c) in st.items() if ms / 3 > 0.05})
-    print('max |offset fused - chain| = %.2e m' % float((outs[True] - outs[False]).abs().max()))
+    if os.environ.get('V3D_FUSED_PHASES'):      # library built with -DV3D_PHASE_TIMING (fused_decoder_ablate.sh build "-DV3D_PHASE_TIMING")
+        import ctypes
+        fn = libm.load().v3d_debug_fused_phase_read; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+        buf = (ctypes.c_ulonglong * 8)(); nb = 16 * 3136 // 8; fn(buf, nb); tot = sum(buf)
+        print('phases (cycles per workgroup of the last launch, wave 0): total %.0f:' % (tot / nb), ' '.join('%d:%.0f (%.1f%%)' % (i, v / nb, 100.0 * v / tot) for i, v in enumerate(buf)))
+    if False in outs: print('max |offset fused - chain| = %.2e m' % float((outs[True] - outs[False]).abs().max()))
