@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--refs', type=int, default=32)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--tag', default='')
+    ap.add_argument('--precision', default='split_bf16', choices=['split_bf16', 'fp32'])
     args = ap.parse_args()
     syn = importlib.import_module('3dvnet_amd.synthetic')
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
@@ -27,6 +28,7 @@ def main():
     inp = syn.make_costvolume_inputs('cfg2', n_ref=args.refs)
     net = mvs.MVSNet(32, inp['img_size']).eval()
     net.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
+    net.cnn_3d.precision = args.precision
     net = net.to(dev)
     b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(dev)
     feat = inp['feat'].to(dev)
