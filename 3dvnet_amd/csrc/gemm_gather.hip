@@ -352,6 +352,179 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
   PHASE_FLUSH;
 }
 
+// ---- the same GEMM in rounds of S (segment, K chunk) steps: the small-M kernel of the sparse convolutions ------------------
+// gemm_gather_kernel moves ONE step per pair of barriers: a thread has one 16-byte gather (and its share of the weight slab)
+// in flight, so a tile's time is (number of steps) x (a memory round trip): 27 offsets x K / 32 chunks -- 108 steps on the
+// 128-channel level of the sparse U-Net, whose 3.5 k rows are 110 workgroups on 256 CUs (nothing else hides the latency).
+// Here a round stages S steps' activation tiles at once (S gathers per thread in flight, one pair of barriers per round) and the
+// weight fragments go from L2 straight into the registers of the wave that owns the channel block (they were never shared
+// between waves; the LDS round trip of the slab is gone).  The neighbour-table column of every segment is read once into an
+// LDS row table (the old kernel read it twice: activity scan + staging).  Same step order and MFMA order per accumulator:
+// bit-identical to gemm_gather_kernel<MBW, NB, true>.
+template <int MBW, int NB, int S>
+__global__ __launch_bounds__(256) void gemm_gather_rounds_kernel(GemmParams p) {
+  constexpr int kTM = 16 * NB, NPASS = (kTM + 31) / 32, MB = 4 * MBW;
+  constexpr int kWslab = 4 * MBW * 16 * kKC;       // packed floats per (segment, K chunk)
+  constexpr int kTile = 2 * kTM * 4;                // 16-byte slots of one step's activation tile: [hi, lo][row][4 k groups]
+  __shared__ __attribute__((aligned(16))) u32x4 xq[S * kTile];
+  __shared__ int rowtab[kMaxSeg * kTM];
+  __shared__ int s_act[kMaxSeg], s_list[kMaxSeg], s_nact;
+  __shared__ int steptab[kMaxSeg * 8 + 2 * S];     // (segment << 8 | K chunk) of every step of the flat sequence, -1 behind its end
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jn = lane & 15;
+  // rows are sorted by voxel key: a contiguous run of tiles per XCD keeps the neighbour rows a tile gathers in that XCD's L2
+  const int m0 = v3d::xcd_contiguous_block() * kTM;
+  const int nkc = p.KP / kKC;
+
+  f32x4 acc[NB][MBW];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- row table: source row of (segment, tile row), -1 = zero row; which segments does the tile need at all? ----------------
+  if (tid < kMaxSeg) s_act[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < p.n_seg * kTM; e += 256) {
+    const int sg = e / kTM, row = e % kTM, m = m0 + row;
+    int v = -1;
+    if (m < p.M) {
+      if (p.group_len > 0) {
+        const int h = m % p.group_len + sg - p.n_seg / 2;
+        v = (h >= 0 && h < p.group_len) ? m + sg - p.n_seg / 2 : -1;
+      } else {
+        v = p.seg[sg].idx ? p.seg[sg].idx[m] : m;
+      }
+    }
+    rowtab[e] = v;
+    if (v >= 0 || p.seg[sg].idx == nullptr) s_act[sg] = 1;       // benign race: everybody writes the same value
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int sg = 0; sg < p.n_seg; ++sg) if (s_act[sg]) s_list[n++] = sg;
+    s_nact = n;
+  }
+  __syncthreads();
+  const int n_steps = s_nact * nkc;                 // flat (active segment, K chunk) sequence
+  for (int f = tid; f < n_steps + 2 * S; f += 256) steptab[f] = f < n_steps ? (s_list[f / nkc] << 8) | (f % nkc) : -1;
+  __syncthreads();
+  // One source matrix for every segment (a sparse convolution: only the row maps differ): its pointer and row stride are read
+  // once.  Otherwise they are looked up per step -- a scalar load from the kernel arguments behind an LDS read, ~500 cycles in
+  // front of every gather (measured: 1.9 k cycles per round of four steps just to issue the gathers).
+  bool one_src = true;
+  for (int sg = 1; sg < p.n_seg; ++sg) one_src = one_src && p.seg[sg].src == p.seg[0].src && p.seg[sg].ld == p.seg[0].ld;
+  const float* const src0 = p.seg[0].src;
+  const int ld0 = p.seg[0].ld;
+  PHASE_DECL;
+
+  // staging role: 8 lanes x float4 cover the 32 columns of one row; 32 rows per pass
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  f32x4 xr[S][NPASS];
+  u32x4 afr[S][2 * MBW];
+  int st[S];                                        // the steps of the round being issued (wave-uniform)
+  auto load_steps = [&](int f0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) st[j] = __builtin_amdgcn_readfirstlane(steptab[f0 + j]);
+  };
+  auto issue_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (st[j] >= 0) {
+        const int sg = st[j] >> 8, col = (st[j] & 255) * kKC + sc4;
+        const float* const src = one_src ? src0 : p.seg[sg].src;
+        const int ld = one_src ? ld0 : p.seg[sg].ld;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+          const int row = srow + 32 * i;
+          const int r = row < kTM ? rowtab[sg * kTM + row] : -1;
+          xr[j][i] = (r >= 0 && col < p.K) ? *reinterpret_cast<const f32x4*>(src + (size_t)r * ld + col)
+                                           : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+  auto issue_a = [&](int stj, u32x4 (&a)[2 * MBW]) __attribute__((always_inline)) {
+    if (stj >= 0) {
+      const int sg = stj >> 8, kc = stj & 255;
+      const u32x4* w = reinterpret_cast<const u32x4*>(p.wp + (size_t)(sg * nkc + kc) * kWslab) + lane;
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) {
+        a[m] = w[(wave * MBW + m) * 64];
+        a[MBW + m] = w[(MB + wave * MBW + m) * 64];
+      }
+    }
+  };
+  auto commit = [&](int f0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (f0 + j < n_steps) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+          const int row = srow + 32 * i;
+          if (row < kTM) {
+            f32x4 v = xr[j][i];
+            if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            // this thread holds k = sc4 .. sc4+3 of the row: half of the 8-wide k group kg = sc4 / 8
+            const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+            const int slot = kg ^ ((((row & 15) >> 3) & 1) * 3);
+            const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
+            const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
+            const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+            u32x2* xh2 = reinterpret_cast<u32x2*>(xq + j * kTile);
+            xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
+            xh2[((kTM + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+          }
+        }
+      }
+    }
+  };
+
+  load_steps(0);
+  issue_x();
+#pragma unroll
+  for (int j = 0; j < S; ++j) issue_a(st[j], afr[j]);
+  const int bslot = kq ^ (((jn >> 3) & 1) * 3);
+  PHASE_MARK(0);
+#pragma unroll 1
+  for (int f0 = 0; f0 < n_steps; f0 += S) {
+    __syncthreads();                 // the previous round's MFMAs are done with the activation tiles
+    PHASE_MARK(1);
+    commit(f0);
+    PHASE_MARK(2);
+    __syncthreads();
+    PHASE_MARK(3);
+    load_steps(f0 + S);
+    issue_x();                       // the next round's gathers fly during this round's MFMAs
+    PHASE_MARK(4);
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (f0 + j < n_steps) {
+        const u32x4* xs = xq + j * kTile;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[(nb * 16 + jn) * 4 + bslot]);
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[(kTM + nb * 16 + jn) * 4 + bslot]);
+#pragma unroll
+          for (int m = 0; m < MBW; ++m) {
+            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[j][m]), a_lo = __builtin_bit_cast(bf16x8, afr[j][MBW + m]);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[nb][m], 0, 0, 0);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[nb][m], 0, 0, 0);
+            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
+          }
+        }
+      }
+      issue_a(st[j], afr[j]);        // this step's fragment registers are free: the next round's step j takes them
+    }
+    PHASE_MARK(5);
+  }
+  gemm_epilogue<MBW, NB>(p, acc, m0, wave, kq, jn);
+  PHASE_MARK(6);
+  PHASE_FLUSH;
+}
+
 // ---- Conv1d(k = 3, pad 1) over groups of `group_len` consecutive rows (the hypothesis decoder, refinement.py:29-30) ----
 // The three taps read the same activation rows shifted by -1 / 0 / +1, so the tile (+ one halo row on either side) is
 // gathered, split and committed to LDS once per K chunk and used by all three taps; only the 16 KB weight slab changes
@@ -610,7 +783,26 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
     if (fp32_path) gemm_gather_kernel<MBW_, NB_, false><<<blocks, 256, 0, s>>>(p);         \
     else gemm_gather_kernel<MBW_, NB_, true><<<blocks, 256, 0, s>>>(p);                    \
   } while (0)
-    if (h->MBW == 2) { if (small) V3D_GG(2, 2); else V3D_GG(2, 8); }
+    // small M, split-bf16, every segment 16-byte loadable: the rounds kernel (four steps per pair of barriers)
+    bool rounds = small && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && !getenv("V3D_GEMM_NO_ROUNDS");
+    for (int t = 0; rounds && t < h->n_seg; ++t)
+      rounds = p.seg[t].ld % 4 == 0 && (reinterpret_cast<size_t>(p.seg[t].src) & 15) == 0;
+    if (rounds) {
+      // developer A/B: rows per tile (32 / 64 / 128) -- a tile re-reads the whole weight image, so L2 -> CU weight traffic is
+      // M / rows x 27 x K x N x 4 bytes (0.8 GB per 64-channel conv on 60 k voxels with 32-row tiles, twice the gathers)
+      static const int rows_env = getenv("V3D_GEMM_ROUND_ROWS") ? atoi(getenv("V3D_GEMM_ROUND_ROWS")) : 0;
+      const int rows = rows_env ? rows_env : 32;
+      const unsigned rb = (unsigned)((M + rows - 1) / rows);
+      if (h->MBW == 2) {
+        if (rows == 128) gemm_gather_rounds_kernel<2, 8, 2><<<rb, 256, 0, s>>>(p);
+        else if (rows == 64) gemm_gather_rounds_kernel<2, 4, 4><<<rb, 256, 0, s>>>(p);
+        else gemm_gather_rounds_kernel<2, 2, 4><<<rb, 256, 0, s>>>(p);
+      } else {
+        if (rows == 128) gemm_gather_rounds_kernel<1, 8, 2><<<rb, 256, 0, s>>>(p);
+        else if (rows == 64) gemm_gather_rounds_kernel<1, 4, 4><<<rb, 256, 0, s>>>(p);
+        else gemm_gather_rounds_kernel<1, 2, 4><<<rb, 256, 0, s>>>(p);
+      }
+    } else if (h->MBW == 2) { if (small) V3D_GG(2, 2); else V3D_GG(2, 8); }
     else { if (small) V3D_GG(1, 2); else V3D_GG(1, 8); }
 #undef V3D_GG
   }

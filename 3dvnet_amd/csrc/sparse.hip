@@ -36,16 +36,16 @@ __global__ void hash_insert_kernel(HashTable t, const int* __restrict__ coords, 
 
 // nbr[k][p] = row of (out_coords[p] + step * o_k) in the hashed map, o_k in {-1,0,1}^3 with
 // k = (ox+1) + 3 (oy+1) + 9 (oz+1);  conv: step = +ts_in, transposed conv: step = -ts_out.
+// One thread per (offset, output row): the 27 probes of a row were a loop in one thread -- 27 dependent probe chains in a row,
+// 40-50 us per launch whatever the level's size (2.8 k rows took as long as 60 k).  blockIdx.y = offset k, so a wave's stores
+// are 64 consecutive ints of column k.
 __global__ void neighbors_kernel(HashTable t, const int* __restrict__ out_coords, int n_out, int step,
                                  int* __restrict__ nbr) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
   if (i >= n_out) return;
-  const int b = out_coords[i * 4], x = out_coords[i * 4 + 1], y = out_coords[i * 4 + 2], z = out_coords[i * 4 + 3];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
-    nbr[(size_t)k * n_out + i] = hash_find(t, pack_key(b, x + step * ox, y + step * oy, z + step * oz));
-  }
+  const int4 c = *reinterpret_cast<const int4*>(out_coords + (size_t)i * 4);      // (batch, x, y, z)
+  const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+  nbr[(size_t)k * n_out + i] = hash_find(t, pack_key(c.x, c.y + step * ox, c.z + step * oy, c.w + step * oz));
 }
 
 // Sparse trilinear interpolation in two kernels:
@@ -142,7 +142,7 @@ extern "C" int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* 
   hipStream_t s = (hipStream_t)stream;
   HashTable t = table_view(const_cast<void*>(table), n_in);
   v3d::TimedScope ts("sparse_neighbors", s);
-  neighbors_kernel<<<(n_out + 255) / 256, 256, 0, s>>>(t, out_coords, n_out, step, nbr);
+  neighbors_kernel<<<dim3((n_out + 255) / 256, 27), 256, 0, s>>>(t, out_coords, n_out, step, nbr);
   V3D_CHECK_LAUNCH("neighbors_kernel");
   return V3D_OK;
 }

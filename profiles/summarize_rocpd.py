@@ -3,6 +3,7 @@
 
     python profiles/summarize_rocpd.py stats <results.db> <out.csv>          # --kernel-trace --stats
     python profiles/summarize_rocpd.py pmc   <results.db> <out.csv>          # --pmc COUNTER pass
+    python profiles/summarize_rocpd.py trace <results.db> <out.csv> [last_n] # --kernel-trace: the last n dispatches in order
 """
 import csv
 import re
@@ -27,6 +28,16 @@ def main():
             for name, calls, total, avg, pct in cur.execute(
                     'select name, total_calls, total_duration, average, percentage from top_kernels'):
                 w.writerow([short(name), calls, '%.1f' % (total), '%.2f' % (avg), '%.2f' % pct])
+        elif mode == 'trace':
+            n = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+            w.writerow(['start_us', 'duration_us', 'grid', 'workgroup', 'kernel'])
+            cols = [d[0] for d in cur.execute('select * from kernels limit 1').description]
+            grid = 'grid_size' if 'grid_size' in cols else 'grid_x' if 'grid_x' in cols else 'grid_size_x' if 'grid_size_x' in cols else '0'
+            wgs = 'workgroup_size' if 'workgroup_size' in cols else 'workgroup_x' if 'workgroup_x' in cols else 'workgroup_size_x' if 'workgroup_size_x' in cols else '0'
+            rows = list(cur.execute('select start, end - start, %s, %s, name from kernels order by start' % (grid, wgs)))[-n:]
+            t0 = rows[0][0] if rows else 0
+            for st, dur, g, wg, name in rows:
+                w.writerow(['%.1f' % ((st - t0) / 1e3), '%.1f' % (dur / 1e3), g, wg, short(name)])
         else:
             w.writerow(['kernel', 'counter', 'dispatches', 'avg_value_per_dispatch'])
             for name, ctr, n, avg in cur.execute(
