@@ -88,8 +88,15 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         k = ka = int(n_src_on_either_side)
     halo = k + ka          # images a chunk of reference views needs beyond its own (2k in the reference)
     with torch.no_grad():
-        ref_idx = torch.unique(batch.ref_src_edges[0])
+        # the edge list is sliced per chunk with boolean masks: on a host copy (one transfer per scene when the batch already
+        # lives on the device; masks on device tensors synchronise the host at every chunk)
+        scene_edges = batch.ref_src_edges.cpu()
+        ref_idx = torch.unique(scene_edges[0])
         n_ref_imgs = len(ref_idx)
+        # the reference's layout (dsets/dataset.py:133-137): the reference views are images k .. k + n_ref - 1.  Only then does a
+        # chunk of reference views [c0, c1) hold exactly c1 - c0 references, the count the device-side edge tables are built from
+        # (mvsnet.edges_to_csr); any other edge list takes the generic path (torch.unique on the device, one readback per chunk)
+        contiguous_refs = bool(torch.equal(ref_idx, torch.arange(k, k + n_ref_imgs, dtype=ref_idx.dtype)))
         r0, r1 = shard_range(n_ref_imgs, rank, world)
         n_local = r1 - r0
         has_feats = getattr(batch, 'features_quarter', None) is not None
@@ -102,12 +109,13 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             c1 = min(c0 + init_depth_batch, r1)
             ref_idx_start, ref_idx_end = c0 + k, c1 + k
             idx_start, idx_end = c0, c1 + halo
-            edges = utils.slice_edges(batch.ref_src_edges, ref_idx_start, ref_idx_end, 0) - idx_start
+            edges = utils.slice_edges(scene_edges, ref_idx_start, ref_idx_end, 0) - idx_start
             sl = Batch(None if batch.images is None else batch.images[idx_start:idx_end],
                        batch.rotmats[idx_start:idx_end], batch.tvecs[idx_start:idx_end],
                        batch.K[idx_start:idx_end], None, edges)
             sl.images_batch = torch.zeros(idx_end - idx_start, dtype=torch.long)
-            sl.n_ref = c1 - c0               # every image in [c0 + k, c1 + k) is a reference view of this chunk
+            if contiguous_refs:
+                sl.n_ref = c1 - c0           # every image in [c0 + k, c1 + k) is a reference view of this chunk
             if has_feats:
                 sl.features_quarter = batch.features_quarter[idx_start:idx_end]
                 if getattr(batch, 'features_half', None) is not None:
@@ -136,7 +144,8 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         rot = batch.rotmats[r0:r1 + halo].to(device)
         tv = batch.tvecs[r0:r1 + halo].to(device)
         K = batch.K[r0:r1 + halo].to(device)
-        edges_local = (utils.slice_edges(batch.ref_src_edges, r0 + k, r1 + k, 0) - r0).to(device)
+        edges_local_host = utils.slice_edges(scene_edges, r0 + k, r1 + k, 0) - r0
+        edges_local = edges_local_host.to(device)
         depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
         n_pix = depth_config['size'][0] * depth_config['size'][1]
         shard_rows = [(shard_range(n_ref_imgs, g, world)[1] - shard_range(n_ref_imgs, g, world)[0]) for g in range(world)]
@@ -146,8 +155,13 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         chunks = []
         for b0 in range(0, n_local, offset_batch):
             b1 = min(b0 + offset_batch, n_local)
-            e = utils.slice_edges(edges_local, b0 + k, b1 + k, 0) - b0
-            chunks.append((b0, b1, e, edges_to_csr(e) if e.is_cuda else None))
+            e = (utils.slice_edges(edges_local_host, b0 + k, b1 + k, 0) - b0).to(device)
+            # every image in [b0 + k, b1 + k) of the chunk's slice is a reference view: the device kernel builds the tables
+            if e.is_cuda and contiguous_refs:
+                csr = edges_to_csr(e, n_ref=b1 - b0, n_img=b1 - b0 + halo)
+            else:
+                csr = edges_to_csr(e) if e.is_cuda else None
+            chunks.append((b0, b1, e, csr))
         for offsets in offsets_list:
             xs = net.model_scene(all_depth, depth_batch, feats_local, rot, tv, K, edges_local,
                                  gather_fn=gather_fn)

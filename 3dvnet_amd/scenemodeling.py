@@ -359,6 +359,13 @@ class SparseUNet(nn.Module):
             x_batch = lv.coords[:, 0].type_as(batch)
             x_pts = x_idx * res + pts_min[x_batch]
             lv.feats = xf
+            # scatter(x.pts, x.batch, reduce='min') of the interpolation (refinement.py:33), here where the number of batch
+            # elements is known: the decoder would have to read it back from the device in front of its first launch
+            if n_batches == 1:
+                min_pts = x_pts.amin(dim=0, keepdim=True)
+            else:
+                sel = x_batch[None, :, None] == torch.arange(n_batches, device=x_batch.device)[:, None, None]
+                min_pts = torch.where(sel, x_pts[None], x_pts.new_full((), float('inf'))).amin(dim=1)
             out_info.append({'feats': xf, 'pts': x_pts, 'res': lv.stride * res, 'batch': x_batch,
-                             'idx': x_idx, 'stride': lv.stride, 'sparse': lv})
+                             'idx': x_idx, 'stride': lv.stride, 'sparse': lv, '_min_pts': min_pts})
         return out_info

@@ -353,6 +353,7 @@ def bench_scene(args, rank, world, dev, dist):
         gt = gt + 0.02 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(7))
         return bb, gt
     b, gt = make(refs, 1237)
+    b = b.to(dev)          # inputs resident in HBM before the timed region (features = the backbone's output, cameras, edges)
     gt = gt.to(dev)
     sds = dict(cr=syn.costregnet_weights(seed=0, sharpen=200.0), pn=syn.pointnet_weights(), un=syn.sparse_unet_weights(),
                dec=syn.decoder_weights(sharpen=50.0))

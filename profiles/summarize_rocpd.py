@@ -4,6 +4,7 @@
     python profiles/summarize_rocpd.py stats <results.db> <out.csv>          # --kernel-trace --stats
     python profiles/summarize_rocpd.py pmc   <results.db> <out.csv>          # --pmc COUNTER pass
     python profiles/summarize_rocpd.py trace <results.db> <out.csv> [last_n] # --kernel-trace: the last n dispatches in order
+    python profiles/summarize_rocpd.py gaps  <results.db> <out.csv> [last_n] # idle time between the last n dispatches, by the kernel that follows the gap
 """
 import csv
 import re
@@ -28,6 +29,20 @@ def main():
             for name, calls, total, avg, pct in cur.execute(
                     'select name, total_calls, total_duration, average, percentage from top_kernels'):
                 w.writerow([short(name), calls, '%.1f' % (total), '%.2f' % (avg), '%.2f' % pct])
+        elif mode == 'gaps':
+            n = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+            rows = list(cur.execute('select start, end, name from kernels order by start'))[-n:]
+            span = rows[-1][1] - rows[0][0]
+            busy = sum(e - st for st, e, _ in rows)
+            by = {}
+            for (st0, e0, n0), (st1, e1, n1) in zip(rows, rows[1:]):
+                g = max(0, st1 - e0)
+                k = short(n1)
+                a = by.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += g
+            w.writerow(['span_us %.1f busy_us %.1f idle_us %.1f over %d dispatches' % (span / 1e3, busy / 1e3, (span - busy) / 1e3, len(rows)), '', ''])
+            w.writerow(['kernel_after_gap', 'gaps', 'idle_us'])
+            for k, (c, g) in sorted(by.items(), key=lambda kv: -kv[1][1])[:40]:
+                w.writerow([k, c, '%.1f' % (g / 1e3)])
         elif mode == 'trace':
             n = int(sys.argv[4]) if len(sys.argv) > 4 else 200
             w.writerow(['start_us', 'duration_us', 'grid', 'workgroup', 'kernel'])
