@@ -162,9 +162,16 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             else:
                 csr = edges_to_csr(e) if e.is_cuda else None
             chunks.append((b0, b1, e, csr))
+        scene_csr = edges_to_csr(edges_local, n_ref=n_local, n_img=n_local + halo) \
+            if edges_local.is_cuda and contiguous_refs else None
+        # what this driver knows and a bare ``net.model_scene`` would have to read back from the device: the edge tables, the
+        # number of batch elements (one scene: depth_batch is all zeros); the hash-table range checks wait until the end.
+        # (Only for nets that take these hints: the tests run this driver over a CPU net with the reference's plain signature.)
+        unet = getattr(net, 'sparse_conv', None)
+        hints = dict(csr=scene_csr, n_batches=1, defer_checks=True) if hasattr(unet, 'flush_checks') else {}
         for offsets in offsets_list:
             xs = net.model_scene(all_depth, depth_batch, feats_local, rot, tv, K, edges_local,
-                                 gather_fn=gather_fn)
+                                 gather_fn=gather_fn, **hints)
             for offset in offsets:
                 for b0, b1, e, csr in chunks:
                     kw = {} if csr is None else {'csr': csr}
@@ -172,6 +179,8 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                                                           feats_local[b0:b1 + halo], rot[b0:b1 + halo],
                                                           tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3,
                                                           **kw)
+        if hints:
+            unet.flush_checks()             # hash-table range checks of both scene models: one wait here, not two in between
         if upsample:
             # ---- stage 3 (:101-125): plane grid -> 1/4 -> 1/2 -> full resolution, guided by the quarter /
             # half features and the image of each reference view (images k .. k + n_local of the halo'd slice)

@@ -102,20 +102,23 @@ class PL3DVNet(nn.Module):
         return depth_pred, depth_batch, feats_half, feats_quarter, features_eighth, ref_idx
 
     def construct_feature_rich_pointcloud(self, depth_pred, depth_batch, img_feats, rotmats, tvecs, K,
-                                          ref_src_edges):
-        """lightningmodel.py:132-174 -> (pts [Np,3], pts_feat [Np,C], pts_batch [Np])."""
+                                          ref_src_edges, csr=None):
+        """lightningmodel.py:132-174 -> (pts [Np,3], pts_feat [Np,C], pts_batch [Np]).  ``csr``: as in run_pointflow."""
         n_imgs = depth_pred.shape[0]
         pts, var = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
-                                        self.hparams.img_size, workspace=self._ws)
+                                        self.hparams.img_size, workspace=self._ws, csr=csr)
         pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, depth_pred.shape[1] * depth_pred.shape[2]).reshape(-1)
         return pts.view(-1, 3), var.view(-1, var.shape[-1]), pts_batch
 
     def model_scene(self, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
-                    return_pts=False, gather_fn=None):
+                    return_pts=False, gather_fn=None, csr=None, n_batches=None, defer_checks=False):
         """lightningmodel.py:176-185.  ``gather_fn`` (multi-GPU): all-gathers the local
-        feature-rich point cloud in view order before the replicated voxelise / PointNet / U-Net."""
+        feature-rich point cloud in view order before the replicated voxelise / PointNet / U-Net.  ``csr``: the edge tables
+        of ``ref_src_edges`` when the caller already holds them; ``n_batches``: the number of batch elements (scenes) when
+        the caller knows it -- otherwise the U-Net reads ``max(batch) + 1`` back from the device (scenemodeling.py:221);
+        ``defer_checks``: the caller will call ``self.sparse_conv.flush_checks()`` before it uses the results."""
         pts, pts_feat, pts_batch = self.construct_feature_rich_pointcloud(depth_pred, depth_batch, img_feats,
-                                                                          rotmats, tvecs, K, ref_src_edges)
+                                                                          rotmats, tvecs, K, ref_src_edges, csr=csr)
         if gather_fn is not None:
             pts, pts_feat, pts_batch = gather_fn(pts, pts_feat, pts_batch)
         anchor_pts, anchor_idx3d, anchor_batch, anchor_pts_edges = utils.voxelize(pts, pts_batch, self.edge_len)
@@ -123,7 +126,8 @@ class PL3DVNet(nn.Module):
         x = torch.cat((pts[anchor_pts_edges[1]] - anchor_pts[anchor_pts_edges[0]],
                        pts_feat[anchor_pts_edges[1]]), dim=1)
         x = self.pointnet(x, anchor_pts_edges[0], n_anchors)
-        xs = self.sparse_conv(x, anchor_pts, anchor_idx3d, anchor_batch, self.edge_len)
+        xs = self.sparse_conv(x, anchor_pts, anchor_idx3d, anchor_batch, self.edge_len, n_batches=n_batches,
+                              defer_checks=defer_checks)
         return (xs, pts) if return_pts else xs
 
     def run_pointflow(self, xs, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,

@@ -303,7 +303,13 @@ class SparseUNet(nn.Module):
         y = self._conv(packs[0], x, nbr, n, blk.n1.gn.eps)
         return self._conv(packs[1], y, nbr, n, blk.n2.gn.eps, residual=x)
 
-    def forward(self, F, pts, idx, batch, res):
+    def flush_checks(self):
+        """Raise for every level built since the last call whose hash table dropped rows (``SparseLevel.check``)."""
+        pending, self._pending_checks = getattr(self, '_pending_checks', []), []
+        for lv in pending:
+            lv.check()
+
+    def forward(self, F, pts, idx, batch, res, n_batches=None, defer_checks=False):
         if not F.is_cuda:
             raise _lib.V3DLibraryError('SparseUNet: tensors must live on a HIP device (no CPU fallback)')
         self._dev = F.device
@@ -338,9 +344,14 @@ class SparseUNet(nn.Module):
             out.append((tgt, x))
 
         out_info = []
-        n_batches = int(torch.max(batch).item()) + 1                                   # scenemodeling.py:221
-        for lv in levels:       # the host is synchronised here anyway: surface rows the hash tables refused (range check)
-            lv.check()
+        if n_batches is None:
+            n_batches = int(torch.max(batch).item()) + 1                               # scenemodeling.py:221
+        # rows the hash tables refused (range check): read the status words now (one readback each, after the last kernel of
+        # the forward: the host cannot run ahead into the caller's next launches), or -- a driver that calls flush_checks()
+        # before it uses the results -- at the next point where the host waits for the device anyway
+        self._pending_checks = getattr(self, '_pending_checks', []) + list(levels)
+        if not defer_checks:
+            self.flush_checks()
         # scenemodeling.py:222-231 per batch element b: pts_min = pts[batch == b][0] - idx[batch == b][0] * res and
         # x_pts = x_idx * res + pts_min -- the same numbers without a boolean-mask gather (and its host synchronisation) per
         # level and batch element: the first row of every batch element.  With few batch elements that is the first True of a
