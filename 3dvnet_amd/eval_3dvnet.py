@@ -93,10 +93,13 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         scene_edges = batch.ref_src_edges.cpu()
         ref_idx = torch.unique(scene_edges[0])
         n_ref_imgs = len(ref_idx)
-        # the reference's layout (dsets/dataset.py:133-137): the reference views are images k .. k + n_ref - 1.  Only then does a
-        # chunk of reference views [c0, c1) hold exactly c1 - c0 references, the count the device-side edge tables are built from
-        # (mvsnet.edges_to_csr); any other edge list takes the generic path (torch.unique on the device, one readback per chunk)
-        contiguous_refs = bool(torch.equal(ref_idx, torch.arange(k, k + n_ref_imgs, dtype=ref_idx.dtype)))
+        # The reference's layout (dsets/dataset.py:133-137): the reference views are images k .. k + n_ref - 1.  The chunking
+        # below (like eval-3dvnet.py:42-52) addresses reference views by that rule, and a chunk [c0, c1) then holds exactly
+        # c1 - c0 of them -- the count the device-side edge tables are built from (mvsnet.edges_to_csr) without a readback.
+        if not torch.equal(ref_idx, torch.arange(k, k + n_ref_imgs, dtype=ref_idx.dtype)):
+            raise ValueError('process_scene: the reference views of ref_src_edges must be images %d .. %d (dataset layout, '
+                             'n_src_on_either_side = %d before); got %s' % (k, k + n_ref_imgs - 1, k, ref_idx.tolist()))
+        contiguous_refs = True
         r0, r1 = shard_range(n_ref_imgs, rank, world)
         n_local = r1 - r0
         has_feats = getattr(batch, 'features_quarter', None) is not None

@@ -230,6 +230,17 @@ def test_hip_driver_matches_oracle_driver(cuda):
     assert float(m['abs_rel']) < 2e-5 and float(m['d_125']) == pytest.approx(1.0) and float(m['rmse']) < 1e-4
 
 
+def test_driver_rejects_an_edge_list_that_breaks_the_dataset_layout():
+    """The driver addresses reference views as images k .. k + n - 1 (eval-3dvnet.py:42-52) and builds its device-side edge
+    tables from a chunk's reference count: an edge list in which a reference view has no edges would be processed with the
+    wrong count.  It is refused on the host before anything runs."""
+    drv = v3d('eval_3dvnet')
+    b = make_scene()
+    b.ref_src_edges = b.ref_src_edges[:, b.ref_src_edges[0] != 3]
+    with pytest.raises(ValueError, match='reference views'):
+        drv.process_scene(b, OracleNet(*weights(), IMG, 0.16), 1, torch.device('cpu'), CFG, OFFSETS, 18, 16)
+
+
 @pytest.mark.gpu
 def test_bench_line_schema_and_checks(cuda):
     """`bench.py` end to end on a small batch (8 views, 2 steps): ONE JSON line with the contract's fields, both operand

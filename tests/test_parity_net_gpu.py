@@ -2,6 +2,8 @@
 against a dense conv3d recipe with ONE-HOT kernels (a wrong offset <-> weight-index convention cannot hide behind random
 weights), stage 3 of the scene driver on device, re-packing of cached weights, and the range checks of the fixed-size
 device tables."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -500,3 +502,36 @@ def test_segment_csr_and_max_equal_scatter_amax(n, n_seg, N, cuda):
     assert torch.equal(out.cpu(), ref)
     if n_seg > 3:
         assert bool(torch.isinf(out[2]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,C,N', [(2816, 128, 128), (13500, 64, 64), (777, 32, 128), (33, 64, 32)])
+def test_gather_gemm_rounds_kernel_bit_identical_to_one_step_kernel(M, C, N, cuda):
+    """The small-M gather-GEMM in rounds of four (offset, K chunk) steps (gemm_gather_rounds_kernel: sparse convolutions) keeps the
+    step order and the MFMA order per accumulator of gemm_gather_kernel: same bits, with absent neighbours, whole absent
+    offsets (skipped segments), a ragged last tile, GroupNorm + residual + ReLU in the epilogue."""
+    sm = v3d('scenemodeling')
+    g = torch.Generator().manual_seed(M)
+    w = torch.randn(27, C, N, generator=g) * 0.05
+    gn_w, gn_b = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    pk = sm.PackedGemm(w, C * N, 1, N, 27, N, C, gn_w=gn_w, gn_b=gn_b)
+    x = torch.randn(M, C, generator=g).to(cuda)
+    nbr = (torch.arange(M)[None, :] + torch.randint(-50, 51, (27, M), generator=g)).clamp_(0, M - 1)
+    nbr[torch.rand(27, M, generator=g) < 0.6] = -1
+    nbr[5] = -1                                    # an offset no row of any tile has
+    nbr[13] = torch.arange(M)
+    nbr = nbr.to(torch.int32).to(cuda).contiguous()
+    res = torch.randn(M, N, generator=g).to(cuda)
+    outs = {}
+    for tag, env in (('rounds', None), ('one_step', '1')):
+        if env is None:
+            os.environ.pop('V3D_GEMM_NO_ROUNDS', None)
+        else:
+            os.environ['V3D_GEMM_NO_ROUNDS'] = env
+        try:
+            outs[tag] = pk(M, [x] * 27, idxs=[nbr[k] for k in range(27)], use_gn=True, residual=res, relu_out=True)
+        finally:
+            os.environ.pop('V3D_GEMM_NO_ROUNDS', None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs['rounds']).all()
+    assert torch.equal(outs['rounds'], outs['one_step'])
