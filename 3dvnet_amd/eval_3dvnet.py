@@ -99,7 +99,6 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         if not torch.equal(ref_idx, torch.arange(k, k + n_ref_imgs, dtype=ref_idx.dtype)):
             raise ValueError('process_scene: the reference views of ref_src_edges must be images %d .. %d (dataset layout, '
                              'n_src_on_either_side = %d before); got %s' % (k, k + n_ref_imgs - 1, k, ref_idx.tolist()))
-        contiguous_refs = True
         r0, r1 = shard_range(n_ref_imgs, rank, world)
         n_local = r1 - r0
         has_feats = getattr(batch, 'features_quarter', None) is not None
@@ -117,8 +116,7 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                        batch.rotmats[idx_start:idx_end], batch.tvecs[idx_start:idx_end],
                        batch.K[idx_start:idx_end], None, edges)
             sl.images_batch = torch.zeros(idx_end - idx_start, dtype=torch.long)
-            if contiguous_refs:
-                sl.n_ref = c1 - c0           # every image in [c0 + k, c1 + k) is a reference view of this chunk
+            sl.n_ref = c1 - c0               # every image in [c0 + k, c1 + k) is a reference view of this chunk
             if has_feats:
                 sl.features_quarter = batch.features_quarter[idx_start:idx_end]
                 if getattr(batch, 'features_half', None) is not None:
@@ -160,13 +158,9 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             b1 = min(b0 + offset_batch, n_local)
             e = (utils.slice_edges(edges_local_host, b0 + k, b1 + k, 0) - b0).to(device)
             # every image in [b0 + k, b1 + k) of the chunk's slice is a reference view: the device kernel builds the tables
-            if e.is_cuda and contiguous_refs:
-                csr = edges_to_csr(e, n_ref=b1 - b0, n_img=b1 - b0 + halo)
-            else:
-                csr = edges_to_csr(e) if e.is_cuda else None
-            chunks.append((b0, b1, e, csr))
+            chunks.append((b0, b1, e, edges_to_csr(e, n_ref=b1 - b0, n_img=b1 - b0 + halo) if e.is_cuda else None))
         scene_csr = edges_to_csr(edges_local, n_ref=n_local, n_img=n_local + halo) \
-            if edges_local.is_cuda and contiguous_refs else None
+            if edges_local.is_cuda else None
         # what this driver knows and a bare ``net.model_scene`` would have to read back from the device: the edge tables, the
         # number of batch elements (one scene: depth_batch is all zeros); the hash-table range checks wait until the end.
         # (Only for nets that take these hints: the tests run this driver over a CPU net with the reference's plain signature.)
