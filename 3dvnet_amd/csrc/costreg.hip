@@ -158,7 +158,10 @@ struct ConvCfg {
   static_assert(LDS_FLOATS * 4 <= 64 * 1024, "LDS tile");
 };
 
-template <class C>
+// VEC (stride-1 layers in prefetch mode, tile and volume widths multiples of 4): the halo'd rows are fetched as aligned float4s
+// (16 lanes per row, [ix0 - 3, ix0 + 61)) instead of one float per lane -- the CU's vector-memory path charges a 4-byte-per-lane
+// wave instruction twice the cycles of a 16-byte one for a quarter of the bytes.
+template <class C, bool VEC>
 __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) {
   constexpr int MODE = C::MODE;
   __shared__ float xs[C::LDS_FLOATS];
@@ -235,23 +238,53 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   __syncthreads();
   const int myrow0 = wave * C::RPW + lrow;        // this lane's rows: myrow0 + it * 4 * RPW
 
-  float pre[C::PF ? C::NIT : 1], wreg[C::PF ? C::NWIT : 1];
+  constexpr int NITV = (C::ROWS + 15) / 16;     // VEC: 16 rows per workgroup iteration
+  const int vj = tid & 15, vrow = tid >> 4;
+  const int vgx = ix0 - 3 + 4 * vj;
+  const bool vin = vgx >= 0 && vgx + 3 < p.Wi && 4 * vj - 3 < C::IW;
+  float pre[(C::PF && !VEC) ? C::NIT : 1], wreg[C::PF ? C::NWIT : 1];
+  f32x4 pre4[(C::PF && VEC) ? NITV : 1];
   auto pf_issue = [&](int chunk) {
-    const float* inc = inb + (size_t)chunk * C::CK * in_plane + lx;
+    if constexpr (VEC) {
+      const float* incv = inb + (size_t)chunk * C::CK * in_plane + (4 * vj - 3);
 #pragma unroll
-    for (int it = 0; it < C::NIT; ++it) {
-      const int g = rowg[myrow0 + it * 4 * C::RPW];
-      pre[it] = (g != kRowOob && xin) ? inc[g] : 0.f;
+      for (int it = 0; it < NITV; ++it) {
+        const int r = it * 16 + vrow;
+        const int g = rowg[min(r, C::TROWS - 1)];
+        pre4[it] = (r < C::ROWS && g != kRowOob && vin) ? *reinterpret_cast<const f32x4*>(incv + g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const float* inc = inb + (size_t)chunk * C::CK * in_plane + lx;
+#pragma unroll
+      for (int it = 0; it < C::NIT; ++it) {
+        const int g = rowg[myrow0 + it * 4 * C::RPW];
+        pre[it] = (g != kRowOob && xin) ? inc[g] : 0.f;
+      }
     }
     const float* wc = p.wp + (size_t)chunk * C::WCH + tid;
 #pragma unroll
     for (int i = 0; i < C::NWIT; ++i) wreg[i] = (i * 256 + tid < C::WCH) ? wc[i * 256] : 0.f;
   };
   auto pf_commit = [&]() {
+    if constexpr (VEC) {
 #pragma unroll
-    for (int it = 0; it < C::NIT; ++it) {
-      const int d = rowd[myrow0 + it * 4 * C::RPW];
-      if (d >= 0 && xok) xs[d + lx] = pre[it];
+      for (int it = 0; it < NITV; ++it) {
+        const int r = it * 16 + vrow;
+        const int d = rowd[min(r, C::TROWS - 1)];
+        if (r < C::ROWS && d >= 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int x = 4 * vj - 3 + e;
+            if (x >= 0 && x < C::IW) xs[d + x] = pre4[it][e];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < C::NIT; ++it) {
+        const int d = rowd[myrow0 + it * 4 * C::RPW];
+        if (d >= 0 && xok) xs[d + lx] = pre[it];
+      }
     }
 #pragma unroll
     for (int i = 0; i < C::NWIT; ++i)
@@ -1708,7 +1741,15 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
               "conv3d: input volume too large for 32-bit tile offsets");
   {
     v3d::TimedScope ts(name, s);
-    conv3d_mfma_kernel<C><<<(unsigned)blocks, 256, 0, s>>>(p);
+    // (conv0 only: on conv2 the 40 extra staging registers cost more than the loads save: 0.37 -> 0.41 ms)
+    constexpr bool kVecOk = C::MODE == kConvS1Pair && C::PF && C::TW % 4 == 0 && C::IW <= 61;
+    const bool vec = kVecOk && Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && !getenv("V3D_CONV_NO_VEC");
+    if constexpr (kVecOk) {
+      if (vec) conv3d_mfma_kernel<C, true><<<(unsigned)blocks, 256, 0, s>>>(p);
+      else conv3d_mfma_kernel<C, false><<<(unsigned)blocks, 256, 0, s>>>(p);
+    } else {
+      conv3d_mfma_kernel<C, false><<<(unsigned)blocks, 256, 0, s>>>(p);
+    }
   }
   V3D_CHECK_LAUNCH("conv3d_mfma_kernel");
   return V3D_OK;
