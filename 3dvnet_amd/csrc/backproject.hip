@@ -77,34 +77,64 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
     }
     __syncthreads();
     if (ec == 0) v3d::world_point(s_ref, xf, yf, dep, X, Y, Z);   // (lightningmodel.py:142-144,202-204)
-    if (!active) continue;
-    for (int e = 0; e < nec; ++e) {
-      float ix, iy;
-      v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ix > -1.f && ix < Wfm1 + 1.f && iy > -1.f && iy < Hfm1 + 1.f) {
-        const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
-        const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
-        const float w00 = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f, w01 = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
-        const float w10 = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f, w11 = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
-        const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
-        const float* fb = p.featT + (size_t)s_base[e] * C + cg * 4;
-        const float4 v00 = *reinterpret_cast<const float4*>(fb + (yi0 * p.Wf + xi0) * C);
-        const float4 v01 = *reinterpret_cast<const float4*>(fb + (yi0 * p.Wf + xi1) * C);
-        const float4 v10 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi0) * C);
-        const float4 v11 = *reinterpret_cast<const float4*>(fb + (yi1 * p.Wf + xi1) * C);
-        // F.grid_sample's tap order as an FMA chain: ((nw + ne) + sw) + se (same sequence as the warp kernels)
-        s.x = v3d::mul_rn(v00.x, w00); s.y = v3d::mul_rn(v00.y, w00); s.z = v3d::mul_rn(v00.z, w00); s.w = v3d::mul_rn(v00.w, w00);
-        s.x = __builtin_fmaf(v01.x, w01, s.x); s.y = __builtin_fmaf(v01.y, w01, s.y);
-        s.z = __builtin_fmaf(v01.z, w01, s.z); s.w = __builtin_fmaf(v01.w, w01, s.w);
-        s.x = __builtin_fmaf(v10.x, w10, s.x); s.y = __builtin_fmaf(v10.y, w10, s.y);
-        s.z = __builtin_fmaf(v10.z, w10, s.z); s.w = __builtin_fmaf(v10.w, w10, s.w);
-        s.x = __builtin_fmaf(v11.x, w11, s.x); s.y = __builtin_fmaf(v11.y, w11, s.y);
-        s.z = __builtin_fmaf(v11.z, w11, s.z); s.w = __builtin_fmaf(v11.w, w11, s.w);
+    // The LP lanes of a sample need the same projection for every edge.  Lane cg projects edges cg, cg + LP, ... of the chunk
+    // and the group reads the tap weights / offsets of edge e from lane e % LP (ds_bpermute): the pinned projection chain
+    // (~80 VALU instructions per edge) runs once per sample instead of LP times.  (Lanes of an inactive sample run along with
+    // pixel 0: the shuffles are wave-wide.)
+    constexpr int kEPL = (kMaxE + LP - 1) / LP;                   // edges a lane projects per chunk
+    float tw[kEPL][4];
+    int to[kEPL][4];
+#pragma unroll
+    for (int q = 0; q < kEPL; ++q) {
+      const int e = cg + q * LP;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { tw[q][k] = 0.f; to[q][k] = k == 0 ? -1 : 0; }      // offset 0 of tap 0 < 0: sample outside the image
+      if (e < nec) {
+        float ix, iy;
+        v3d::sample_position(s_P[e], X, Y, Z, Wm1, rWm1, Hm1, rHm1, Wfm1, Hfm1, ix, iy);
+        if (ix > -1.f && ix < Wfm1 + 1.f && iy > -1.f && iy < Hfm1 + 1.f) {
+          const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
+          const bool vx0 = x0 >= 0.f, vx1 = x1 <= Wfm1, vy0 = y0 >= 0.f, vy1 = y1 <= Hfm1;
+          tw[q][0] = (vx0 && vy0) ? (x1 - ix) * (y1 - iy) : 0.f; tw[q][1] = (vx1 && vy0) ? (ix - x0) * (y1 - iy) : 0.f;
+          tw[q][2] = (vx0 && vy1) ? (x1 - ix) * (iy - y0) : 0.f; tw[q][3] = (vx1 && vy1) ? (ix - x0) * (iy - y0) : 0.f;
+          const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+          const int base = s_base[e];
+          to[q][0] = (base + yi0 * p.Wf + xi0) * C; to[q][1] = (base + yi0 * p.Wf + xi1) * C;
+          to[q][2] = (base + yi1 * p.Wf + xi0) * C; to[q][3] = (base + yi1 * p.Wf + xi1) * C;
+        }
       }
-      acc_s.x += s.x; acc_s.y += s.y; acc_s.z += s.z; acc_s.w += s.w;
-      acc_q.x = __builtin_fmaf(s.x, s.x, acc_q.x); acc_q.y = __builtin_fmaf(s.y, s.y, acc_q.y);
-      acc_q.z = __builtin_fmaf(s.z, s.z, acc_q.z); acc_q.w = __builtin_fmaf(s.w, s.w, acc_q.w);
+    }
+    const int lane0 = (tid & 63) & ~(LP - 1);
+    const float* const fb = p.featT + cg * 4;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+      if (e < nec) {                                              // wave-uniform
+        float w[4];
+        int o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          w[k] = __shfl(tw[e / LP][k], lane0 + e % LP, 64);
+          o[k] = __shfl(to[e / LP][k], lane0 + e % LP, 64);
+        }
+        const bool inside = o[0] >= 0;                            // outside: nothing is sampled (grid_sample's zero padding)
+        const float4 v00 = *reinterpret_cast<const float4*>(fb + max(o[0], 0));
+        const float4 v01 = *reinterpret_cast<const float4*>(fb + o[1]);
+        const float4 v10 = *reinterpret_cast<const float4*>(fb + o[2]);
+        const float4 v11 = *reinterpret_cast<const float4*>(fb + o[3]);
+        // F.grid_sample's tap order as an FMA chain: ((nw + ne) + sw) + se (same sequence as the warp kernels)
+        float4 s;
+        s.x = v3d::mul_rn(v00.x, w[0]); s.y = v3d::mul_rn(v00.y, w[0]); s.z = v3d::mul_rn(v00.z, w[0]); s.w = v3d::mul_rn(v00.w, w[0]);
+        s.x = __builtin_fmaf(v01.x, w[1], s.x); s.y = __builtin_fmaf(v01.y, w[1], s.y);
+        s.z = __builtin_fmaf(v01.z, w[1], s.z); s.w = __builtin_fmaf(v01.w, w[1], s.w);
+        s.x = __builtin_fmaf(v10.x, w[2], s.x); s.y = __builtin_fmaf(v10.y, w[2], s.y);
+        s.z = __builtin_fmaf(v10.z, w[2], s.z); s.w = __builtin_fmaf(v10.w, w[2], s.w);
+        s.x = __builtin_fmaf(v11.x, w[3], s.x); s.y = __builtin_fmaf(v11.y, w[3], s.y);
+        s.z = __builtin_fmaf(v11.z, w[3], s.z); s.w = __builtin_fmaf(v11.w, w[3], s.w);
+        if (!inside) s = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc_s.x += s.x; acc_s.y += s.y; acc_s.z += s.z; acc_s.w += s.w;
+        acc_q.x = __builtin_fmaf(s.x, s.x, acc_q.x); acc_q.y = __builtin_fmaf(s.y, s.y, acc_q.y);
+        acc_q.z = __builtin_fmaf(s.z, s.z, acc_q.z); acc_q.w = __builtin_fmaf(s.w, s.w, acc_q.w);
+      }
     }
   }
   if (!active) return;
@@ -135,6 +165,8 @@ extern "C" int v3d_backproject_variance_f32(const float* depth, const float* fea
   V3D_REQUIRE(depth && feat && K && R && t && ref_img && edge_ofs && edge_src && pts && var && workspace,
               V3D_ERR_BAD_ARG, "v3d_backproject_variance_f32: null pointer argument");
   V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED, "v3d_backproject_variance_f32: C=%d unsupported", C);
+  V3D_REQUIRE((long long)n_img * Hf * Wf * C < (1ll << 31), V3D_ERR_BAD_SHAPE,
+              "v3d_backproject_variance_f32: feature tensor too large for 32-bit tap offsets");
   V3D_REQUIRE(n_img > 0 && n_ref > 0 && n_edges >= 0 && H > 1 && W > 1 && h > 0 && w > 0 && n_half >= 0,
               V3D_ERR_BAD_SHAPE, "v3d_backproject_variance_f32: bad shape");
   V3D_REQUIRE(workspace_bytes >= v3d_backproject_workspace_bytes(n_img, C, Hf, Wf),

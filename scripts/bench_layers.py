@@ -20,9 +20,11 @@ def main():
     ap.add_argument('--tag', default='')
     ap.add_argument('--precision', default='split_bf16', choices=['split_bf16', 'fp32'])
     args = ap.parse_args()
+    libm = importlib.import_module('3dvnet_amd._lib')
+    if os.environ.get('V3D_LIB_OVERRIDE'):      # a variant build (scripts/build_variant.py)
+        libm.LIB_PATH = os.environ['V3D_LIB_OVERRIDE']
     syn = importlib.import_module('3dvnet_amd.synthetic')
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
-    libm = importlib.import_module('3dvnet_amd._lib')
     Batch = importlib.import_module('3dvnet_amd.batch').Batch
     dev = torch.device('cuda:0')
     inp = syn.make_costvolume_inputs('cfg2', n_ref=args.refs)
