@@ -105,7 +105,7 @@ constexpr int kFMBW = 2, kFMB = 4 * kFMBW;      // per wave: kFNB column blocks 
 constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap, K chunk) of a layer's weight image
 constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
 constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
-constexpr size_t kFConstBytes = (3 * 128 + 128 * 3 + 4) * 4;                // biases of the three layers, head weights, head bias
+constexpr size_t kFConstBytes = (3 * 128 + 128 * 3 + 4 + 8) * 4;            // biases of the three layers, head weights, head bias, offset values
 constexpr size_t kFUsedLdsBytes = 2 * kFActBytes + kFConstBytes;
 // Requested LDS: 80 KB = two workgroups per CU (two waves per SIMD: the kernel's 186 VGPRs + 50 AGPRs allow exactly that).
 //
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
   for (int i = tid; i < 3 * kFH; i += kFThreads) cbias[i] = (i < kFH ? p.bias[0] : i < 2 * kFH ? p.bias[1] : p.bias[2])[i % kFH];
   for (int i = tid; i < 3 * kFH; i += kFThreads) chead[i] = p.head_w[i];
   if (tid == 0) chead[3 * kFH] = p.head_b[0];
+  if (tid < 8) chead[3 * kFH + 4 + tid] = (p.vals && tid < p.n_hyp) ? p.vals[tid] : 0.f;      // offset values of the expectation
   // bias + ReLU of this wave's 32 channels x 64 rows -> split -> LDS activation buffer (B-fragment order, 16-byte slots of 8
   // channels, slot index XOR-ed with the row so that the 16 row-lanes of a ds_read_b128 hit 16 different slots)
   auto store_act = [&](u32x4* dst, const float* bias) __attribute__((always_inline)) {
@@ -721,14 +722,22 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
       }
       if (hl32 == 0 && hpt < kFPts && pt0 + hpt < p.n_pts) {
         float m = -INFINITY;
-        for (int h = 0; h < n_hyp; ++h) m = fmaxf(m, score[h]);
-        float sum = 0.f;
-        for (int h = 0; h < n_hyp; ++h) sum += expf(score[h] - m);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) if (h < n_hyp) m = fmaxf(m, score[h]);
+        float ex[8], sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {                 // every exponential once; same values, same summation order as before
+          ex[h] = h < n_hyp ? expf(score[h] - m) : 0.f;
+          if (h < n_hyp) sum += ex[h];
+        }
         float e = 0.f;
-        for (int h = 0; h < n_hyp; ++h) {
-          const float pr = expf(score[h] - m) / sum;
-          p.preds[(size_t)(pt0 + hpt) * n_hyp + h] = pr;
-          if (p.vals) e += p.vals[h] * pr;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          if (h < n_hyp) {
+            const float pr = ex[h] / sum;
+            p.preds[(size_t)(pt0 + hpt) * n_hyp + h] = pr;
+            e += chead[3 * kFH + 4 + h] * pr;         // (offset values parked in LDS: a global load per hypothesis sat in this chain)
+          }
         }
         if (p.expect) p.expect[pt0 + hpt] = e;
       }
