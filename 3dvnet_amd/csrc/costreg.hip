@@ -1277,11 +1277,11 @@ constexpr int PT_CK = 2;
 constexpr int PT_ID = PT_D + 2, PT_IH = PT_H + 2, PT_IW = PT_W + 2, PT_RS = 72;
 constexpr int PT_PLANE = PT_ID * PT_IH * PT_RS;
 
-// VEC (W a multiple of 4): the halo'd rows are staged as aligned float4s [ox0 - 4, ox0 + 60) -- 16 lanes per row, 16 rows per
-// workgroup instruction round -- and the window of an output starts 3 floats into the LDS row.  With one float per lane (58 of 64
-// lanes, 232 bytes per wave instruction at the 4-byte rate of the CU's vector-memory path) the staging loads were the kernel:
-// 0.62 ms per 64 views at cfg2 against 0.1 ms of arithmetic.
-template <int CIN, bool VEC>
+// The halo'd rows are staged as aligned float4s [ox0 - 4, ox0 + 60) -- 16 lanes per row, 16 rows per workgroup instruction
+// round (the regulariser's volumes are multiples of 8 wide, v3d_costreg_depth_f32) -- and the window of an output starts 3
+// floats into the LDS row.  With one float per lane (58 of 64 lanes, 232 bytes per wave instruction at the 4-byte rate of the
+// CU's vector-memory path) the staging loads were the kernel: 0.62 ms per 64 views at cfg2 against 0.1 ms of arithmetic.
+template <int CIN>
 __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ in,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
@@ -1301,45 +1301,40 @@ __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict_
 
   // compute role: one z per wave, lane = y * 8 + xg
   const int cz = wave, cy = lane >> 3, cxg = lane & 7;
-  const int cbase = (cz * PT_IH + cy) * PT_RS + cxg * PT_RX + (VEC ? 3 : 0);
+  const int cbase = (cz * PT_IH + cy) * PT_RS + cxg * PT_RX + 3;
   float acc[PT_RX];
 #pragma unroll
   for (int i = 0; i < PT_RX; ++i) acc[i] = 0.f;
 
-  constexpr int ROWS = PT_CK * PT_ID * PT_IH;          // scalar staging: one 64-lane group per row; VEC: 16 lanes per row
-  constexpr int NIT = VEC ? (ROWS + 15) / 16 : (ROWS + 3) / 4;
+  constexpr int ROWS = PT_CK * PT_ID * PT_IH;          // 16 lanes per row
+  constexpr int NIT = (ROWS + 15) / 16;
   static_assert(PT_W % 4 == 0 && PT_RS % 4 == 0 && PT_RS >= 64, "float4 staging");
   // staging: the next chunk's rows are loaded into registers right after the barrier and stay in flight while the current
   // chunk is being consumed
-  const int sgx = VEC ? ox0 - 4 + 4 * (tid & 15) : ox0 - 1 + lane;
-  const bool xok = VEC ? true : lane < PT_IW;
-  const bool xin = VEC ? (sgx >= 0 && sgx + 3 < W) : (xok && sgx >= 0 && sgx < W);
-  f32x4 pre[VEC ? NIT : 1];
-  float pres[VEC ? 1 : NIT];
+  const int sgx = ox0 - 4 + 4 * (tid & 15);
+  const bool xin = sgx >= 0 && sgx + 3 < W;
+  f32x4 pre[NIT];
   auto issue = [&](int c0) {
     int gx_o = sgx;                           // opaque copies keep the per-row address arithmetic from
     asm volatile("" : "+v"(gx_o));            // being hoisted out of the chunk loop into VGPRs
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int row = VEC ? it * 16 + (tid >> 4) : it * 4 + wave;
+      const int row = it * 16 + (tid >> 4);
       const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
       const int gz = oz0 - 1 + rz, gy = oy0 - 1 + ry;
       const bool ok = row < ROWS && xin && gz >= 0 && gz < D && gy >= 0 && gy < H;
       const float* src = inb + (size_t)(c0 + ck) * plane + ((size_t)gz * H + gy) * W + gx_o;
-      if constexpr (VEC) pre[it] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      else pres[it] = ok ? *src : 0.f;
+      pre[it] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
   auto commit = [&]() {
-    int lane_o = VEC ? 4 * (tid & 15) : lane;
+    int lane_o = 4 * (tid & 15);
     asm volatile("" : "+v"(lane_o));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int row = VEC ? it * 16 + (tid >> 4) : it * 4 + wave;
+      const int row = it * 16 + (tid >> 4);
       const int ck = row / (PT_ID * PT_IH), rz = (row / PT_IH) % PT_ID, ry = row % PT_IH;
-      float* dst = xs + ck * PT_PLANE + (rz * PT_IH + ry) * PT_RS + lane_o;
-      if constexpr (VEC) { if (row < ROWS) *reinterpret_cast<f32x4*>(dst) = pre[it]; }
-      else { if (row < ROWS && xok) *dst = pres[it]; }
+      if (row < ROWS) *reinterpret_cast<f32x4*>(xs + ck * PT_PLANE + (rz * PT_IH + ry) * PT_RS + lane_o) = pre[it];
     }
   };
   issue(0);
@@ -2252,12 +2247,8 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     {
       v3d::TimedScope ts("costreg_prob", s);
       const int ntz = (D + PT_D - 1) / PT_D, nty = (H + PT_H - 1) / PT_H, ntx = (W + PT_W - 1) / PT_W;
-      if ((W & 3) == 0)
-        prob_conv_kernel<8, true><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(
-            F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
-      else
-        prob_conv_kernel<8, false><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(
-            F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
+      prob_conv_kernel<8><<<(unsigned)((size_t)n * ntz * nty * ntx), 256, 0, s>>>(      // W % 8 == 0 (checked above)
+          F(ws.u9), h->dev + h->prob_w_ofs, h->dev + h->prob_b_ofs, xreg, n, D, H, W, ntz, nty, ntx);
     }
     V3D_CHECK_LAUNCH("prob_conv_kernel");
   }

@@ -321,10 +321,16 @@ def test_costreg_single_layers(layer, cuda):
     # every other layer is exact-fp32 MFMA
     tol = (4e-5 if layer == 0 else 1e-5) * max(1.0, float(ref.abs().max()))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5 if layer else 0, atol=tol)
-    if layer == 0:      # and conv0's exact-fp32 kernel (precision='fp32')
+    if layer == 0:      # and conv0's exact-fp32 kernel (precision='fp32'): float4 staging (width 12) ...
         out32 = net.run_layer(0, x.to(cuda), precision='fp32')
         np.testing.assert_allclose(out32.cpu().numpy(), ref.numpy(), rtol=1e-5,
                                    atol=1e-5 * max(1.0, float(ref.abs().max())))
+        # ... and the one-float-per-lane staging a width that is not a multiple of 4 falls back to
+        x14 = torch.randn((1, cin, 5, 9, 14), generator=g)
+        ref14 = ocv.conv_bn_relu3d(x14, sd, name)
+        out14 = net.run_layer(0, x14.to(cuda), precision='fp32')
+        np.testing.assert_allclose(out14.cpu().numpy(), ref14.numpy(), rtol=1e-5,
+                                   atol=1e-5 * max(1.0, float(ref14.abs().max())))
 
 
 @pytest.mark.parametrize('layer', list(range(1, 9)))
