@@ -421,6 +421,49 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
     // (accumulator halves cl = 0 / 1), so lane jn holds x = 2 xc and 2 xc + 1: one float2 store per
     // (channel, voxel pair) -> 16 lanes write 128 contiguous bytes.
     const int pz = (wave >> 1) & 1, py = wave & 1;
+    // Where the whole output tile fits the (dead) input tile's LDS and rows are 16-byte addressable, it leaves through LDS as
+    // float4 row segments with float4 skip loads.  The direct path below issues one 8-byte skip load and one 8-byte store per
+    // (channel, voxel pair) and lane: on conv9 (8 channels at full resolution) that epilogue was 75 % of the workgroup's time.
+    constexpr int OCS = C::NVOX + 4;                 // channel stride of the staged tile (padded against bank conflicts)
+    constexpr bool kStage = C::COUT * OCS <= C::LDS_FLOATS && C::TW % 4 == 0;
+    if (kStage && (p.Wo & 3) == 0 && ((reinterpret_cast<size_t>(p.out) | reinterpret_cast<size_t>(p.skip)) & 15) == 0) {
+      float* const os = xs;
+      __syncthreads();                               // every wave is done reading the input tile / weight fragments
+#pragma unroll
+      for (int i = 0; i < C::NBC; ++i) {
+        const int v = i * 16 + jn;
+        if (v >= C::NVC) continue;
+        const int z = 2 * (v / (C::CH * C::CW)) + pz, y = 2 * ((v / C::CW) % C::CH) + py, x = 2 * (v % C::CW);
+#pragma unroll
+        for (int m = 0; m < C::MB; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = m * 16 + kq * 4 + r;
+            if (co < C::COUT) {
+              const float bsv = p.bias[co];
+              float2 val = make_float2(acc[i][m][r] + bsv, acc[C::NBC + i][m][r] + bsv);
+              if (p.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); }
+              *reinterpret_cast<float2*>(os + co * OCS + (z * C::TH + y) * C::TW + x) = val;
+            }
+          }
+      }
+      __syncthreads();
+      constexpr int QPR = C::TW / 4, NQ = C::COUT * C::TD * C::TH * QPR;      // float4 per row, per tile
+#pragma unroll 4
+      for (int q4 = tid; q4 < NQ; q4 += 256) {
+        const int co = q4 / (C::TD * C::TH * QPR), rem = q4 % (C::TD * C::TH * QPR);
+        const int row = rem / QPR, xq4 = rem % QPR;
+        const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 4 * xq4;
+        if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;     // Wo % 4 == 0: a float4 is inside or outside as a whole
+        f32x4 val = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C::TW + 4 * xq4);
+        const size_t o = ((size_t)n * C::COUT + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+        if (p.skip) val += *reinterpret_cast<const f32x4*>(p.skip + o);
+        *reinterpret_cast<f32x4*>(p.out + o) = val;
+      }
+      PHASE_MARK(6);
+      PHASE_FLUSH;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < C::NBC; ++i) {
       const int v = i * 16 + jn;

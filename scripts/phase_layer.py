@@ -18,10 +18,13 @@ def main():
     ap.add_argument('--layer', type=int, required=True)
     ap.add_argument('--refs', type=int, default=32)
     ap.add_argument('--blocks', type=int, default=0)
+    ap.add_argument('--precision', default='split_bf16')
     args = ap.parse_args()
+    libm = importlib.import_module('3dvnet_amd._lib')
+    if os.environ.get('V3D_LIB_OVERRIDE'):
+        libm.LIB_PATH = os.environ['V3D_LIB_OVERRIDE']
     syn = importlib.import_module('3dvnet_amd.synthetic')
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
-    libm = importlib.import_module('3dvnet_amd._lib')
     lib = libm.load()
     fn = lib.v3d_debug_phase_read
     fn.restype = ctypes.c_int
@@ -32,15 +35,16 @@ def main():
     net = net.to(dev)
     ci, div = SHAPES[args.layer]
     x = torch.rand(args.refs, ci, 96 // div, 56 // div, 56 // div, device=dev)
+    skip = torch.rand(args.refs, {7: 32, 8: 16, 9: 8}[args.layer], 2 * x.shape[2], 2 * x.shape[3], 2 * x.shape[4], device=dev) if args.layer >= 7 else None
     buf = (ctypes.c_ulonglong * 8)()
     with torch.no_grad():
         for _ in range(2):
-            net.run_layer(args.layer, x)
+            net.run_layer(args.layer, x, skip, precision=args.precision)
         torch.cuda.synchronize()
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         t0.record()
         for _ in range(5):
-            net.run_layer(args.layer, x)
+            net.run_layer(args.layer, x, skip, precision=args.precision)
         t1.record(); torch.cuda.synchronize()
     nb = args.blocks or 65536
     fn(buf, nb)

@@ -321,6 +321,13 @@ def test_costreg_single_layers(layer, cuda):
     # every other layer is exact-fp32 MFMA
     tol = (4e-5 if layer == 0 else 1e-5) * max(1.0, float(ref.abs().max()))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5 if layer else 0, atol=tol)
+    if layer >= 7:      # output width 14: rows that are not 16-byte addressable take the direct (unstaged) epilogue
+        x7 = torch.randn((1, cin, 2, 3, 7), generator=g)
+        ref7 = ocv.deconv_bn_relu3d(x7, sd, name)
+        skip7 = torch.randn(ref7.shape, generator=g)
+        out7 = net.run_layer(layer, x7.to(cuda), skip7.to(cuda))
+        np.testing.assert_allclose(out7.cpu().numpy(), (skip7 + ref7).numpy(), rtol=1e-5,
+                                   atol=1e-5 * max(1.0, float(ref7.abs().max())))
     if layer == 0:      # and conv0's exact-fp32 kernel (precision='fp32'): float4 staging (width 12) ...
         out32 = net.run_layer(0, x.to(cuda), precision='fp32')
         np.testing.assert_allclose(out32.cpu().numpy(), ref.numpy(), rtol=1e-5,
