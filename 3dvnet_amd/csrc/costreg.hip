@@ -416,19 +416,41 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
   PHASE_MARK(5);
   // ---- epilogue: bias, ReLU, skip, store ([n, COUT, Do, Ho, Wo]) -------------------------------
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
+  // Where the whole output tile fits the (dead) input tile's LDS and rows are 16-byte addressable, it leaves through LDS as
+  // float4 row segments with float4 skip loads.  The direct paths below issue 4- or 8-byte skip loads and stores per (channel,
+  // voxel) and lane: on conv9 (8 channels at full resolution) that epilogue was 75 % of the workgroup's time.
+  constexpr int OCS = C::NVOX + 4;                 // channel stride of the staged tile (padded against bank conflicts)
+  constexpr bool kStage = C::COUT * OCS <= C::LDS_FLOATS && C::TW % 4 == 0;
+  const bool staged = kStage && (p.Wo & 3) == 0 &&
+                      ((reinterpret_cast<size_t>(p.out) | reinterpret_cast<size_t>(p.skip)) & 15) == 0;
+  float* const os = xs;
+  auto stage_value = [&](int co, int z, int y, int x, float val) __attribute__((always_inline)) {
+    val += p.bias[co];
+    if (p.relu) val = fmaxf(val, 0.f);
+    os[co * OCS + (z * C::TH + y) * C::TW + x] = val;
+  };
+  auto store_staged = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    constexpr int QPR = C::TW / 4, NQ = C::COUT * C::TD * C::TH * QPR;      // float4 per row, per tile
+#pragma unroll 4
+    for (int q4 = tid; q4 < NQ; q4 += 256) {
+      const int co = q4 / (C::TD * C::TH * QPR), rem = q4 % (C::TD * C::TH * QPR);
+      const int row = rem / QPR, xq4 = rem % QPR;
+      const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 4 * xq4;
+      if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;     // Wo % 4 == 0: a float4 is inside or outside as a whole
+      f32x4 val = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C::TW + 4 * xq4);
+      const size_t o = ((size_t)n * C::COUT + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
+      if (p.skip) val += *reinterpret_cast<const f32x4*>(p.skip + o);
+      *reinterpret_cast<f32x4*>(p.out + o) = val;
+    }
+  };
+  if (staged) __syncthreads();                     // every wave is done reading the input tile / weight fragments
   if constexpr (MODE == kDeconvS2) {
     // This wave owns output parities (pz, py) = (wave >> 1, wave & 1) and BOTH x parities
     // (accumulator halves cl = 0 / 1), so lane jn holds x = 2 xc and 2 xc + 1: one float2 store per
     // (channel, voxel pair) -> 16 lanes write 128 contiguous bytes.
     const int pz = (wave >> 1) & 1, py = wave & 1;
-    // Where the whole output tile fits the (dead) input tile's LDS and rows are 16-byte addressable, it leaves through LDS as
-    // float4 row segments with float4 skip loads.  The direct path below issues one 8-byte skip load and one 8-byte store per
-    // (channel, voxel pair) and lane: on conv9 (8 channels at full resolution) that epilogue was 75 % of the workgroup's time.
-    constexpr int OCS = C::NVOX + 4;                 // channel stride of the staged tile (padded against bank conflicts)
-    constexpr bool kStage = C::COUT * OCS <= C::LDS_FLOATS && C::TW % 4 == 0;
-    if (kStage && (p.Wo & 3) == 0 && ((reinterpret_cast<size_t>(p.out) | reinterpret_cast<size_t>(p.skip)) & 15) == 0) {
-      float* const os = xs;
-      __syncthreads();                               // every wave is done reading the input tile / weight fragments
+    if (staged) {
 #pragma unroll
       for (int i = 0; i < C::NBC; ++i) {
         const int v = i * 16 + jn;
@@ -439,27 +461,10 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = m * 16 + kq * 4 + r;
-            if (co < C::COUT) {
-              const float bsv = p.bias[co];
-              float2 val = make_float2(acc[i][m][r] + bsv, acc[C::NBC + i][m][r] + bsv);
-              if (p.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); }
-              *reinterpret_cast<float2*>(os + co * OCS + (z * C::TH + y) * C::TW + x) = val;
-            }
+            if (co < C::COUT) { stage_value(co, z, y, x, acc[i][m][r]); stage_value(co, z, y, x + 1, acc[C::NBC + i][m][r]); }
           }
       }
-      __syncthreads();
-      constexpr int QPR = C::TW / 4, NQ = C::COUT * C::TD * C::TH * QPR;      // float4 per row, per tile
-#pragma unroll 4
-      for (int q4 = tid; q4 < NQ; q4 += 256) {
-        const int co = q4 / (C::TD * C::TH * QPR), rem = q4 % (C::TD * C::TH * QPR);
-        const int row = rem / QPR, xq4 = rem % QPR;
-        const int gz = oz0 + row / C::TH, gy = oy0 + row % C::TH, gx = ox0 + 4 * xq4;
-        if (gz >= p.Do || gy >= p.Ho || gx >= p.Wo) continue;     // Wo % 4 == 0: a float4 is inside or outside as a whole
-        f32x4 val = *reinterpret_cast<const f32x4*>(os + co * OCS + row * C::TW + 4 * xq4);
-        const size_t o = ((size_t)n * C::COUT + co) * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx;
-        if (p.skip) val += *reinterpret_cast<const f32x4*>(p.skip + o);
-        *reinterpret_cast<f32x4*>(p.out + o) = val;
-      }
+      store_staged();
       PHASE_MARK(6);
       PHASE_FLUSH;
       return;
@@ -496,6 +501,20 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
     // rows 0-7: x shift 0, rows 8-15: x shift 1 -> lane quarter kq holds channels 4*(kq&1)+r at
     // x = 2*pair + (kq >> 1); quarters kq and kq+2 interleave into full 128-B runs per channel.
     const int sx = kq >> 1, cbase = 4 * (kq & 1);
+    if (staged) {
+#pragma unroll
+      for (int j = 0; j < C::NBW; ++j) {
+        const int v = (wave * C::NBW + j) * 16 + jn;
+        if (v >= C::NVC) continue;
+        const int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = 2 * (v % C::CW) + sx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage_value(cbase + r, z, y, x, acc[j][0][r]);
+      }
+      store_staged();
+      PHASE_MARK(6);
+      PHASE_FLUSH;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < C::NBW; ++j) {
       const int v = (wave * C::NBW + j) * 16 + jn;
@@ -515,6 +534,25 @@ __global__ __launch_bounds__(256, C::OCC) void conv3d_mfma_kernel(ConvParams p) 
       }
     }
   } else {
+    if (staged) {
+#pragma unroll
+      for (int j = 0; j < C::NBW; ++j) {
+        const int v = (wave * C::NBW + j) * 16 + jn;
+        if (v >= C::NVC) continue;
+        const int z = v / (C::CH * C::CW), y = (v / C::CW) % C::CH, x = v % C::CW;
+#pragma unroll
+        for (int m = 0; m < C::MB; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = m * 16 + kq * 4 + r;
+            if (co < C::COUT) stage_value(co, z, y, x, acc[j][m][r]);
+          }
+      }
+      store_staged();
+      PHASE_MARK(6);
+      PHASE_FLUSH;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < C::NBW; ++j) {
       const int v = (wave * C::NBW + j) * 16 + jn;

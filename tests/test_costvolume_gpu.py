@@ -338,6 +338,12 @@ def test_costreg_single_layers(layer, cuda):
         out14 = net.run_layer(0, x14.to(cuda), precision='fp32')
         np.testing.assert_allclose(out14.cpu().numpy(), ref14.numpy(), rtol=1e-5,
                                    atol=1e-5 * max(1.0, float(ref14.abs().max())))
+    if layer in (1, 2):  # the exact-fp32 kernels' direct epilogue (output rows that are not 16-byte addressable)
+        x14 = torch.randn((1, cin, 5, 9, 14), generator=g)
+        ref14 = ocv.conv_bn_relu3d(x14, sd, name, stride=2 if layer == 1 else 1)
+        out14 = net.run_layer(layer, x14.to(cuda))
+        np.testing.assert_allclose(out14.cpu().numpy(), ref14.numpy(), rtol=1e-5,
+                                   atol=1e-5 * max(1.0, float(ref14.abs().max())))
 
 
 @pytest.mark.parametrize('layer', list(range(1, 9)))
