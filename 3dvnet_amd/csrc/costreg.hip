@@ -2209,7 +2209,7 @@ extern "C" int v3d_costreg_layer_split_f32(const v3d_costreg_weights* h, int lay
 }
 
 namespace {
-struct WsPlan { size_t c0, c1, c2, c3, c4, c5, c6, u7, u8, u9, reg, total; };
+struct WsPlan { size_t c0, c1, c2, c3, c4, c5, c6, u7, u8, u9, reg, enc, total; };
 WsPlan plan_ws(int n, int D, int h, int w) {
   const size_t V0 = (size_t)D * h * w, V1 = V0 / 8, V2 = V1 / 8, V3 = V2 / 8;
   WsPlan p; size_t o = 0;
@@ -2217,7 +2217,9 @@ WsPlan plan_ws(int n, int D, int h, int w) {
   p.c0 = take(n * 8 * V0); p.c1 = take(n * 16 * V1); p.c2 = take(n * 16 * V1);
   p.c3 = take(n * 32 * V2); p.c4 = take(n * 32 * V2); p.c5 = take(n * 64 * V3);
   p.c6 = take(n * 64 * V3); p.u7 = take(n * 32 * V2); p.u8 = take(n * 16 * V1);
-  p.u9 = take(n * 8 * V0); p.reg = take(n * V0); p.total = o;
+  p.u9 = take(n * 8 * V0); p.reg = take(n * V0);
+  p.enc = take(32 * V0);        // ONE view's variance volume in the split layout (fp32 entry point, see costreg_depth_impl)
+  p.total = o;
   return p;
 }
 }  // namespace
@@ -2257,9 +2259,20 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
     RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
   } else {
-    if ((rc = launch_conv0_bf16(split_in, true, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], nullptr, F(ws.c0), n,
-                                D, H, W, s)) != V3D_OK)
-      return rc;
+    // conv0: the depth-march kernel (conv0z.hip) reads the split hand-off format.  The fp32 entry point (CostRegNet.forward
+    // on a reference-layout tensor, return_intermediates) encodes one view at a time into the workspace's `enc` slot and runs
+    // the same kernel on it: both entry points give the same bits.
+    if (split_in) {
+      if ((rc = v3d::launch_conv0z(var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0), n, D, H, W, s)) != V3D_OK) return rc;
+    } else {
+      const size_t V0 = (size_t)D * H * W, total = 4 * V0;
+      for (int i = 0; i < n; ++i) {
+        encode_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(var + (size_t)i * 32 * V0, (u32x4*)F(ws.enc), 32, V0, total);
+        V3D_CHECK_LAUNCH("encode_split_kernel");
+        if ((rc = v3d::launch_conv0z(F(ws.enc), h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0) + (size_t)i * 8 * V0, 1, D, H,
+                                     W, s)) != V3D_OK) return rc;
+      }
+    }
 #ifdef V3D_PHASE_TIMING
     const int stop_after = getenv("V3D_STOP_AFTER") ? atoi(getenv("V3D_STOP_AFTER")) : 99;   // isolate one kernel's counters
 #define V3D_STOP(l) if (stop_after == (l)) return V3D_OK

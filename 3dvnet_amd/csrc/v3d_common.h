@@ -183,6 +183,11 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
   iy = mul_rn(add_rn(gy, 1.f), mul_rn(0.5f, Hfm1));
 }
 
+// conv0 of CostRegNet as a depth march (conv0z.hip): split variance volume [n][4][hi, lo][D][H][W] -> split activation
+// [n][hi, lo][D][H][W] (16-byte slots of 8 bf16); `wbf` = the split-bf16 weight image of conv0 (costreg.hip, c0bf)
+int launch_conv0z(const void* in_split, const float* wbf, const float* bias, void* out_split, int n, int D, int H, int W,
+                  hipStream_t s);
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 
