@@ -833,18 +833,20 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   // developer switch (scripts/micro/fused_decoder_stress.py): dynamic LDS request in KB
   static const size_t lds_bytes = getenv("V3D_FUSED_LDS_KB") ? (size_t)atoi(getenv("V3D_FUSED_LDS_KB")) * 1024 : kFLdsBytes;
   V3D_REQUIRE(lds_bytes >= kFUsedLdsBytes && lds_bytes <= 160 * 1024, V3D_ERR_BAD_ARG, "V3D_FUSED_LDS_KB out of range");
-  static bool attr_set = false;
-  static int resident = 0;     // workgroups the device holds at once: the LDS request admits 160 KB / lds_bytes per CU
-  if (!attr_set) {
+  // per device: the dynamic-LDS opt-in and the number of workgroups the device holds at once (160 KB / lds_bytes per CU)
+  static int resident_of[64] = {0};
+  int dev = 0;
+  V3D_CHECK_HIP(hipGetDevice(&dev));
+  V3D_REQUIRE(dev >= 0 && dev < 64, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: device ordinal %d", dev);
+  if (!resident_of[dev]) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_bytes));
-    int dev = 0, n_cu = 0;
-    V3D_CHECK_HIP(hipGetDevice(&dev));
+    int n_cu = 0;
     V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int per_cu = getenv("V3D_FUSED_WG_PER_CU") ? atoi(getenv("V3D_FUSED_WG_PER_CU")) : (int)(160 * 1024 / lds_bytes);
-    resident = n_cu * (per_cu > 0 ? per_cu : 1);
-    attr_set = true;
+    resident_of[dev] = (n_cu > 0 ? n_cu : 256) * (per_cu > 0 ? per_cu : 1);
   }
+  const int resident = resident_of[dev];
   {
     // persistent tile walk: workgroup b takes tiles b, b + grid, ... (equal work per tile, so a static split is balanced)
     const int n_tiles = (n_pts + kFPts - 1) / kFPts;

@@ -791,6 +791,8 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
       // developer A/B: rows per tile (32 / 64 / 128) -- a tile re-reads the whole weight image, so L2 -> CU weight traffic is
       // M / rows x 27 x K x N x 4 bytes (0.8 GB per 64-channel conv on 60 k voxels with 32-row tiles, twice the gathers)
       static const int rows_env = getenv("V3D_GEMM_ROUND_ROWS") ? atoi(getenv("V3D_GEMM_ROUND_ROWS")) : 0;
+      V3D_REQUIRE(rows_env == 0 || rows_env == 32 || rows_env == 64 || rows_env == 128, V3D_ERR_BAD_ARG,
+                  "V3D_GEMM_ROUND_ROWS must be 32, 64 or 128 (got %d)", rows_env);
       const int rows = rows_env ? rows_env : 32;
       const unsigned rb = (unsigned)((M + rows - 1) / rows);
       if (h->MBW == 2) {

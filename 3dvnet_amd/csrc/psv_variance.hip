@@ -785,10 +785,11 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     wq = (f32x4){v3d::mul_rn(wx0, wy0), v3d::mul_rn(wx1, wy0), v3d::mul_rn(wx0, wy1), v3d::mul_rn(wx1, wy1)};
     xb = (int)x0 + 1;
     yb = (int)y0 + 1;
-    if (!live1) {                          // lanes beyond the plane grid / the last plane must not stretch the box
-      xb = __builtin_amdgcn_readfirstlane(xb);
-      yb = __builtin_amdgcn_readfirstlane(yb);
-    }
+    // lanes beyond the plane grid / the last plane must not stretch the box: they take lane 0's cell (always live) -- read
+    // under full exec (inside a branch on !live1 readfirstlane would return the first DEAD lane's own value)
+    const int xb0 = __builtin_amdgcn_readlane(xb, 0), yb0 = __builtin_amdgcn_readlane(yb, 0);
+    xb = live1 ? xb : xb0;
+    yb = live1 ? yb : yb0;
   };
   // Software pipeline over the edges: the samples of edge e + 1 are projected while the window of edge e is on its way
   // from L2 to LDS (the copy's latency was 0.27 of 1.59 ms when the wave simply waited for it)

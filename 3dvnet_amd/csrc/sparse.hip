@@ -139,6 +139,8 @@ extern "C" int v3d_sparse_neighbors(const void* table, int n_in, const int32_t* 
                                     int step, int32_t* nbr, void* stream) {
   V3D_REQUIRE(table && out_coords && nbr, V3D_ERR_BAD_ARG, "v3d_sparse_neighbors: null argument");
   V3D_REQUIRE(n_in > 0 && n_out > 0 && step != 0, V3D_ERR_BAD_SHAPE, "v3d_sparse_neighbors: bad shape");
+  V3D_REQUIRE((reinterpret_cast<size_t>(out_coords) & 15) == 0, V3D_ERR_BAD_ARG,
+              "v3d_sparse_neighbors: out_coords must be 16-byte aligned (the kernel loads a coordinate row as one int4)");
   hipStream_t s = (hipStream_t)stream;
   HashTable t = table_view(const_cast<void*>(table), n_in);
   v3d::TimedScope ts("sparse_neighbors", s);

@@ -29,19 +29,6 @@ struct HashTable {          // device layout inside the caller-provided buffer
 // +-1 voxel probes of the neighbour tables cannot wrap either
 constexpr int kCoordMax = 65535 - 2 * kGuard;
 
-// the probe sequence of `key` continued at its probe number `first` (slot = hash + first): for callers that fetched the first
-// slots themselves (decoder.hip loads two slots of several keys at once)
-__device__ __forceinline__ int hash_find_from(const HashTable& t, unsigned long long key, unsigned slot, unsigned first) {
-  slot &= t.mask;
-  for (unsigned probe = first; probe <= t.mask; ++probe) {
-    const unsigned long long k = t.keys[slot];
-    if (k == key) return t.vals[slot];
-    if (k == kEmpty) return -1;
-    slot = (slot + 1) & t.mask;
-  }
-  return -1;
-}
-
 __device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
   unsigned slot = hash_u64(key) & t.mask;
   for (unsigned probe = 0; probe <= t.mask; ++probe) {

@@ -99,6 +99,20 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         if not torch.equal(ref_idx, torch.arange(k, k + n_ref_imgs, dtype=ref_idx.dtype)):
             raise ValueError('process_scene: the reference views of ref_src_edges must be images %d .. %d (dataset layout, '
                              'n_src_on_either_side = %d before); got %s' % (k, k + n_ref_imgs - 1, k, ref_idx.tolist()))
+        # Every source view must lie inside its reference view's window [ref - k, ref + ka] and inside the scene: the chunk
+        # slices below carry exactly that halo, and the device-side table builder (v3d_edges_csr) answers an index outside a
+        # chunk with an EMPTY table -- a zero variance volume and a plausible-looking depth, not an error.  The list is on the
+        # host already, so the check costs nothing.
+        n_img_scene = int(batch.rotmats.shape[0])
+        if scene_edges.shape[1]:
+            delta = scene_edges[1] - scene_edges[0]
+            if int(delta.min()) < -k or int(delta.max()) > ka or int(scene_edges[1].min()) < 0 \
+                    or int(scene_edges[1].max()) >= n_img_scene:
+                bad = ((delta < -k) | (delta > ka) | (scene_edges[1] < 0) | (scene_edges[1] >= n_img_scene)).nonzero()[0]
+                raise ValueError('process_scene: edge %s -> %s lies outside the source window [ref - %d, ref + %d] / the %d '
+                                 'images of the scene (n_src_on_either_side = %r)'
+                                 % (int(scene_edges[0, bad[0]]), int(scene_edges[1, bad[0]]), k, ka, n_img_scene,
+                                    n_src_on_either_side))
         r0, r1 = shard_range(n_ref_imgs, rank, world)
         n_local = r1 - r0
         has_feats = getattr(batch, 'features_quarter', None) is not None

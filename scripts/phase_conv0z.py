@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Developer tool (variant library built with -DV3D_PHASE_TIMING, scripts/build_variant.py conv0z.hip ...): cycles of wave 0
+per phase of the depth-march conv0 kernel at cfg2 shapes, summed over the workgroups.
+    V3D_LIB_OVERRIDE=3dvnet_amd/build/ablate/lib_czph.so python scripts/phase_conv0z.py [--refs 64]"""
+import argparse
+import ctypes
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+NAMES = ['M: wait at B', "M: MFMA phase (B', stores inside)", "H: wait at B'", 'M: task end barriers', 'H: task prologue', 'H: wait vmcnt', 'H: wait at B', 'H: issue DMA + epilogue']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--refs', type=int, default=64)
+    args = ap.parse_args()
+    libm = importlib.import_module('3dvnet_amd._lib')
+    if os.environ.get('V3D_LIB_OVERRIDE'):
+        libm.LIB_PATH = os.environ['V3D_LIB_OVERRIDE']
+    syn = importlib.import_module('3dvnet_amd.synthetic')
+    mvs = importlib.import_module('3dvnet_amd.mvsnet')
+    Batch = importlib.import_module('3dvnet_amd.batch').Batch
+    lib = libm.load()
+    fn = lib.v3d_debug_conv0z_phase_read
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    dev = torch.device('cuda:0')
+    inp = syn.make_costvolume_inputs('cfg2', n_ref=args.refs)
+    net = mvs.MVSNet(32, inp['img_size']).eval()
+    net.cnn_3d.load_state_dict(syn.costregnet_weights(seed=0, sharpen=200.0), strict=False)
+    net = net.to(dev)
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(dev)
+    feat = inp['feat'].to(dev)
+    d0, dd, D = inp['depth']
+    with torch.no_grad():
+        for _ in range(3):
+            net.cost_volume_depth(feat, b, d0, dd, D, inp['plane_size'])
+        torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    fn(buf, 1024)
+    tot = sum(buf)
+    print('conv0z phases (cycles of wave 0, %d workgroups): total %.3e' % (256, tot))
+    for n, v in zip(NAMES, buf):
+        print('  %-34s %6.1f %%  %.3e' % (n, 100.0 * v / max(tot, 1), v))
+
+
+if __name__ == '__main__':
+    main()

@@ -241,6 +241,27 @@ def test_driver_rejects_an_edge_list_that_breaks_the_dataset_layout():
         drv.process_scene(b, OracleNet(*weights(), IMG, 0.16), 1, torch.device('cpu'), CFG, OFFSETS, 18, 16)
 
 
+def test_driver_rejects_a_source_view_outside_the_window():
+    """A source index outside a chunk's halo would make the device-side table builder write an EMPTY table (zero variance,
+    plausible depth): the driver validates the whole list on the host -- window [ref - k, ref + ka] and the scene's image
+    range -- before anything runs."""
+    drv = v3d('eval_3dvnet')
+    net = OracleNet(*weights(), IMG, 0.16)
+    b = make_scene()
+    e = b.ref_src_edges.clone()
+    j = int((e[0] == 3).nonzero()[0])
+    e[1, j] = 0                                   # image 0 is 3 views away from reference view 3; the window is +-1
+    b.ref_src_edges = e
+    with pytest.raises(ValueError, match='outside the source window'):
+        drv.process_scene(b, net, 1, torch.device('cpu'), CFG, OFFSETS, 18, 16)
+    b = make_scene()
+    e = b.ref_src_edges.clone()
+    e[1, -1] = b.rotmats.shape[0]                 # one past the last image of the scene
+    b.ref_src_edges = e
+    with pytest.raises(ValueError, match='outside the source window'):
+        drv.process_scene(b, net, (1, 2), torch.device('cpu'), CFG, OFFSETS, 18, 16)
+
+
 @pytest.mark.gpu
 def test_bench_line_schema_and_checks(cuda):
     """`bench.py` end to end on a small batch (8 views, 2 steps): ONE JSON line with the contract's fields, both operand
