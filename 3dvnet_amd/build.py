@@ -60,6 +60,15 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s' % src)
         if verbose and out:
             print(out.decode())
+    # Static guard for the fused decoder's LDS hazard (scripts/check_lds_hazard.py): the default build must carry the LDS
+    # read signature that passed the determinism test on hardware; developer flag sets are not checked.
+    if not os.environ.get('V3D_EXTRA_FLAGS', '').strip() and not os.environ.get('V3D_SKIP_LDS_CHECK'):
+        sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+        try:
+            import check_lds_hazard
+            check_lds_hazard.check(os.path.join(objdir, 'decoder.o'))
+        finally:
+            sys.path.pop(0)
     if force or procs or linked != tag or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

@@ -285,6 +285,9 @@ def bench_costvolume(args, rank, world, dev, dist):
         d_host = torch.cat([cpu_run(v, min(v + chunk, n_host)) for v in range(0, n_host, chunk)])
         rel_host = float(((d_gpu[:n_host] - d_host).abs() / d_host).max())
         rel_host32 = float(((d_gpu32[:n_host] - d_host).abs() / d_host).max())
+        # reference-vs-reference spread: the two CPU evaluations of the SAME reference arithmetic (pinned orders of the
+        # golden run vs this host's BLAS orders) on the same views -- what a 1e-4 gate against "the reference" can resolve
+        spread = float(((d_cpu[:n_host] - d_host).abs() / d_host).max())
         abs_rel = float(((d_gpu - d_cpu).abs() / (d_cpu + 1e-7)).mean())   # eval/metricfunctions.py:41 with gt := oracle
         cpu_baseline = dict(value=by_threads.get(cores), unit='depth maps/s', cores=cores, kind='port',
                             sample='%d reference view(s) of the same %s batch (oracle: torch CPU grid_sample + '
@@ -298,7 +301,8 @@ def bench_costvolume(args, rank, world, dev, dist):
                             max_rel_depth_err_gpu_fp32_exact_vs_cpu=rel32, abs_rel_gpu_vs_cpu=abs_rel,
                             checker='oracle with pinned evaluation orders (oracle/pinned.py)',
                             max_rel_depth_err_gpu_vs_host_blas_oracle=rel_host,
-                            max_rel_depth_err_gpu_fp32_exact_vs_host_blas_oracle=rel_host32, host_blas_checked_views=n_host)
+                            max_rel_depth_err_gpu_fp32_exact_vs_host_blas_oracle=rel_host32, host_blas_checked_views=n_host,
+                            max_rel_depth_spread_pinned_vs_host_blas_oracle=spread)
 
     if rank != 0:
         return None
@@ -410,16 +414,26 @@ def bench_scene(args, rank, world, dev, dist):
                             avg_ms=st[dom][0] / st[dom][1], traffic=None)
     # ---- parity of the refinement leg: a 4-view scene of the same shapes / weights through the same driver, HIP against the
     # oracle-backed net (CPU; rows A1-A4 with the pinned orders), final depths after 2 x (scene model + 3 sweeps)
-    parity = None
+    parity, cpu_baseline = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.net import OracleNet          # checker only
+        from oracle.net import OracleNet          # checker / reported baseline only
         n_chk = 4
         bs, gts = make(n_chk, 77)
         with torch.no_grad():
             d_hip = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev)).cpu()
-            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            nt = min(32, os.cpu_count() or 1)
+            torch.set_num_threads(nt)
             onet = OracleNet(sds['cr'], sds['pn'], sds['un'], sds['dec'], cfg['img_size'], cfg['edge_len'], pinned=True)
+            t_cpu = time.perf_counter()
             d_cpu = drv.process_scene(bs, onet, win, torch.device('cpu'), init_depth_override=gts)
+            t_cpu = time.perf_counter() - t_cpu
+        # the reference's CPU path of the WHOLE pipeline (dense-formulation sparse convolutions, torch CPU
+        # grid_sample / Conv3d) timed beside the GPU figure -- the run that also serves as the checker, one pass, no warm-up
+        cpu_baseline = dict(value=n_chk / t_cpu, unit='depth maps/s', cores=nt, kind='port',
+                            sample='one %d-view scene of the same shapes / weights through the same driver on the oracle-backed '
+                                   'net (oracle/net.py; sample coordinates with the pinned orders, i.e. elementwise torch ops '
+                                   'instead of bmm), one pass of %.1f s, no warm-up' % (n_chk, t_cpu),
+                            cpu_model=cpu_info())
         parity = dict(checked_views=n_chk, checker='oracle-backed scene driver (oracle/net.py: oracle/costvolume.py + '
                       'oracle/scene.py), same driver code, CPU',
                       max_rel_depth_err_gpu_vs_cpu=float(((d_hip - d_cpu).abs() / d_cpu).max()),
@@ -439,7 +453,7 @@ def bench_scene(args, rank, world, dev, dist):
                    'parallelism': ('ref-view sharding + RCCL all-gather of the feature-rich point cloud per outer '
                                    'iteration (the communicating mode)' if world > 1 else 'single GPU'),
                    'ranks_seen': world if dist is None else dist.get_world_size()},
-        'roofline': roofline, 'cpu_baseline': None, 'parity': parity, 'kernels': kernels}
+        'roofline': roofline, 'cpu_baseline': cpu_baseline, 'parity': parity, 'kernels': kernels}
 
 
 def compact(line):
@@ -451,11 +465,14 @@ def compact(line):
         if k in line['config']:
             out[k] = line['config'][k]
     out['roofline'] = line.get('roofline')
-    cb = line.get('cpu_baseline') or line.get('parity') or {}
+    cb = line.get('parity') or line.get('cpu_baseline') or {}
     out['parity'] = {k: cb[k] for k in ('checked_views', 'checker', 'max_rel_depth_err_gpu_vs_cpu',
                                         'max_rel_depth_err_gpu_fp32_exact_vs_cpu', 'abs_rel_gpu_vs_cpu',
-                                        'max_rel_depth_err_gpu_vs_host_blas_oracle', 'host_blas_checked_views',
-                                        'max_abs_refinement_m') if k in cb}
+                                        'max_rel_depth_err_gpu_vs_host_blas_oracle',
+                                        'max_rel_depth_err_gpu_fp32_exact_vs_host_blas_oracle', 'host_blas_checked_views',
+                                        'max_rel_depth_spread_pinned_vs_host_blas_oracle', 'max_abs_refinement_m') if k in cb}
+    if line.get('cpu_baseline') and line.get('parity'):
+        out['cpu_baseline'] = line['cpu_baseline']
     top = sorted(line.get('kernels', {}).items(), key=lambda kv: -kv[1].get('share', 0))[:4]
     out['top_kernels'] = {k: {kk: v[kk] for kk in ('avg_ms', 'total_ms', 'share', 'frac') if kk in v} for k, v in top}
     return out
@@ -476,6 +493,32 @@ def spawn_ranks(n):
     return subprocess.call(rank_command(n, port, sys.argv[1:]), env=env)
 
 
+class _DryNet:
+    """Stand-in for PL3DVNet in `--config cfg4 --dry-run`: the three methods eval_3dvnet.process_scene calls, with
+    bookkeeping arithmetic only (a view's "depth" is its global image index, carried in tvecs[:, 0]) -- so that the REAL
+    driver code (sharding, chunking, halos, gather_pointcloud with uneven shards, the final all-gather of the depths) runs
+    over gloo on CPU and its result can be checked in closed form.  It is not on any product or measured path."""
+
+    def __init__(self, k):
+        self.k = k
+
+    def make_initial_depth_predictions(self, sl, cfg):
+        n_ref, (h, w) = sl.n_ref, cfg['size']
+        ident = sl.tvecs[self.k:self.k + n_ref, 0].float()
+        return ident.view(-1, 1, 1).expand(n_ref, h, w).clone(), None, None, sl.features_quarter, None, None
+
+    def model_scene(self, depth, depth_batch, feats, rot, tv, K, edges, gather_fn=None, **_):
+        pts = depth.reshape(-1, 1).repeat(1, 3)
+        feat = torch.ones((pts.shape[0], 2), dtype=torch.float32)
+        bid = torch.zeros(pts.shape[0], dtype=torch.long)
+        if gather_fn is not None:
+            pts, feat, bid = gather_fn(pts, feat, bid)
+        return {'rows': pts.shape[0], 'sum': float(pts[:, 0].double().sum()), 'sorted': bool((pts[1:, 0] >= pts[:-1, 0]).all())}
+
+    def run_pointflow(self, xs, depth, *_, **__):
+        return torch.full_like(depth, 1e-3 * xs['rows'])
+
+
 def bench_dry_run(args, rank, world):
     """`--dry-run`: the multi-rank plumbing of this script without a GPU (gloo, CPU tensors, a no-op step): rendezvous from
     the launcher's environment, barrier-bracketed timing, max over ranks, every rank counted, ONE JSON line from rank 0.
@@ -486,6 +529,28 @@ def bench_dry_run(args, rank, world):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
     refs = args.refs or 64
+    scene_check = None
+    if args.config == 'cfg4':
+        # the communicating mode's host path: one scene sharded by reference view through the real driver (see _DryNet)
+        drv = importlib.import_module('3dvnet_amd.eval_3dvnet')
+        syn = importlib.import_module('3dvnet_amd.synthetic')
+        Batch = importlib.import_module('3dvnet_amd.batch').Batch
+        nb, na = (int(v) for v in args.scene_window.split(','))
+        edges, n_img = syn.make_edges(refs, nb, na)
+        rot, tv, K = syn.make_cameras(n_img, (64, 80), seed=3)
+        tv = tv.clone()
+        tv[:, 0] = torch.arange(n_img, dtype=tv.dtype)                 # image identity for _DryNet
+        b = Batch(None, rot, tv, K, None, edges)
+        b.features_quarter = torch.zeros((n_img, 32, 2, 2))
+        cfg = {'depth_start': 0.5, 'depth_interval': 0.1, 'n_intervals': 8, 'size': (4, 4)}
+        offsets = [[0.05, 0.025], [0.05]]
+        d = drv.process_scene(b, _DryNet(nb), (nb, na), torch.device('cpu'), cfg, offsets, 3, 2, rank=rank, world=world,
+                              group=None, gather_depth=True)
+        n_pix, sweeps = 16, sum(len(o) for o in offsets)
+        shard = [drv.shard_range(refs, g, world) for g in range(world)]
+        want = (torch.arange(nb, nb + refs, dtype=torch.float32) + sweeps * 1e-3 * refs * n_pix).view(-1, 1, 1).expand(refs, 4, 4)
+        scene_check = {'refs': refs, 'shard_views': [e - s0 for s0, e in shard], 'gathered_rows_per_outer_iteration': refs * n_pix,
+                       'depths_equal_closed_form': bool(d.shape == want.shape and torch.allclose(d, want, rtol=0, atol=1e-4))}
 
     def fence():
         if dist is not None:
@@ -513,7 +578,7 @@ def bench_dry_run(args, rank, world):
                           'data': 'none', 'dry_run': True,
                           'config': {'workload': 'dry run of the rank plumbing', 'refs_per_step_per_gpu': refs,
                                      'parallelism': 'ref-view sharding, no collective' if world > 1 else 'single process',
-                                     'ranks_seen': seen}}))
+                                     'ranks_seen': seen, 'cfg4_scene_check': scene_check}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -569,10 +634,10 @@ def main():
             extra = {}
             a5 = copy.copy(args)
             a5.config, a5.refs, a5.steps, a5.warmup = 'cfg5', 8, min(args.steps, 10), 2
-            a5.check_refs, a5.host_check_refs, a5.cpu_timing, a5.graph = 1, 1, False, False
+            a5.check_refs, a5.host_check_refs, a5.cpu_timing, a5.graph = 4, 4, False, False
             extra['cfg5'] = compact(bench_costvolume(a5, rank, world, dev, dist))
             a3 = copy.copy(args)
-            a3.config, a3.refs, a3.steps, a3.warmup = 'cfg3', 64, min(args.steps, 5), 1
+            a3.config, a3.refs, a3.steps, a3.warmup = 'cfg3', 64, min(args.steps, 10), 2
             extra['cfg3'] = compact(bench_scene(a3, rank, world, dev, dist))
             line['extra'] = extra
             line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Build-time guard for the LDS hazard of the fused hypothesis decoder (csrc/decoder.hip kFLdsBytes).
+
+Observed on gfx950 / ROCm 7.2 (reproducer: scripts/micro/lds_b128.hip): when hipcc merged the eight consecutive corner
+weights a thread reads from the LDS corner table into 16-byte reads, lanes 48..63 received stale data whenever a second
+wave on the SIMD had MFMAs in flight.  The table is corner-major now, so THOSE reads cannot be merged -- but nothing in
+the language stops a later compiler from forming a wide LDS read somewhere else in the kernel.  This script pins the LDS
+read signature of `decoder_fused_kernel` as the compiler emitted it for the build that passed the 60-launch determinism
+test (tests/test_parity_net_gpu.py::test_fused_decoder_is_deterministic_at_two_workgroups_per_cu): the number of LDS
+reads of every width.  `3dvnet_amd/build.py` runs it on the default build and FAILS the build when the signature moves --
+a new compiler or an edit of the kernel then has to re-run that test on a GPU and re-pin (`--print` shows the new one).
+
+    python scripts/check_lds_hazard.py 3dvnet_amd/build/<tag>/decoder.o [--print]
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get('V3D_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+KERNEL = 'decoder_fused_kernel'
+# signature of the build verified on MI355X (hipcc of ROCm 7.2.0): corner-table reads are the 4-byte kinds
+# (ds_read_b32 / ds_read2_b32 / ds_read2st64_b32); the 16-byte reads are the B fragments of the three layers.
+PINNED = {'ds_read_b128': 129, 'ds_read_b96': 1, 'ds_read_b64': 1, 'ds_read2_b64': 0, 'ds_read2st64_b64': 0,
+          'ds_read_b32': 44, 'ds_read2_b32': 9, 'ds_read2st64_b32': 7}
+
+
+def signature(obj):
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, 'fat'), os.path.join(td, 'co')
+        subprocess.check_call([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, obj])
+        subprocess.check_call([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fat,
+                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+        dis = subprocess.check_output([os.path.join(LLVM, 'llvm-objdump'), '-d', co], text=True)
+    inside, counts = False, collections.Counter()
+    for line in dis.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(.*)>:', line)
+        if m:
+            inside = KERNEL in m.group(1)
+            continue
+        if inside:
+            m = re.search(r'\b(ds_read[0-9a-z_]*)\b', line)
+            if m:
+                counts[m.group(1)] += 1
+    if not counts:
+        raise RuntimeError('%s not found in %s' % (KERNEL, obj))
+    return {k: counts.get(k, 0) for k in sorted(set(PINNED) | set(counts))}
+
+
+def check(obj):
+    sig = signature(obj)
+    bad = {k: (sig.get(k, 0), PINNED.get(k, 0)) for k in sig if sig.get(k, 0) != PINNED.get(k, 0)}
+    if bad:
+        raise RuntimeError(
+            'LDS read signature of %s moved (found, pinned): %s.\nA wide LDS read of the corner table returns stale lanes on '
+            'gfx950 (DESIGN.md 8.4).  Re-run tests/test_parity_net_gpu.py::test_fused_decoder_is_deterministic_at_two_'
+            'workgroups_per_cu and test_fused_decoder_matches_unfused_chain_and_golden on a GPU with this build, then update '
+            'PINNED in scripts/check_lds_hazard.py (V3D_SKIP_LDS_CHECK=1 builds without the guard).' % (KERNEL, bad))
+    return sig
+
+
+if __name__ == '__main__':
+    if '--print' in sys.argv:
+        print(signature(sys.argv[1]))
+    else:
+        print('ok', check(sys.argv[1]))

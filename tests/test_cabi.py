@@ -89,3 +89,29 @@ def test_pl3dvnet_default_construction_and_unsupported_feat_dim():
     assert net.hparams.feat_dim == 32 and net.sparse_conv.dims == (64, 128, 128)
     with pytest.raises(ValueError, match='feat_dim'):
         lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=16)
+
+
+def test_lds_hazard_guard_pins_the_fused_decoder_signature():
+    """scripts/check_lds_hazard.py (run by 3dvnet_amd/build.py on the default build): the LDS read signature of
+    decoder_fused_kernel in the built object equals the pinned one, and a moved signature fails the check."""
+    import glob
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tag = open(os.path.join(root, '3dvnet_amd', 'build', 'linked_flags')).read().strip()
+    obj = os.path.join(root, '3dvnet_amd', 'build', tag, 'decoder.o')
+    if not os.path.exists(obj) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no decoder.o / llvm tools here')
+    sys.path.insert(0, os.path.join(root, 'scripts'))
+    try:
+        chk = importlib.import_module('check_lds_hazard')
+        sig = chk.check(obj)
+        assert sig['ds_read_b128'] > 0 and sig['ds_read_b32'] > 0
+        pinned = dict(chk.PINNED)
+        chk.PINNED['ds_read_b64'] += 1
+        with pytest.raises(RuntimeError, match='signature'):
+            chk.check(obj)
+        chk.PINNED.update(pinned)
+    finally:
+        sys.path.pop(0)

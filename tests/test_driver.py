@@ -347,3 +347,23 @@ def test_bench_rank_plumbing_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['config']['ranks_seen'] == 2
+
+
+def test_bench_cfg4_dry_run_shards_a_scene_through_the_real_driver():
+    """`bench.py --config cfg4 --gpus 2 --dry-run`: the communicating mode's host path on CPU -- the real process_scene
+    (ref-view sharding 3 + 2, chunking, one-sided halos, gather_pointcloud with uneven shards, the final all-gather of the
+    depths) over gloo with a bookkeeping stand-in for the net; every rank sees the whole cloud each outer iteration and the
+    gathered depths equal the closed form."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'cfg4', '--gpus', '2', '--dry-run',
+                        '--refs', '5', '--scene-window', '1,2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    chk = d['config']['cfg4_scene_check']
+    assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2
+    assert chk['shard_views'] == [3, 2] and chk['gathered_rows_per_outer_iteration'] == 5 * 16
+    assert chk['depths_equal_closed_form'] is True
