@@ -942,15 +942,19 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void conv0_bf16x2_kernel(ConvP
 // per-layer kernels that still follow), the split layout (for the next layer of this kind), or both.
 enum { kOutF32 = 1, kOutSplit = 2 };
 
-template <int CIN_, int COUT_, int STRIDE_, int WB_, int OUT_>
+// FLAT (round 4, PropagationNet): no taps along z -- the "volume" is a stack of independent images [n][C/8][hi, lo][B][H][W]
+// and the layer a batched 3x3 conv2d (upsampling.py:6-11); the weight image then holds the 3 ky fragments only.
+template <int CIN_, int COUT_, int STRIDE_, int WB_, int OUT_, bool FLAT_ = false>
 struct CG {
   static constexpr int CIN = CIN_, COUT = COUT_, S = STRIDE_, WB = WB_, OUT = OUT_;
+  static constexpr bool FLAT = FLAT_;
   static constexpr int NCH = CIN / 8, NCG = COUT / 16;
   static constexpr int NRB = 16 / WB;                                  // output rows per MFMA column block
   static constexpr int TD = S == 2 ? 2 : 4, TH = 4 * NRB, TW = WB;
-  static constexpr int ID = S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
+  static constexpr int NKZ = FLAT ? 1 : 3;                             // z taps
+  static constexpr int ID = FLAT ? TD : S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
   static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;         // idle lanes read a few slots past a row
-  static constexpr int WQ = 9 * 2 * 64;                                // 16-byte words of one chunk's weight image
+  static constexpr int WQ = NKZ * 3 * 2 * 64;                          // 16-byte words of one chunk's weight image
   static constexpr int NVO = TD * TH * TW;
   static constexpr int LPR = IW <= 16 ? 16 : 32, RPI = 256 / LPR;      // staging: lanes per row, rows per iteration
   static constexpr int NROWS = 2 * ID * IH, NIT = (NROWS + RPI - 1) / RPI;
@@ -961,9 +965,10 @@ struct CG {
   // cost a workgroup per CU (conv2: 138 -> 195 VGPRs, 0.20 -> 0.25 ms), so they keep one item per workgroup.
   static constexpr bool PERSIST = NCH == 1;
   static constexpr int OCC = 2;      // (cutting conv2 / conv6 to 128 VGPRs for a fourth workgroup per CU: no gain / slower)
-  static_assert(CIN % 8 == 0 && COUT % 16 == 0 && (WB == 14 || WB == 8), "shape");
-  static_assert((size_t)NVO * 64 <= (size_t)2 * NVOXP * 16, "split output staging fits in the input tile");
-  static_assert((size_t)16 * (NVO + 2) * 4 <= (size_t)2 * NVOXP * 16, "fp32 output staging fits in the input tile");
+  static_assert(CIN % 8 == 0 && COUT % 16 == 0 && (WB == 14 || WB == 8) && (!FLAT || S == 1), "shape");
+  // (the output staging starts at the LDS base: behind the last barrier the weight fragments are as dead as the input tile)
+  static_assert((size_t)NVO * 64 <= LDS_BYTES, "split output staging fits in the workgroup's LDS");
+  static_assert((size_t)16 * (NVO + 2) * 4 <= LDS_BYTES, "fp32 output staging fits in the workgroup's LDS");
 };
 
 struct ConvGParams {
@@ -1013,7 +1018,7 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
   u32x4 pre[C::NIT], wreg[C::NWIT];
   constexpr bool XPRE = C::PERSIST;
   auto issue = [&](const Item& q, int chunk) __attribute__((always_inline)) {
-    const int iz0 = C::S * q.oz0 - 1, iy0 = C::S * q.oy0 - 1, sgx = C::S * q.ox0 - 1 + lx;
+    const int iz0 = C::FLAT ? q.oz0 : C::S * q.oz0 - 1, iy0 = C::S * q.oy0 - 1, sgx = C::S * q.ox0 - 1 + lx;
     const bool xin = xok && sgx >= 0 && sgx < p.Wi;
     const int sxc = min(max(sgx, 0), p.Wi - 1);
     const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)q.n * C::NCH * 2 * in_plane;
@@ -1073,9 +1078,9 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
       else if (XPRE && has_next) issue(nxt, 0);
 #pragma unroll 1
       for (int ky = 0; ky < 3; ++ky) {
-        bf16x8 a_hi[3], a_lo[3];
+        bf16x8 a_hi[C::NKZ], a_lo[C::NKZ];
 #pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
+        for (int kz = 0; kz < C::NKZ; ++kz) {
           a_hi[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2) * 64]);
           a_lo[kz] = __builtin_bit_cast(bf16x8, wf[((kz * 3 + ky) * 2 + 1) * 64]);
         }
@@ -1085,19 +1090,19 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
           const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW]);
           const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[rowbase + iz * C::IH * C::IW + C::NVOXP]);
 #pragma unroll
-          for (int kz = 0; kz < 3; ++kz) {
-            const int z2 = iz - kz;
+          for (int kz = 0; kz < C::NKZ; ++kz) {
+            const int z2 = iz - kz;      // (FLAT: the single tap is the centre one: input plane iz -> output plane iz)
             if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
               acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
           }
 #pragma unroll
-          for (int kz = 0; kz < 3; ++kz) {
+          for (int kz = 0; kz < C::NKZ; ++kz) {
             const int z2 = iz - kz;
             if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
               acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[kz], b_lo, acc[z2 / C::S], 0, 0, 0);
           }
 #pragma unroll
-          for (int kz = 0; kz < 3; ++kz) {
+          for (int kz = 0; kz < C::NKZ; ++kz) {
             const int z2 = iz - kz;
             if (z2 >= 0 && z2 % C::S == 0 && z2 / C::S < C::TD)
               acc[z2 / C::S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[kz], b_hi, acc[z2 / C::S], 0, 0, 0);
@@ -2206,6 +2211,177 @@ extern "C" int v3d_costreg_layer_split_f32(const v3d_costreg_weights* h, int lay
     case 7: return launch_deconvg<DG<64, 32, 8, kOutF32>>("costreg_conv7", workspace, w, bias, skip, out, nullptr, n, Di, Hi, Wi, s);
     default: return launch_deconvg<DG<32, 16, 14, kOutF32>>("costreg_conv8", workspace, w, bias, skip, out, nullptr, n, Di, Hi, Wi, s);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PropagationNet (mv3d/subnetworks/upsampling.py:14-36, stage 3 of eval-3dvnet.py:101-125):
+//   x = cat(features, depth) -> 4 x [conv2d 3x3 p1 + BN + ReLU] (in -> 32 -> 32 -> 32 -> 9) -> softmax over the 9 logits
+//   -> out = sum_k p_k * depth_pad[y + k / 3, x + k % 3]   (replicate padding).
+// The four conv layers run on the FLAT variant of convg_bf16x2_kernel (split-bf16 matrix cores, the image stack as the
+// z axis, split channel-last activations between the layers, BN folded, ReLU in the epilogue); the input is encoded and
+// the softmax + 3x3 propagation applied by the two small kernels below.  Nothing runs on MIOpen / PyTorch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct v3d_propagation_weights {
+  int in_dim, cinp;
+  float* dev;
+  size_t w_ofs[4], b_ofs[4], total;
+};
+
+namespace {
+// cat(features [B, Cf, HW], depth [B, HW]) -> split layout [CINP / 8][hi, lo][B * HW] (channels >= Cf + 1 are zero)
+__global__ __launch_bounds__(256) void prop_encode_kernel(const float* __restrict__ feat, const float* __restrict__ depth,
+                                                          u32x4* __restrict__ out, int Cf, int n_grp, size_t HW, size_t N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * n_grp) return;
+  const size_t v = i % N;
+  const int g = (int)(i / N);
+  const size_t img = v / HW, px = v % HW;
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = g * 8 + e;
+    const float x = c < Cf ? feat[(img * Cf + c) * HW + px] : c == Cf ? depth[v] : 0.f;
+    h[e] = bf16_rne(x);
+    l[e] = bf16_rne(x - __uint_as_float(h[e] << 16));
+  }
+  out[((size_t)g * 2) * N + v] = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  out[((size_t)g * 2 + 1) * N + v] = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+}
+
+// softmax over the 9 (already ReLU'd) logits of a pixel (upsampling.py:27) and the weighted sum of its replicate-padded 3x3
+// depth neighbourhood in unfold order (:29-36).  logits: [16][B * HW] (channels 9..15 are padding).
+__global__ __launch_bounds__(256) void prop_finish_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
+                                                          float* __restrict__ out, int H, int W, size_t N) {
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= N) return;
+  const size_t HW = (size_t)H * W, img = v / HW;
+  const int y = (int)((v % HW) / W), x = (int)(v % W);
+  float e[9], m = -3.4e38f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { e[k] = logits[(size_t)k * N + v]; m = fmaxf(m, e[k]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { e[k] = expf(e[k] - m); sum += e[k]; }
+  const float* const d = depth + img * HW;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = min(max(y + k / 3 - 1, 0), H - 1), xx = min(max(x + k % 3 - 1, 0), W - 1);
+    acc += (e[k] / sum) * d[(size_t)yy * W + xx];
+  }
+  out[v] = acc;
+}
+}  // namespace
+
+extern "C" int v3d_propagation_pack(const float* const* conv_weight_host, const float* const* bn_weight_host,
+                                    const float* const* bn_bias_host, const float* const* bn_mean_host,
+                                    const float* const* bn_var_host, int in_dim, int h_dim, float bn_eps,
+                                    v3d_propagation_weights** out_handle) {
+  V3D_REQUIRE(conv_weight_host && bn_weight_host && bn_bias_host && bn_mean_host && bn_var_host && out_handle, V3D_ERR_BAD_ARG,
+              "v3d_propagation_pack: null argument");
+  V3D_REQUIRE(h_dim == 32, V3D_ERR_UNSUPPORTED, "v3d_propagation_pack: h_dim=%d unsupported (32, lightningmodel.py:41-43)", h_dim);
+  const int cinp = (in_dim + 7) / 8 * 8;
+  V3D_REQUIRE(in_dim >= 2 && (cinp == 8 || cinp == 24 || cinp == 40), V3D_ERR_UNSUPPORTED,
+              "v3d_propagation_pack: in_dim=%d unsupported (guide channels + 1 <= 8, 17..24 or 33..40)", in_dim);
+  auto* h = new v3d_propagation_weights();
+  h->in_dim = in_dim; h->cinp = cinp; h->dev = nullptr;
+  std::vector<float> host;
+  auto reserve = [&](size_t n) { size_t o = host.size(); host.resize(o + (n + 63) / 64 * 64, 0.f); return o; };
+  auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+  auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+  for (int l = 0; l < 4; ++l) {
+    const int cin = l == 0 ? in_dim : 32, cout = l == 3 ? 9 : 32;
+    const int cp = l == 0 ? cinp : 32, op = l == 3 ? 16 : 32, nch = cp / 8, ncg = op / 16;
+    // [cout group][8-channel chunk][ky][hi, lo][lane 64][4 words]; rows = output channel, k = 8 * x tap + ci (x tap 3 = 0)
+    h->w_ofs[l] = reserve((size_t)ncg * nch * 3 * 2 * 64 * 4);
+    h->b_ofs[l] = reserve(op);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->w_ofs[l]);
+    for (int co = 0; co < cout; ++co) {
+      const float sc = bn_weight_host[l][co] / sqrtf(bn_var_host[l][co] + bn_eps);
+      host[h->b_ofs[l] + co] = bn_bias_host[l][co] - bn_mean_host[l][co] * sc;
+    }
+    for (int g = 0; g < ncg; ++g)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = g * 16 + (lane & 15), kx = lane >> 4;
+            unsigned hi[8], lo[8];
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * 8 + e;
+              float v = 0.f;
+              if (kx <= 2 && co < cout && ci < cin) {
+                const float sc = bn_weight_host[l][co] / sqrtf(bn_var_host[l][co] + bn_eps);
+                v = conv_weight_host[l][(((size_t)co * cin + ci) * 3 + ky) * 3 + kx] * sc;
+              }
+              hi[e] = rne(v);
+              lo[e] = rne(v - up(hi[e]));
+            }
+            for (int part = 0; part < 2; ++part) {
+              const unsigned* src = part ? lo : hi;
+              unsigned* dst = wb + ((((size_t)g * nch + ch) * 3 + ky) * 2 + part) * 256 + lane * 4;
+              for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+            }
+          }
+  }
+  h->total = host.size();
+  hipError_t e = hipMalloc((void**)&h->dev, h->total * sizeof(float));
+  if (e != hipSuccess) { delete h; return v3d::fail(V3D_ERR_HIP, "hipMalloc(propagation weights): %s", hipGetErrorString(e)); }
+  e = hipMemcpy(h->dev, host.data(), h->total * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return v3d::fail(V3D_ERR_HIP, "hipMemcpy(propagation weights): %s", hipGetErrorString(e)); }
+  *out_handle = h;
+  return V3D_OK;
+}
+
+extern "C" void v3d_propagation_free(v3d_propagation_weights* h) {
+  if (!h) return;
+  if (h->dev) (void)hipFree(h->dev);
+  delete h;
+}
+
+extern "C" size_t v3d_propagation_workspace_bytes(const v3d_propagation_weights* h, int B, int H, int W) {
+  if (!h || B <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t N = (size_t)B * H * W;
+  // encoded input (cinp channels), two 32-channel activations (ping-pong), 16 logit channels: 4 bytes per value each
+  return v3d::align_up((size_t)h->cinp * N * 4, 256) + 2 * v3d::align_up((size_t)32 * N * 4, 256) + v3d::align_up((size_t)16 * N * 4, 256);
+}
+
+extern "C" int v3d_propagation_f32(const v3d_propagation_weights* h, const float* features, const float* depth, int B, int Cf,
+                                   int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(h && features && depth && out && workspace, V3D_ERR_BAD_ARG, "v3d_propagation_f32: null argument");
+  V3D_REQUIRE(B > 0 && H > 0 && W > 0 && Cf + 1 == h->in_dim, V3D_ERR_BAD_SHAPE,
+              "v3d_propagation_f32: bad shape (B=%d, Cf=%d, H=%d, W=%d; packed for in_dim=%d)", B, Cf, H, W, h->in_dim);
+  V3D_REQUIRE(workspace_bytes >= v3d_propagation_workspace_bytes(h, B, H, W), V3D_ERR_WORKSPACE_TOO_SMALL,
+              "v3d_propagation_f32: workspace %zu < %zu", workspace_bytes, v3d_propagation_workspace_bytes(h, B, H, W));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = (size_t)B * H * W;
+  V3D_REQUIRE(N * 5 < ((size_t)1 << 31) * 4, V3D_ERR_BAD_SHAPE, "v3d_propagation_f32: batch too large (chunk the views)");
+  char* base = (char*)workspace;
+  void* enc = base;
+  void* a = base + v3d::align_up((size_t)h->cinp * N * 4, 256);
+  void* b = (char*)a + v3d::align_up((size_t)32 * N * 4, 256);
+  float* logits = (float*)((char*)b + v3d::align_up((size_t)32 * N * 4, 256));
+  {
+    v3d::TimedScope ts("propagation_encode", s);
+    const size_t total = N * (h->cinp / 8);
+    prop_encode_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(features, depth, (u32x4*)enc, Cf, h->cinp / 8, (size_t)H * W, N);
+  }
+  V3D_CHECK_LAUNCH("prop_encode_kernel");
+  auto Wt = [&](int l) { return h->dev + h->w_ofs[l]; };
+  auto Bs = [&](int l) { return h->dev + h->b_ofs[l]; };
+  int rc;
+  if (h->cinp == 8) rc = launch_convg<CG<8, 32, 1, 14, kOutSplit, true>>("propagation_conv1", enc, Wt(0), Bs(0), nullptr, a, 1, B, H, W, s);
+  else if (h->cinp == 24) rc = launch_convg<CG<24, 32, 1, 14, kOutSplit, true>>("propagation_conv1", enc, Wt(0), Bs(0), nullptr, a, 1, B, H, W, s);
+  else rc = launch_convg<CG<40, 32, 1, 14, kOutSplit, true>>("propagation_conv1", enc, Wt(0), Bs(0), nullptr, a, 1, B, H, W, s);
+  if (rc != V3D_OK) return rc;
+  if ((rc = launch_convg<CG<32, 32, 1, 14, kOutSplit, true>>("propagation_conv2", a, Wt(1), Bs(1), nullptr, b, 1, B, H, W, s)) != V3D_OK) return rc;
+  if ((rc = launch_convg<CG<32, 32, 1, 14, kOutSplit, true>>("propagation_conv3", b, Wt(2), Bs(2), nullptr, a, 1, B, H, W, s)) != V3D_OK) return rc;
+  if ((rc = launch_convg<CG<32, 16, 1, 14, kOutF32, true>>("propagation_conv4", a, Wt(3), Bs(3), logits, nullptr, 1, B, H, W, s)) != V3D_OK) return rc;
+  {
+    v3d::TimedScope ts("propagation_softmax_sum", s);
+    prop_finish_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(logits, depth, out, H, W, N);
+  }
+  V3D_CHECK_LAUNCH("prop_finish_kernel");
+  return V3D_OK;
 }
 
 namespace {

@@ -1,47 +1,105 @@
-"""Depth upsampling by learned 3x3 propagation -- "next" row of SURVEY.md §8f (rank 2), the stage that
-follows the hot path in ``mv3d/eval-3dvnet.py:101-125``.  Mirrors the interface and ``state_dict`` keys of
-``mv3d/subnetworks/upsampling.py::PropagationNet`` (``conv{1..4}.{0.weight,1.*}``).
+"""Depth upsampling by learned 3x3 propagation -- SURVEY.md §8f rank 2, the stage that follows the hot path in
+``mv3d/eval-3dvnet.py:101-125``.  Host-side mirror of ``mv3d/subnetworks/upsampling.py::PropagationNet``: same
+constructor, ``forward(features, depth)`` signature and ``state_dict`` keys (``conv{1..4}.{0.weight,1.*}``).
 
-Like in the reference these are stock 2D convolutions executed by PyTorch-ROCm (MIOpen); nothing here is a
-hand-written kernel.  Formulation: the 9-way softmax weights are applied to the nine shifted views of the
-replicate-padded depth map (no im2col buffer).
+The arithmetic runs in the HIP library (``v3d_propagation_f32``, csrc/costreg.hip): the four 3x3 convolutions on
+split-bf16 matrix cores with eval-mode BatchNorm folded and ReLU in the epilogue, activations between the layers in the
+split channel-last layout, then one kernel for the 9-way softmax and the weighted sum over the replicate-padded 3x3
+depth neighbourhood (no unfold buffer).  No CPU fallback: tensors must live on a HIP device.
 """
+import ctypes
+
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+from .mvsnet import _Workspace, module_state_key
+
 
 def _stage(c_in, c_out):
+    """Parameter container with the reference's layout (upsampling.py:6-11)."""
     return nn.Sequential(nn.Conv2d(c_in, c_out, 3, 1, 1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU(inplace=True))
 
 
 class PropagationNet(nn.Module):
-    """``forward(features[B,Cf,H,W], depth[B,1,H,W]) -> [B,H,W]``: each output depth is a convex
-    combination (softmax over 9 logits predicted from features+depth) of its 3x3 neighbourhood."""
+    """``forward(features[B,Cf,H,W], depth[B,1,H,W]) -> [B,H,W]``: each output depth is a convex combination (softmax
+    over 9 logits predicted from features+depth) of its 3x3 neighbourhood (upsampling.py:23-36)."""
 
     def __init__(self, in_dim=4, h_dim=32):
         super().__init__()
+        self.in_dim, self.h_dim = in_dim, h_dim
         widths = [in_dim, h_dim, h_dim, h_dim, 9]
         for i in range(4):
             setattr(self, 'conv%d' % (i + 1), _stage(widths[i], widths[i + 1]))
+        self._handle, self._packed_key = None, None
+        self._ws = _Workspace()
+
+    def packed_handle(self, device):
+        key = (str(device),) + module_state_key(self)
+        if self._handle is not None and key == self._packed_key:
+            return self._handle
+        self.release()
+        lib = _lib.load()
+        keep = []
+
+        def host(t):
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_float_p)
+
+        def parray(ts):
+            arr = (_lib.c_float_p * len(ts))(*[host(t) for t in ts])
+            keep.append(arr)
+            return arr
+        stages = [getattr(self, 'conv%d' % i) for i in range(1, 5)]
+        eps = {float(st[1].eps) for st in stages}
+        assert len(eps) == 1
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):          # the library allocates the weight image on the current device
+            rc = lib.v3d_propagation_pack(parray([st[0].weight for st in stages]), parray([st[1].weight for st in stages]),
+                                          parray([st[1].bias for st in stages]), parray([st[1].running_mean for st in stages]),
+                                          parray([st[1].running_var for st in stages]), self.in_dim, self.h_dim, eps.pop(),
+                                          ctypes.byref(handle))
+        _lib.check(rc, 'v3d_propagation_pack')
+        self._handle, self._packed_key = handle, key
+        return handle
+
+    def release(self):
+        if self._handle is not None:
+            _lib.load().v3d_propagation_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def forward(self, features, depth):
-        x = torch.cat((features, depth), dim=1)
-        for i in range(1, 5):
-            x = getattr(self, 'conv%d' % i)(x)
-        w = F.softmax(x, dim=1)                                   # [B, 9, H, W], row-major 3x3 order
-        padded = F.pad(depth, (1, 1, 1, 1), mode='replicate')[:, 0]
-        H, W = depth.shape[-2:]
-        out = torch.zeros_like(depth[:, 0])
-        for k in range(9):
-            dy, dx = divmod(k, 3)
-            out = out + w[:, k] * padded[:, dy:dy + H, dx:dx + W]
+        if not (features.is_cuda and depth.is_cuda):
+            raise _lib.V3DLibraryError('PropagationNet: tensors must live on a HIP device (no CPU fallback)')
+        assert not self.training, 'inference only: BatchNorm is folded with running statistics'
+        lib = _lib.load()
+        dev = features.device
+        features = features.contiguous().float()
+        depth = depth.contiguous().float()
+        B, Cf, H, W = features.shape
+        assert depth.shape == (B, 1, H, W) and Cf + 1 == self.in_dim, (tuple(depth.shape), tuple(features.shape), self.in_dim)
+        handle = self.packed_handle(dev)
+        out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        ws = self._ws.get('prop', lib.v3d_propagation_workspace_bytes(handle, B, H, W), dev)
+        rc = lib.v3d_propagation_f32(handle, features.data_ptr(), depth.data_ptr(), B, Cf, H, W, out.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, 'v3d_propagation_f32')
         return out
 
 
 def upsample_depth(all_depth, stages, chunk=100):
     """Stage 3 of the scene driver (eval-3dvnet.py:101-125): for each (PropagationNet, guide tensor) pair,
-    nearest-neighbour resize the depth to the guide's resolution and refine it, `chunk` views at a time."""
+    nearest-neighbour resize the depth to the guide's resolution and refine it, `chunk` views at a time
+    (UPSAMPLE_BATCH = 100 in the reference)."""
     for net, guide in stages:
         all_depth = F.interpolate(all_depth.unsqueeze(1), guide.shape[-2:], mode='nearest').squeeze(1)
         for s in range(0, all_depth.shape[0], chunk):

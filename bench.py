@@ -343,12 +343,16 @@ def bench_scene(args, rank, world, dev, dist):
     # eval script runs its driver with 2 src on either side = 5 edges, eval/main.py:36: `--scene-window 2,2`.)
     nb, na = (int(v) for v in args.scene_window.split(','))
     win = (nb, na)
+    stage3 = bool(getattr(args, 'stage3', False))       # + the three PropagationNet upsampling steps to 256 x 320
 
     def make(n_ref, seed):
         edges, n_img = syn.make_edges(n_ref, nb, na)
         rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=seed, yaw_step_deg=360.0 / max(n_img, 60))
         bb = Batch(None, rot, tv, K, None, edges)
         bb.features_quarter = syn.make_features(n_img, 32, *cfg['feat_size'], seed=seed)
+        if stage3:      # the guides of stage 3 (eval-3dvnet.py:36,62,118): half-resolution features and the images
+            bb.features_half = syn.make_features(n_img, 32, 2 * cfg['feat_size'][0], 2 * cfg['feat_size'][1], seed=seed + 1)
+            bb.images = syn.make_images(n_img, cfg['img_size'], seed=seed + 2)
         # Random synthetic features give noise depths => a volume-filling point cloud.  Stage 1 runs and is timed, but
         # its output is then replaced by surface-like depths (analytic wall depth of the box room + 2 cm seeded noise,
         # SURVEY §8d) so that the scene model and the point-flow sweeps see a ScanNet-like voxel count.
@@ -366,12 +370,15 @@ def bench_scene(args, rank, world, dev, dist):
     net.pointnet.load_state_dict(sds['pn'])
     net.sparse_conv.load_state_dict(sds['un'])
     net.decoder.load_state_dict(sds['dec'], strict=False)
+    sds_prop = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
+    for m, sdp in zip((net.refine_quarter, net.refine_half, net.refine_full), sds_prop):
+        m.load_state_dict(sdp, strict=False)
     net = net.to(dev)
     group = None
 
     def step():
         return drv.process_scene(b, net, win, dev, rank=rank, world=world, group=group, gather_depth=False,
-                                 init_depth_override=gt)
+                                 init_depth_override=gt, upsample=stage3)
 
     def fence():
         torch.cuda.synchronize()
@@ -404,6 +411,21 @@ def bench_scene(args, rank, world, dev, dist):
         for name, (ms, c) in sorted(st.items(), key=lambda kv: -kv[1][0]):
             kernels[name] = dict(total_ms=round(ms, 3), launches=c, share=round(ms / tot, 3))
         dom = max(st, key=lambda kk: st[kk][0])
+        stage3_info = None
+        if stage3:
+            # stage 3's own figures: time of its launches inside the scene, and the four conv layers priced against the
+            # split-bf16 MFMA peak: 2*9*(33*32 + 2*32*32 + 32*9) FLOP per pixel at 1/4 and 1/2 resolution, 4 instead of 33
+            # input channels at full resolution (upsampling.py:17-20)
+            H, W = cfg['img_size']
+            per_px = lambda cin: 2.0 * 9 * (cin * 32 + 2 * 32 * 32 + 32 * 9)
+            flops3 = (refs // world) * ((H // 4) * (W // 4) * per_px(33) + (H // 2) * (W // 2) * per_px(33) + H * W * per_px(4))
+            conv_ms = sum(ms for kk, (ms, _) in st.items() if kk.startswith('propagation_conv'))
+            all_ms = sum(ms for kk, (ms, _) in st.items() if kk.startswith('propagation_'))
+            a3 = flops3 / (conv_ms * 1e-3) / 1e12
+            stage3_info = dict(stage3_kernel_ms_per_scene=round(all_ms, 3), conv_kernel_ms_per_scene=round(conv_ms, 3),
+                               roofline=dict(bound='mfma', achieved=a3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0, unit='TFLOP/s',
+                                             frac=a3 / (PEAK_BF16_MFMA_TFLOPS / 3.0), kernel='propagation_conv1..4 (all three '
+                                             'resolutions)', avg_ms=conv_ms / 12.0, traffic=None))
         if dom in ('conv1d_gemm', 'decoder_fused'):
             # decoder conv1d stack: 2*7*P*(3*352*128 + 2*3*128*128 + 3*128) FLOP per view per sweep, 6 sweeps
             P = drv.DEPTH_CONFIG['size'][0] * drv.DEPTH_CONFIG['size'][1]
@@ -420,12 +442,19 @@ def bench_scene(args, rank, world, dev, dist):
         n_chk = 4
         bs, gts = make(n_chk, 77)
         with torch.no_grad():
-            d_hip = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev)).cpu()
+            d_hip = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev), upsample=stage3).cpu()
             nt = min(32, os.cpu_count() or 1)
             torch.set_num_threads(nt)
             onet = OracleNet(sds['cr'], sds['pn'], sds['un'], sds['dec'], cfg['img_size'], cfg['edge_len'], pinned=True)
             t_cpu = time.perf_counter()
             d_cpu = drv.process_scene(bs, onet, win, torch.device('cpu'), init_depth_override=gts)
+            if stage3:      # the oracle's stage-3 chain (oracle/scene.py::propagation_net) on the refined plane-grid depths
+                from oracle import scene as osc
+                import torch.nn.functional as F
+                d_grid = d_cpu
+                for sdp, gd in zip(sds_prop, (bs.features_quarter[nb:nb + n_chk], bs.features_half[nb:nb + n_chk],
+                                              bs.images[nb:nb + n_chk])):
+                    d_cpu = osc.propagation_net(gd, F.interpolate(d_cpu.unsqueeze(1), gd.shape[-2:], mode='nearest'), sdp)
             t_cpu = time.perf_counter() - t_cpu
         # the reference's CPU path of the WHOLE pipeline (dense-formulation sparse convolutions, torch CPU
         # grid_sample / Conv3d) timed beside the GPU figure -- the run that also serves as the checker, one pass, no warm-up
@@ -437,18 +466,23 @@ def bench_scene(args, rank, world, dev, dist):
         parity = dict(checked_views=n_chk, checker='oracle-backed scene driver (oracle/net.py: oracle/costvolume.py + '
                       'oracle/scene.py), same driver code, CPU',
                       max_rel_depth_err_gpu_vs_cpu=float(((d_hip - d_cpu).abs() / d_cpu).max()),
-                      max_abs_refinement_m=float((d_cpu - gts).abs().max()))
+                      max_abs_refinement_m=float(((d_grid if stage3 else d_cpu) - gts).abs().max()))
     if rank != 0:
         return None
+    line_extra = {'stage3': stage3_info} if stage3 and rank == 0 else {}
     return {
-        'metric': 'depth maps/sec (256x320, 96 planes, full 3DVNet pipeline: cost volume + scene model + 2x3 sweeps)',
+        **line_extra,
+        'metric': 'depth maps/sec (256x320, 96 planes, full 3DVNet pipeline: cost volume + scene model + 2x3 sweeps%s)'
+                  % (' + stage-3 upsampling to 256x320' if stage3 else ''),
         'value': value, 'unit': 'depth maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
         'config': {'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, %d edges/ref (ref-%d .. ref+%d), '
                                '96 planes, 56x56 plane grid, 4 cm voxels; stage A (timed) -> its depths replaced '
-                               'by analytic wall depth + 2 cm noise -> 2 x (scene model + 3 point-flow sweeps)'
-                               % (args.config, refs, nb + na + 1, nb, na),
+                               'by analytic wall depth + 2 cm noise -> 2 x (scene model + 3 point-flow sweeps)%s'
+                               % (args.config, refs, nb + na + 1, nb, na,
+                                  ' -> stage 3: nearest + PropagationNet at 64x80, 128x160, 256x320 (eval-3dvnet.py:101-125)'
+                                  if stage3 else ''),
                    'refs_per_scene': refs, 'refs_per_gpu': refs // world, 'edges_per_ref': nb + na + 1,
                    'parallelism': ('ref-view sharding + RCCL all-gather of the feature-rich point cloud per outer '
                                    'iteration (the communicating mode)' if world > 1 else 'single GPU'),
@@ -599,6 +633,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--scene-window', default='4,3', help='cfg3/cfg4: source views before,after each reference view '
                     '(4,3 = SURVEY 8d: 1 ref + 7 src; 2,2 = the reference eval script)')
+    ap.add_argument('--stage3', action='store_true', help='cfg3/cfg4: include stage 3 (PropagationNet upsampling to full '
+                    'resolution) in the timed scene')
     ap.add_argument('--no-extra', action='store_true', help='default cfg2 run: do not append the cfg5 / cfg3 figures')
     ap.add_argument('--extra', action='store_true', help='append the cfg5 / cfg3 figures also when --refs is given')
     ap.add_argument('--dry-run', action='store_true', help='rank plumbing only (gloo, no GPU, no-op step): see bench_dry_run')
@@ -639,6 +675,12 @@ def main():
             a3 = copy.copy(args)
             a3.config, a3.refs, a3.steps, a3.warmup = 'cfg3', 64, min(args.steps, 10), 2
             extra['cfg3'] = compact(bench_scene(a3, rank, world, dev, dist))
+            # ... and the same scene with stage 3 (full-resolution output): BASELINE config 3's "Full 3DVNet" end to end
+            a3f = copy.copy(a3)
+            a3f.stage3, a3f.steps = True, min(args.steps, 5)
+            line3f = bench_scene(a3f, rank, world, dev, dist)
+            extra['cfg3_full'] = compact(line3f)
+            extra['cfg3_full']['stage3'] = line3f.get('stage3')
             line['extra'] = extra
             line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '
                                                 'scaling: reference views are independent units); the communicating mode is '

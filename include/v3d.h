@@ -296,6 +296,26 @@ int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int C, const fl
                          const float* bias, const float* offset_vals, float* preds, float* expect,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md 8f rank 2 -- PropagationNet, the learned 3x3 depth propagation of stage 3
+ * (mv3d/subnetworks/upsampling.py:14-36; called at 1/4, 1/2 and full resolution by mv3d/eval-3dvnet.py:101-125 and
+ * mv3d/lightningmodel.py:85,98,111).  Replaces PropagationNet.forward(features, depth):
+ *   x = cat(features, depth); four Conv2d(3x3, pad 1, no bias) + BatchNorm2d (eval, folded) + ReLU (in -> 32 -> 32 -> 32 -> 9);
+ *   p = softmax over the 9 logits; out = sum_k p_k * unfold(replicate_pad(depth))_k.
+ * v3d_propagation_pack takes HOST pointers to conv{1..4}.0.weight [Co, Ci, 3, 3] and conv{1..4}.1.{weight, bias,
+ * running_mean, running_var}; in_dim = guide channels + 1 (33 for the feature-guided nets, 4 for the image-guided one).
+ *   features [B, in_dim - 1, H, W], depth [B, 1, H, W] (= [B, H, W]), out [B, H, W]; split-bf16 MFMA operands.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct v3d_propagation_weights v3d_propagation_weights;
+int v3d_propagation_pack(const float* const* conv_weight_host, const float* const* bn_weight_host,
+                         const float* const* bn_bias_host, const float* const* bn_mean_host,
+                         const float* const* bn_var_host, int in_dim, int h_dim, float bn_eps,
+                         v3d_propagation_weights** out_handle);
+void v3d_propagation_free(v3d_propagation_weights* handle);
+size_t v3d_propagation_workspace_bytes(const v3d_propagation_weights* handle, int B, int H, int W);
+int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* features, const float* depth, int B, int Cf,
+                        int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Rows C2a + C2b + C3 fused: MinkowskiInterpolation of the three U-Net levels at the hypothesis
  * points (mv3d/subnetworks/refinement.py:28-41) -> the three Conv1d+BN+ReLU layers along the hypothesis axis (:16-23) ->
  * Conv1d(128 -> 1) + softmax (:24,43) -> expected offset (mv3d/lightningmodel.py:237-241) in ONE kernel: the

