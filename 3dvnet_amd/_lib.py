@@ -43,6 +43,10 @@ SIGNATURES = {
                                      [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'v3d_psv_variance_split': (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_double] * 2 + [c_int] * 3 +
                                [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_psv_variance_cl8': (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_double] * 2 + [c_int] * 3 +
+                             [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_costreg_depth_cl8': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p,
+                                                                    c_size_t, c_void_p]),
     'v3d_costreg_pack': (c_int, [c_float_pp] * 5 + [c_float_p, c_float_p, c_int, c_int, c_float,
                                                      ctypes.POINTER(c_void_p)]),
     'v3d_costreg_free': (None, [c_void_p]),

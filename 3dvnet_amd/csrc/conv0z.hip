@@ -100,6 +100,11 @@ __device__ unsigned long long g_cz_phase[8 * 1024];
 #define V3D_CZ_ABLATE 0      // developer ablations: 1 no MFMAs, 2 no DMA, 3 no reduction / finalize
 #endif
 
+// F32 (exact-fp32 operands, V3D_PRECISION_FP32): the input is the fp32 channel-last volume of v3d_psv_variance_cl8 -- the split
+// layout's addressing, the "hi" rows holding channels 0..3 and the "lo" rows channels 4..7 of a group as floats -- the products
+// run on v_mfma_f32_16x16x4_f32 (K = 4 x taps of ONE channel per instruction, 8 instructions per (kz, ky) where the bf16 path
+// has 3), the output is the fp32 [n, 8, D, H, W] tensor the exact-fp32 per-layer kernels continue from.
+template <bool F32>
 __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,8 +142,16 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
   if (!helper) {
     if (V3D_CZ_MPRIO) __builtin_amdgcn_s_setprio(V3D_CZ_MPRIO);
     // ================= matrix role: chunk `wave` of every input plane -> partial sums of 3 out planes =================
-    bf16x8 a_hi[9], a_lo[9];                                           // this wave's weight fragments: resident for the whole kernel
-    {
+    // this wave's weight fragments: resident for the whole kernel (72 registers in both arithmetic types)
+    bf16x8 a_hi[F32 ? 1 : 9], a_lo[F32 ? 1 : 9];
+    float a32[F32 ? 9 : 1][8];                                         // F32: [kz * 3 + ky][channel]: lane (kq, m) = W[row m][x tap kq]
+    if constexpr (F32) {
+      const float* wq = reinterpret_cast<const float*>(p.wp) + (size_t)wave * (9 * 8 * 64) + lane;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a32[k][e] = wq[(k * 8 + e) * 64];
+    } else {
       const u32x4* wq = reinterpret_cast<const u32x4*>(p.wp) + (size_t)wave * (9 * 2 * 64) + lane;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
@@ -178,11 +191,11 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
           // 21 (ky, block) items, each 2 ds_read_b128 -> 9 MFMAs; the B fragments run kPre items ahead of the MFMAs, the
           // scheduler is pinned to that order
           constexpr int NI = 3 * CZ::NBLK, kPre = 2;
-          bf16x8 bh_[NI], bl_[NI];
+          u32x4 bh_[NI], bl_[NI];
           auto load = [&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value, ky = i / CZ::NBLK, b = i % CZ::NBLK;
-            bh_[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16)));
-            bl_[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16) + CZ::HL_BYTES));
+            bh_[i] = *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16));
+            bl_[i] = *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16) + CZ::HL_BYTES);
           };
           // Out plane zi - 1 (slot A2) is complete block by block during the ky = 2 items (block b after item 14 + b).  Its
           // partial sums leave for LDS behind the LAST B-fragment reads (issued with item NI - 1 - kPre): lgkmcnt counts in
@@ -196,34 +209,48 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
             if constexpr (i + kPre < NI) load(std::integral_constant<int, i + kPre>{});
             if constexpr (i == NI - 2) { put(0); put(1); put(2); }
             if constexpr (i == NI - 1) { put(3); put(4); }
-            const bf16x8 b_hi = bh_[i], b_lo = bl_[i];
-            // kz = 0 is the first contribution to out plane zi + 1: its first product starts from zero
-            const f32x4 c0 = ky == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[A0][b];
-            acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[0 * 3 + ky], b_hi, c0, 0, 0, 0);
-            acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[1 * 3 + ky], b_hi, acc[A1][b], 0, 0, 0);
-            acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[2 * 3 + ky], b_hi, acc[A2][b], 0, 0, 0);
-            acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[0 * 3 + ky], b_lo, acc[A0][b], 0, 0, 0);
-            acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[1 * 3 + ky], b_lo, acc[A1][b], 0, 0, 0);
-            acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[2 * 3 + ky], b_lo, acc[A2][b], 0, 0, 0);
-            acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[0 * 3 + ky], b_hi, acc[A0][b], 0, 0, 0);
-            acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[1 * 3 + ky], b_hi, acc[A1][b], 0, 0, 0);
-            acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[2 * 3 + ky], b_hi, acc[A2][b], 0, 0, 0);
+            constexpr int NM = F32 ? 24 : 9;                           // MFMAs per item
+            if constexpr (F32) {
+              // one channel per instruction (k = the 4 x taps): channels 0..3 from the first half slot, 4..7 from the second;
+              // kz = 0 is the first contribution to out plane zi + 1: its first product starts from zero
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float bv = __uint_as_float(e < 4 ? bh_[i][e & 3] : bl_[i][e & 3]);
+                const f32x4 c0 = (ky == 0 && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[A0][b];
+                acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32[0 * 3 + ky][e], bv, c0, 0, 0, 0);
+                acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32[1 * 3 + ky][e], bv, acc[A1][b], 0, 0, 0);
+                acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32[2 * 3 + ky][e], bv, acc[A2][b], 0, 0, 0);
+              }
+            } else {
+              const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bh_[i]), b_lo = __builtin_bit_cast(bf16x8, bl_[i]);
+              // kz = 0 is the first contribution to out plane zi + 1: its first product starts from zero
+              const f32x4 c0 = ky == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[A0][b];
+              acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[0 * 3 + ky], b_hi, c0, 0, 0, 0);
+              acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[1 * 3 + ky], b_hi, acc[A1][b], 0, 0, 0);
+              acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[2 * 3 + ky], b_hi, acc[A2][b], 0, 0, 0);
+              acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[0 * 3 + ky], b_lo, acc[A0][b], 0, 0, 0);
+              acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[1 * 3 + ky], b_lo, acc[A1][b], 0, 0, 0);
+              acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[2 * 3 + ky], b_lo, acc[A2][b], 0, 0, 0);
+              acc[A0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[0 * 3 + ky], b_hi, acc[A0][b], 0, 0, 0);
+              acc[A1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[1 * 3 + ky], b_hi, acc[A1][b], 0, 0, 0);
+              acc[A2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[2 * 3 + ky], b_hi, acc[A2][b], 0, 0, 0);
+            }
             if constexpr (i + kPre < NI) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
             if constexpr (i == NI - 2 && V3D_CZ_ABLATE != 3) {                                   // stores between the MFMAs
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             } else if constexpr (i == NI - 1 && V3D_CZ_ABLATE != 3) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NM / 3, 0);
             } else {
-              __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);                                 // 9 MFMAs
+              __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                // the item's MFMAs
             }
           };
           load(std::integral_constant<int, 0>{});
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
       }
       const char* const in_c = reinterpret_cast<const char*>(p.in) + ((size_t)(q.n * 4 + wave) * 2) * DHW * 16;
       u32x2* const outs = reinterpret_cast<u32x2*>(p.out) + ((size_t)q.n * 2 * DHW) * 2 + (kq & 1);
+      float* const out32 = reinterpret_cast<float*>(p.out) + (size_t)q.n * 8 * DHW;
 
       // one plane of this chunk -> ring slot `rs`: 5 pieces of hi rows, 5 of lo rows
       auto issue = [&](int z, int rs) __attribute__((always_inline)) {
@@ -383,8 +411,15 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
           const unsigned l23 = cz_pack_bf16x2(val[2] - __uint_as_float(h23 << 16), val[3] - __uint_as_float(h23 & 0xffff0000u));
           if (fok[k]) {
             const size_t sp = (size_t)zo * HW + fsp[k];
-            outs[sp * 2] = (u32x2){h01, h23};
-            outs[(DHW + sp) * 2] = (u32x2){l01, l23};
+            if constexpr (F32) {
+              // fp32 [n, 8, D, H, W]: this lane's four channels of its voxel (the 16 lanes of a quarter cover every other x
+              // of a row; the quarter with the other x parity fills the gaps of the same 128-byte lines)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) out32[(size_t)(4 * (kq & 1) + r) * DHW + sp] = val[r];
+            } else {
+              outs[sp * 2] = (u32x2){h01, h23};
+              outs[(DHW + sp) * 2] = (u32x2){l01, l23};
+            }
           }
         }
       };
@@ -424,12 +459,13 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
 
 }  // namespace
 
-// conv0 + folded BN + ReLU of a batch of split variance volumes -> split activation (the fused path's hand-off formats).
-int v3d::launch_conv0z(const void* in_split, const float* wbf, const float* bias, void* out_split, int n, int D, int H, int W,
+// conv0 + folded BN + ReLU of a batch of variance volumes: split-bf16 hand-off formats in and out (f32 = false), or the fp32
+// channel-last volume in and the fp32 [n, 8, D, H, W] tensor out (f32 = true; `wimg` = the fp32 fragment image).
+int v3d::launch_conv0z(bool f32, const void* in, const float* wimg, const float* bias, void* out, int n, int D, int H, int W,
                        hipStream_t s) {
   V3D_REQUIRE((long long)D * H * W * 16 < (1ll << 32), V3D_ERR_BAD_SHAPE, "conv0: volume too large for 32-bit plane offsets");
   CZParams p;
-  p.in = in_split; p.wp = wbf; p.bias = bias; p.out = out_split;
+  p.in = in; p.wp = wimg; p.bias = bias; p.out = out;
   p.n = n; p.D = D; p.H = H; p.W = W;
   p.nty = (H + CZ::TH - 1) / CZ::TH; p.ntx = (W + CZ::TW - 1) / CZ::TW;
   int dev = 0, n_cu = 0;
@@ -449,14 +485,17 @@ int v3d::launch_conv0z(const void* in_split, const float* wbf, const float* bias
   const long long tasks = tiles * p.nseg;
   V3D_REQUIRE(tasks > 0 && tasks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: bad grid");
   p.n_tasks = (int)tasks;
-  static bool attr_set[64] = {false};
-  if (dev < 64 && !attr_set[dev]) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0z_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CZ::LDS_BYTES));
-    attr_set[dev] = true;
+  static bool attr_set[64][2] = {{false}};
+  V3D_REQUIRE(dev >= 0 && dev < 64, V3D_ERR_UNSUPPORTED, "conv0: device ordinal %d", dev);
+  if (!attr_set[dev][f32]) {
+    V3D_CHECK_HIP(hipFuncSetAttribute(f32 ? (const void*)conv0z_kernel<true> : (const void*)conv0z_kernel<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, CZ::LDS_BYTES));
+    attr_set[dev][f32] = true;
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
-    conv0z_kernel<<<v3d::persistent_grid(tasks, 1), 512, CZ::LDS_BYTES, s>>>(p);
+    if (f32) conv0z_kernel<true><<<v3d::persistent_grid(tasks, 1), 512, CZ::LDS_BYTES, s>>>(p);
+    else conv0z_kernel<false><<<v3d::persistent_grid(tasks, 1), 512, CZ::LDS_BYTES, s>>>(p);
   }
   V3D_CHECK_LAUNCH("conv0z_kernel");
   return V3D_OK;

@@ -1945,7 +1945,7 @@ int launch_deconvg(const char* name, const void* in, const float* wbf, const flo
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, cgbf_ofs[7], dgbf_ofs[2], c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c0f32_ofs, cgbf_ofs[7], dgbf_ofs[2], c9bf_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -2026,6 +2026,25 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
             for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
           }
         }
+  }
+  {
+    // exact-fp32 image of conv0 for conv0z_kernel<true> (v_mfma_f32_16x16x4_f32, pair mode): [chunk 4][kz * 3 + ky][channel 8]
+    // [lane 64]; lane (kq, m): row m = x shift * 8 + co, k = x tap kq of the 4-wide window
+    const int l = 0;
+    h->c0f32_ofs = reserve((size_t)4 * 9 * 8 * 64);
+    float* wf = host.data() + h->c0f32_ofs;
+    for (int chunk = 0; chunk < 4; ++chunk)
+      for (int kzy = 0; kzy < 9; ++kzy)
+        for (int e = 0; e < 8; ++e)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, kxp = lane >> 4, sx = row >> 3, co = row & 7, kx = kxp - sx, ci = chunk * 8 + e;
+            float v = 0.f;
+            if (kx >= 0 && kx <= 2) {
+              const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+              v = conv_w[l][((size_t)co * 32 + ci) * 27 + kzy * 3 + kx] * sc;
+            }
+            wf[(((size_t)chunk * 9 + kzy) * 8 + e) * 64 + lane] = v;
+          }
   }
   {
     // split-bf16 image of conv9 for conv9_prob_kernel: [block 9][hi, lo][lane 64][4 words]; block = tz3 * 3 + ty3 with
@@ -2405,7 +2424,8 @@ extern "C" size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights*, int n_
   return plan_ws(n_ref, D, h, w).total;
 }
 
-static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const float* var,
+// in_layout: 0 = reference fp32 [n, C, D, h, w], 1 = split-bf16 hand-off, 2 = fp32 channel-last (v3d_psv_variance_cl8)
+static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const float* var,
                               const float* depth_vals, int n, int D, int H, int W,
                               float* depth, float* reg, int precision, void* workspace,
                               size_t workspace_bytes, void* stream) {
@@ -2429,9 +2449,16 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
   // [n, C, D, H, W] tensors in between.  V3D_PRECISION_SPLIT_BF16: every layer on split-bf16 matrix cores, activations
   // in the split channel-last hand-off format (same bytes as fp32).
   const bool generic = precision == V3D_PRECISION_FP32;
-  V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_PRECISION_FP32 needs the fp32 variance volume");
+  const bool split_in = in_layout == 1, cl8_in = in_layout == 2;
+  V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_PRECISION_FP32 needs an fp32 variance volume");
+  V3D_REQUIRE(generic || !cl8_in, V3D_ERR_UNSUPPORTED, "the fp32 channel-last volume is the input of V3D_PRECISION_FP32");
   if (generic) {
-    RUN(0, var, nullptr, F(ws.c0), D, H, W);
+    if (cl8_in) {      // conv0 as a depth march on exact-fp32 matrix instructions (conv0z.hip)
+      if ((rc = v3d::launch_conv0z(true, var, h->dev + h->c0f32_ofs, h->dev + h->bias_ofs[0], F(ws.c0), n, D, H, W, s)) != V3D_OK)
+        return rc;
+    } else {
+      RUN(0, var, nullptr, F(ws.c0), D, H, W);
+    }
     RUN(1, F(ws.c0), nullptr, F(ws.c1), D, H, W);
     RUN(2, F(ws.c1), nullptr, F(ws.c2), D / 2, H / 2, W / 2);
   } else {
@@ -2439,13 +2466,13 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
     // on a reference-layout tensor, return_intermediates) encodes one view at a time into the workspace's `enc` slot and runs
     // the same kernel on it: both entry points give the same bits.
     if (split_in) {
-      if ((rc = v3d::launch_conv0z(var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0), n, D, H, W, s)) != V3D_OK) return rc;
+      if ((rc = v3d::launch_conv0z(false, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0), n, D, H, W, s)) != V3D_OK) return rc;
     } else {
       const size_t V0 = (size_t)D * H * W, total = 4 * V0;
       for (int i = 0; i < n; ++i) {
         encode_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(var + (size_t)i * 32 * V0, (u32x4*)F(ws.enc), 32, V0, total);
         V3D_CHECK_LAUNCH("encode_split_kernel");
-        if ((rc = v3d::launch_conv0z(F(ws.enc), h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0) + (size_t)i * 8 * V0, 1, D, H,
+        if ((rc = v3d::launch_conv0z(false, F(ws.enc), h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0) + (size_t)i * 8 * V0, 1, D, H,
                                      W, s)) != V3D_OK) return rc;
       }
     }
@@ -2535,14 +2562,21 @@ static int costreg_depth_impl(bool split_in, const v3d_costreg_weights* h, const
 extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var, const float* depth_vals, int n,
                                      int D, int H, int W, float* depth, float* reg, int precision, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  return costreg_depth_impl(false, h, var, depth_vals, n, D, H, W, depth, reg, precision, workspace, workspace_bytes,
+  return costreg_depth_impl(0, h, var, depth_vals, n, D, H, W, depth, reg, precision, workspace, workspace_bytes,
                             stream);
+}
+
+extern "C" int v3d_costreg_depth_cl8(const v3d_costreg_weights* h, const void* var_cl8, const float* depth_vals,
+                                     int n, int D, int H, int W, float* depth, float* reg, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return costreg_depth_impl(2, h, (const float*)var_cl8, depth_vals, n, D, H, W, depth, reg, V3D_PRECISION_FP32, workspace,
+                            workspace_bytes, stream);
 }
 
 extern "C" int v3d_costreg_depth_split(const v3d_costreg_weights* h, const void* var_split, const float* depth_vals,
                                        int n, int D, int H, int W, float* depth, float* reg, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-  return costreg_depth_impl(true, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg,
+  return costreg_depth_impl(1, h, (const float*)var_split, depth_vals, n, D, H, W, depth, reg,
                             V3D_PRECISION_SPLIT_BF16, workspace, workspace_bytes, stream);
 }
 

@@ -667,8 +667,12 @@ __device__ __forceinline__ int psv_smax(int a, int b) { int r; asm("s_max_i32 %0
 #ifndef V3D_PSVW_ABLATE
 #define V3D_PSVW_ABLATE 0    // developer ablations of the window kernel: 1 no blend, 2 no footprint reads, 3 no window copy, 5 no store, 6 no out-of-window path
 #endif
-template <bool SPLIT>
+// CL8 (with SPLIT's geometry: one wave per workgroup, direct stores): the volume leaves as fp32 in the channel-last layout
+// of the exact-fp32 depth-march conv0 (conv0z.hip) -- [n_ref][4 channel groups][2 halves][D][h][w] 16-byte slots of 4 floats
+// (include/v3d.h, v3d_psv_variance_cl8): the split layout's addressing with the values themselves instead of bf16 pairs.
+template <bool SPLIT, bool CL8 = false>
 __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_window_kernel(PsvParams p) {
+  static_assert(SPLIT || !CL8, "the channel-last fp32 output uses the single-wave geometry");
   constexpr int C = 32, WPB = SPLIT ? 1 : 4;
   constexpr unsigned CB = 4 * C;                            // bytes per cell
   constexpr int kOutPl = 4;                                 // planes staged per round of the fp32 epilogue
@@ -921,6 +925,13 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
       const float avg_sq = MEAN(acc_q[pl][k]);                                                                          \
       v[k] = v3d::sub_rn(avg_sq, v3d::mul_rn(avg, avg));                    /* mvsnet.py:216 */                         \
     }                                                                                                                   \
+    const int d = dchunk * kRDB + pl;                                                                                   \
+    if constexpr (CL8) {                                                                                                \
+      /* channels 4 cg .. 4 cg + 3 = half `half` of the voxel's channel group `chunk`: the lane's own 16 bytes */         \
+      const u32x4 slot = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};  \
+      if (gp < P && d < p.D)                                                                                            \
+        __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);               \
+    } else {                                                                                                            \
     const unsigned h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);                                        \
     const unsigned l01 = pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));     \
     const unsigned l23 = pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));     \
@@ -928,9 +939,9 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, true);   /* quad_perm [1,0,3,2] */   \
     const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, true);                              \
     const u32x4 slot = half ? (u32x4){r0, r1, l01, l23} : (u32x4){h01, h23, r0, r1};                                    \
-    const int d = dchunk * kRDB + pl;                                                                                   \
     if (gp < P && d < p.D && (V3D_PSVW_ABLATE != 5 || slot[0] == 0x12345u))                                             \
       __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);                 \
+    }                                                                                                                   \
   }
 #define V3D_MEAN_MUL(x) ((x) * cnt_inv)
     // any other count: the correctly rounded quotient from the correctly rounded reciprocal (v3d::div_uniform, Markstein;
@@ -1023,13 +1034,14 @@ extern "C" size_t v3d_psv_workspace_bytes(int n_img, int C, int Hf, int Wf) {
   return v3d::align_up(psv_feat_bytes(n_img, C, Hf, Wf), 256) + v3d::align_up((size_t)n_img * kCamStride * sizeof(float), 256);
 }
 
-static int psv_variance_impl(bool split, const float* feat, const float* K, const float* R,
+static int psv_variance_impl(int mode, const float* feat, const float* K, const float* R,
                                     const float* t, const int32_t* ref_img,
                                     const int32_t* edge_ofs, const int32_t* edge_src, int n_img,
                                     int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
                                     double depth_start, double depth_interval, int D, int h, int w,
                                     float* var, void* workspace, size_t workspace_bytes,
                                     void* stream) {
+  const bool split = mode != 0, cl8 = mode == 2;      // mode: 0 reference layout, 1 split-bf16 hand-off, 2 fp32 channel-last
   V3D_REQUIRE(feat && K && R && t && ref_img && edge_ofs && edge_src && var && workspace,
               V3D_ERR_BAD_ARG, "v3d_psv_variance_f32: null pointer argument");
   V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED,
@@ -1096,7 +1108,11 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
       static const bool reuse_env = getenv("V3D_PSV_REUSE") != nullptr || kRDB != 8;   // developer A/B switch: round-2 kernel
       // the window kernel's tap words keep their sign bit as a flag: feature maps beyond 2 GB take the reuse kernel
       const bool no_window = reuse_env || psv_feat_bytes(n_img, C, Hf, Wf) >= ((size_t)1 << 31);
-      if (split) {
+      V3D_REQUIRE(!cl8 || !no_window, V3D_ERR_UNSUPPORTED,
+                  "v3d_psv_variance_cl8: only the window kernel writes this layout (feature maps < 2 GB, no developer switch)");
+      if (cl8) {
+        psv_variance_window_kernel<true, true><<<(unsigned)rblocks, 64, 0, s>>>(p);
+      } else if (split) {
         if (no_window) psv_variance_reuse_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
         else psv_variance_window_kernel<true><<<(unsigned)rblocks, 64, 0, s>>>(p);
       } else {      // four 8-pixel tiles per workgroup
@@ -1105,6 +1121,8 @@ static int psv_variance_impl(bool split, const float* feat, const float* K, cons
         if (no_window) psv_variance_reuse_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
         else psv_variance_window_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
       }
+    } else if (cl8) {
+      return v3d::fail(V3D_ERR_UNSUPPORTED, "v3d_psv_variance_cl8: C=%d unsupported (32) / V3D_PSV_GATHER set", C);
     } else if (split) V3D_PSV(32, true);
     else if (C == 32) V3D_PSV(32, false);
     else V3D_PSV(16, false);
@@ -1149,7 +1167,7 @@ extern "C" int v3d_psv_variance_f32(const float* feat, const float* K, const flo
                                     int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
                                     double depth_start, double depth_interval, int D, int h, int w, float* var,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-  return psv_variance_impl(false, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
+  return psv_variance_impl(0, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
                            depth_start, depth_interval, D, h, w, var, workspace, workspace_bytes, stream);
 }
 
@@ -1158,9 +1176,18 @@ extern "C" int v3d_psv_variance_split(const float* feat, const float* K, const f
                                       int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
                                       double depth_start, double depth_interval, int D, int h, int w,
                                       void* var_split, void* workspace, size_t workspace_bytes, void* stream) {
-  return psv_variance_impl(true, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
+  return psv_variance_impl(1, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
                            depth_start, depth_interval, D, h, w, (float*)var_split, workspace, workspace_bytes,
                            stream);
+}
+
+extern "C" int v3d_psv_variance_cl8(const float* feat, const float* K, const float* R, const float* t,
+                                    const int32_t* ref_img, const int32_t* edge_ofs, const int32_t* edge_src,
+                                    int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                                    double depth_start, double depth_interval, int D, int h, int w,
+                                    float* var_cl8, void* workspace, size_t workspace_bytes, void* stream) {
+  return psv_variance_impl(2, feat, K, R, t, ref_img, edge_ofs, edge_src, n_img, n_ref, n_edges, C, Hf, Wf, H, W,
+                           depth_start, depth_interval, D, h, w, var_cl8, workspace, workspace_bytes, stream);
 }
 
 #ifdef V3D_PHASE_TIMING

@@ -183,9 +183,11 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
   iy = mul_rn(add_rn(gy, 1.f), mul_rn(0.5f, Hfm1));
 }
 
-// conv0 of CostRegNet as a depth march (conv0z.hip): split variance volume [n][4][hi, lo][D][H][W] -> split activation
-// [n][hi, lo][D][H][W] (16-byte slots of 8 bf16); `wbf` = the split-bf16 weight image of conv0 (costreg.hip, c0bf)
-int launch_conv0z(const void* in_split, const float* wbf, const float* bias, void* out_split, int n, int D, int H, int W,
+// conv0 of CostRegNet as a depth march (conv0z.hip).  f32 = false: split variance volume [n][4][hi, lo][D][H][W] -> split
+// activation [n][hi, lo][D][H][W] (16-byte slots of 8 bf16), `wimg` = the split-bf16 weight image of conv0 (costreg.hip, c0bf).
+// f32 = true: fp32 channel-last volume [n][4][2 halves][D][H][W] (16-byte slots of 4 floats) -> fp32 [n, 8, D, H, W],
+// `wimg` = the fp32 fragment image (c0f32).
+int launch_conv0z(bool f32, const void* in, const float* wimg, const float* bias, void* out, int n, int D, int H, int W,
                   hipStream_t s);
 
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip

@@ -8,6 +8,7 @@ There is NO CPU / eager-PyTorch fallback: without the built HIP library every fo
 ``torch.no_grad()``, mv3d/eval-3dvnet.py:27).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -156,14 +157,17 @@ class CostRegNet(nn.Module):
     def regularize_depth(self, x, depth_vals, return_reg=False, precision=None):
         """Rows A5-A6 fused: x [B,Cin,D,h,w] variance volume, depth_vals [D] ->
         depth [B,h,w] (and x_reg [B,D,h,w] when return_reg).  ``precision`` overrides ``self.precision``."""
-        split = isinstance(x, SplitVariance)
+        cl8 = isinstance(x, Cl8Variance)
+        split = isinstance(x, SplitVariance) and not cl8
         precision = precision or self.precision
         if split and precision != 'split_bf16':
             raise ValueError("a SplitVariance volume is the split_bf16 operand encoding; pass the fp32 volume for 'fp32'")
-        _require_cuda(x.data if split else x, 'CostRegNet')
+        if cl8 and precision != 'fp32':
+            raise ValueError("a Cl8Variance volume is the input of the exact-fp32 chain; pass precision='fp32'")
+        _require_cuda(x.data if (split or cl8) else x, 'CostRegNet')
         assert not self.training, 'inference only: BatchNorm is folded with running statistics'
         lib = _lib.load()
-        if split:
+        if split or cl8:
             (B, C, D, h, w), x = x.shape, x.data
         else:
             x = x.contiguous().float()
@@ -175,14 +179,15 @@ class CostRegNet(nn.Module):
         nbytes = lib.v3d_costreg_workspace_bytes(handle, B, D, h, w)
         ws = self._ws.get('costreg', nbytes, x.device)
         depth_vals = depth_vals.to(device=x.device, dtype=torch.float32).contiguous()
-        if split:
-            rc = lib.v3d_costreg_depth_split(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth),
-                                             _lib.ptr(reg), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        if split or cl8:
+            fn = lib.v3d_costreg_depth_cl8 if cl8 else lib.v3d_costreg_depth_split
+            rc = fn(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth),
+                    _lib.ptr(reg), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
         else:
             rc = lib.v3d_costreg_depth_f32(handle, _lib.ptr(x), _lib.ptr(depth_vals), B, D, h, w, _lib.ptr(depth),
                                            _lib.ptr(reg), _lib.precision_code(precision), _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr(x.device))
-        _lib.check(rc, 'v3d_costreg_depth_split' if split else 'v3d_costreg_depth_f32')
+        _lib.check(rc, 'v3d_costreg_depth_cl8' if cl8 else 'v3d_costreg_depth_split' if split else 'v3d_costreg_depth_f32')
         return (depth, reg) if return_reg else depth
 
     def run_layer(self, layer, x, skip=None, split=False, precision='split_bf16'):
@@ -289,11 +294,17 @@ class SplitVariance:
         return self.data.device
 
 
+class Cl8Variance(SplitVariance):
+    """The variance volume as fp32 in the channel-last layout of the exact-fp32 chain's conv0 (include/v3d.h,
+    v3d_psv_variance_cl8): [n_ref][4 channel groups][2 halves][D][h][w] slots of 4 floats.  The numbers of the
+    reference-layout tensor, bit for bit; only `CostRegNet.regularize_depth(precision='fp32')` consumes it."""
+
+
 def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, depth_start,
                          depth_interval, n_planes, img_size, depth_img_size, workspace=None,
-                         csr=None, split=False, n_ref=None):
+                         csr=None, split=False, n_ref=None, cl8=False):
     """Rows A1-A4 (mvsnet.py:186-216): variance cost volume [n_ref, C, D, h, w]
-    (`split=True`: the same volume as a `SplitVariance`, C == 32 only)."""
+    (`split=True`: the same volume as a `SplitVariance`, `cl8=True`: as a `Cl8Variance`; C == 32 only)."""
     _require_cuda(features_quarter, 'plane_sweep_variance')
     lib = _lib.load()
     feat = features_quarter.contiguous().float()
@@ -308,13 +319,13 @@ def plane_sweep_variance(features_quarter, rotmats, tvecs, K, ref_src_edges, dep
     nbytes = lib.v3d_psv_workspace_bytes(n_img, C, Hf, Wf)
     ws = (workspace or _Workspace()).get('psv', nbytes, dev)
     Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
-    fn = lib.v3d_psv_variance_split if split else lib.v3d_psv_variance_f32
+    fn = lib.v3d_psv_variance_cl8 if cl8 else lib.v3d_psv_variance_split if split else lib.v3d_psv_variance_f32
     rc = fn(_lib.ptr(feat), _lib.ptr(Kc), _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(ref_img),
             _lib.ptr(edge_ofs), _lib.ptr(edge_src), n_img, n_ref, n_edges, C, Hf, Wf, int(img_size[0]),
             int(img_size[1]), float(depth_start), float(depth_interval), int(n_planes), int(h), int(w),
             _lib.ptr(var), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
-    _lib.check(rc, 'v3d_psv_variance_split' if split else 'v3d_psv_variance_f32')
-    return SplitVariance(var, var.shape) if split else var
+    _lib.check(rc, 'v3d_psv_variance_cl8' if cl8 else 'v3d_psv_variance_split' if split else 'v3d_psv_variance_f32')
+    return Cl8Variance(var, var.shape) if cl8 else SplitVariance(var, var.shape) if split else var
 
 
 def plane_sweep_sample_positions(rotmats, tvecs, K, ref_src_edges, depth_start, depth_interval, n_planes, img_size,
@@ -382,6 +393,10 @@ class MVSNet(nn.Module):
         (identical depth, no conversion pass in conv0)."""
         precision = precision or self.cnn_3d.precision
         split = not return_intermediates and features_quarter.shape[1] == 32 and precision == 'split_bf16'
+        # exact fp32: the volume in the channel-last fp32 layout conv0's depth march streams (same numbers as the reference
+        # layout; V3D_PSV_REUSE / V3D_PSV_GATHER developer runs keep the reference layout, which only the window kernel lacks)
+        cl8 = (not return_intermediates and features_quarter.shape[1] == 32 and precision == 'fp32'
+               and not os.environ.get('V3D_PSV_REUSE') and not os.environ.get('V3D_PSV_GATHER'))
         if csr is None:
             # kept on the module: `check_edges()` reads the device builder's status word (a wrong n_ref gives an EMPTY edge
             # table, i.e. a zero variance volume and a plausible-looking depth, not an exception)
@@ -390,7 +405,7 @@ class MVSNet(nn.Module):
         var = plane_sweep_variance(features_quarter, batch.rotmats, batch.tvecs, batch.K,
                                    batch.ref_src_edges, depth_start, depth_interval, n_planes,
                                    self.img_size, depth_img_size, workspace=self._ws, csr=csr,
-                                   split=split, n_ref=n_ref)
+                                   split=split, n_ref=n_ref, cl8=cl8)
         vals = self.depth_values(depth_start, depth_interval, n_planes, var.device)
         if return_intermediates:
             depth, reg = self.cnn_3d.regularize_depth(var, vals, return_reg=True, precision=precision)

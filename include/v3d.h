@@ -126,6 +126,15 @@ int v3d_psv_variance_split(const float* feat, const float* K, const float* R, co
                          double depth_start, double depth_interval, int D, int h, int w,
                          void* var_split, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same volume as fp32 in the channel-last layout of the exact-fp32 chain's conv0 (V3D_PRECISION_FP32 through
+ * v3d_costreg_depth_cl8): [n_ref][4 channel groups][2 halves][D][h][w] 16-byte slots of 4 floats -- half 0 = channels 0..3
+ * of the group, half 1 = channels 4..7.  The numbers are those of v3d_psv_variance_f32, bit for bit; C must be 32. */
+int v3d_psv_variance_cl8(const float* feat, const float* K, const float* R, const float* t,
+                         const int32_t* ref_img, const int32_t* edge_ofs, const int32_t* edge_src,
+                         int n_img, int n_ref, int n_edges, int C, int Hf, int Wf, int H, int W,
+                         double depth_start, double depth_interval, int D, int h, int w,
+                         float* var_cl8, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rows A5-A6: CostRegNet (dense 3D-conv U-Net, BatchNorm folded) + soft-argmin depth.
  * Replaces mvsnet.py:133-163 (CostRegNet.forward) and mvsnet.py:219-227.
@@ -158,6 +167,11 @@ int v3d_costreg_depth_f32(const v3d_costreg_weights* handle, const float* var,
 /* As above with the variance volume in the split format written by v3d_psv_variance_split (the split format IS the
  * V3D_PRECISION_SPLIT_BF16 operand encoding, so this entry point has no precision argument). */
 int v3d_costreg_depth_split(const v3d_costreg_weights* handle, const void* var_split,
+                          const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
+                          float* reg, void* workspace, size_t workspace_bytes, void* stream);
+/* As v3d_costreg_depth_f32 with V3D_PRECISION_FP32 (exact fp32 products) and the volume in the fp32 channel-last layout
+ * of v3d_psv_variance_cl8: conv0 then runs as a depth march that streams the volume with LDS-DMA (csrc/conv0z.hip). */
+int v3d_costreg_depth_cl8(const v3d_costreg_weights* handle, const void* var_cl8,
                           const float* depth_vals, int n_ref, int D, int h, int w, float* depth,
                           float* reg, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -282,6 +282,45 @@ def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
         np.testing.assert_allclose(res[pr][0], depth_o, rtol=DEPTH_RTOL, atol=0)
 
 
+def test_exact_fp32_chain_through_the_channel_last_volume(cuda):
+    """precision='fp32' without intermediates: the warp kernel writes the volume as fp32 channel-last slots
+    (v3d_psv_variance_cl8) and conv0 runs as the exact-fp32 depth march (v3d_costreg_depth_cl8).  (1) the slots hold the
+    reference-layout volume bit for bit (ragged edges, partial tiles, 13 planes); (2) the depth is inside the 1e-4 gate of the
+    oracle and within 2e-5 of the per-layer exact-fp32 chain on the reference-layout volume (same products, another
+    summation order); (3) batch invariance is bit-exact."""
+    syn, mvs = v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    img_size, feat_size, plane_size = (64, 80), (16, 20), (7, 9)
+    R, tv, K = syn.make_cameras(12, img_size, seed=3)
+    feat = syn.make_features(12, 32, *feat_size, seed=3)
+    refs = [4] + [7] * 3 + [2] * 10
+    srcs = [4] + [6, 7, 8] + list(range(0, 10))
+    edges = torch.tensor([refs, srcs])
+    var = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 13, img_size, plane_size)
+    cv = mvs.plane_sweep_variance(feat.to(cuda), R, tv, K, edges.to(cuda), 0.5, 0.3, 13, img_size, plane_size, cl8=True)
+    n, C, D, h, w = cv.shape
+    dec = cv.data.contiguous().view(n, 4, 2, D, h, w, 4).permute(0, 1, 2, 6, 3, 4, 5).reshape(n, 32, D, h, w)
+    assert torch.equal(dec, var)
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=21)
+    sd = syn.costregnet_weights(seed=3, sharpen=200.0)
+    net = _net(sd, cuda, inp['img_size'])
+    b = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges']).to(cuda)
+    d0, dd, D = inp['depth']
+    with torch.no_grad():
+        d_cl8 = net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'], precision='fp32')
+        d_ref, _, _ = net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'], precision='fp32',
+                                            return_intermediates=True)
+        per = inp['edges'].shape[1] // 3
+        b1 = Batch(None, inp['rotmats'], inp['tvecs'], inp['K'], None, inp['edges'][:, per:2 * per]).to(cuda)
+        d_one = net.cost_volume_depth(inp['feat'].to(cuda), b1, d0, dd, D, inp['plane_size'], precision='fp32')
+        depth_o = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], sd, d0, dd, D,
+                                   inp['img_size'], inp['plane_size'], pinned=True)[0].numpy()
+    assert torch.equal(d_one[0], d_cl8[1])
+    np.testing.assert_allclose(d_cl8.cpu().numpy(), d_ref.cpu().numpy(), rtol=2e-5, atol=0)
+    np.testing.assert_allclose(d_cl8.cpu().numpy(), depth_o, rtol=2e-5, atol=0)
+    assert not torch.equal(d_cl8, d_ref)          # another kernel really ran
+
+
 def test_psv_feat_dim_16(cuda):
     syn, mvs = v3d('synthetic'), v3d('mvsnet')
     img_size, plane_size = (64, 80), (8, 8)
