@@ -271,9 +271,13 @@ def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
         net32 = mvs.MVSNet(32, inp['img_size'], precision='fp32').eval()
         net32.cnn_3d.load_state_dict(sd, strict=False)
         d32 = net32.to(cuda).cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'])
+        d32_kw = net.cost_volume_depth(inp['feat'].to(cuda), b, d0, dd, D, inp['plane_size'], precision='fp32')
         depth_o = ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'], sd, d0, dd, D,
                                    inp['img_size'], inp['plane_size'])[0].numpy()
-    assert np.array_equal(d32.cpu().numpy(), res['fp32'][0])
+    # (without intermediates the exact-fp32 chain takes the channel-last volume and the depth-march conv0: the same products in
+    # another summation order than the per-layer chain behind return_intermediates)
+    assert torch.equal(d32, d32_kw)
+    np.testing.assert_allclose(d32.cpu().numpy(), res['fp32'][0], rtol=2e-5, atol=0)
     np.testing.assert_allclose(res['split_bf16'][0], res['fp32'][0], rtol=2e-4, atol=0)
     scale = float(np.abs(res['fp32'][1]).max())
     np.testing.assert_allclose(res['split_bf16'][1], res['fp32'][1], rtol=0, atol=4e-4 * scale)
