@@ -119,6 +119,16 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         all_depth = torch.empty((n_local, *depth_config['size']), dtype=torch.float32, device=device)
         feats_local = None          # quarter features of images [r0, r1 + halo)
         half_local = None           # half-resolution features of the same images (stage 3 only, eval-3dvnet.py:36,62)
+        # Precomputed features that already live on `device`: the slices ARE the tensors stage 2 / 3 need -- no per-chunk copy
+        # into a second buffer (the reference fills all_feats_quarter / all_feats_half chunk by chunk because its features come
+        # out of the backbone per chunk, eval-3dvnet.py:56-62)
+        dev_feats = has_feats and batch.features_quarter.device == torch.device(device) and batch.features_quarter.dtype == torch.float32
+        half_is_view = False
+        if dev_feats:
+            feats_local = batch.features_quarter[r0:r1 + halo]
+            fh = getattr(batch, 'features_half', None)
+            if upsample and fh is not None and fh.device == torch.device(device) and fh.dtype == torch.float32:
+                half_local, half_is_view = fh[r0:r1 + halo], True
 
         # ---- stage 1: initial depth, chunks of init_depth_batch reference views (:41-63) ----------
         for c0 in range(r0, r1, init_depth_batch):
@@ -138,11 +148,12 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             sl.to(device)
             pred, _, feats_half, feats_quarter, _, _ = net.make_initial_depth_predictions(sl, depth_config)
             all_depth[c0 - r0:c1 - r0] = pred
-            if feats_local is None:
-                feats_local = torch.empty((n_local + halo,) + tuple(feats_quarter.shape[1:]),
-                                          dtype=torch.float32, device=device)
-            feats_local[idx_start - r0:idx_end - r0] = feats_quarter
-            if upsample:
+            if not dev_feats:
+                if feats_local is None:
+                    feats_local = torch.empty((n_local + halo,) + tuple(feats_quarter.shape[1:]),
+                                              dtype=torch.float32, device=device)
+                feats_local[idx_start - r0:idx_end - r0] = feats_quarter
+            if upsample and not half_is_view:
                 # like all_feats_half of the reference (eval-3dvnet.py:36,62): kept from stage 1, whether the
                 # features came from the injected backbone or were precomputed on the batch
                 if feats_half is None:

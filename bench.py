@@ -490,6 +490,32 @@ def bench_scene(args, rank, world, dev, dist):
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'parity': parity, 'kernels': kernels}
 
 
+def bench_backbone(dev, n_img=71, iters=5):
+    """SURVEY 8f rank 3, timed only: the 2D MnasNet-1.0 + FPN backbone (mvsnet.py:55-105; stock PyTorch-ROCm / MIOpen
+    convolutions, fp32, random-init weights) on the cfg2 batch's 71 images of 256 x 320.  Not part of `value`: the
+    cost-volume benches start from quarter-resolution features, as BASELINE config 2 does."""
+    bb = importlib.import_module('3dvnet_amd.backbone')
+    syn = importlib.import_module('3dvnet_amd.synthetic')
+    fe, fs = bb.build_backbone(32)
+    sd_e, sd_s = syn.backbone_weights(32, seed=6)
+    fe.load_state_dict(sd_e, strict=False)
+    fs.load_state_dict(sd_s)
+    fe, fs = fe.eval().to(dev), fs.eval().to(dev)
+    imgs = syn.make_images(n_img, (256, 320), seed=8).to(dev)
+    with torch.no_grad():
+        for _ in range(2):
+            out = fs(*fe(imgs))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = fs(*fe(imgs))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+    return {'workload': 'MnasNet-1.0 trunk + FPN + shrinker, %d images 256x320 -> half / quarter / eighth features (stock '
+                        'PyTorch-ROCm convolutions, fp32)' % n_img, 'ms_per_batch': ms, 'images_per_s': n_img / ms * 1e3,
+            'quarter_features': list(out[1].shape), 'note': 'timed only; parity with torchvision unpinned (absent here)'}
+
+
 def compact(line):
     """The figures of a full bench line that go into the default line's "extra" object."""
     out = {k: line[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'value_fp32_exact',
@@ -681,6 +707,7 @@ def main():
             line3f = bench_scene(a3f, rank, world, dev, dist)
             extra['cfg3_full'] = compact(line3f)
             extra['cfg3_full']['stage3'] = line3f.get('stage3')
+            extra['backbone'] = bench_backbone(dev)
             line['extra'] = extra
             line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '
                                                 'scaling: reference views are independent units); the communicating mode is '
