@@ -2526,6 +2526,13 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   }
   if (!generic) {
+    // conv9 + skip + prob: the tile kernel below.  V3D_C9_MARCH=1 selects the depth-march experiment of round 4 (conv9z.hip:
+    // correct -- the GPU suite passes on it -- but 0.51 against 0.46 ms per 64 views, see its header; developer A/B)
+    static const bool tile_kernel = getenv("V3D_C9_MARCH") == nullptr;
+    if (!tile_kernel) {
+      if ((rc = v3d::launch_conv9z(F(ws.u8), F(ws.c0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9], h->dev + h->prob_w2_ofs,
+                                   h->dev + h->prob_b_ofs, xreg, n, D, H, W, s)) != V3D_OK) return rc;
+    } else {
     C9Params q;
     q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
     q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
@@ -2539,6 +2546,7 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
       conv9_prob_kernel<<<(unsigned)blocks, 512, 0, s>>>(q);
     }
     V3D_CHECK_LAUNCH("conv9_prob_kernel");
+    }
   } else {
     RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
     {

@@ -190,6 +190,12 @@ __device__ __forceinline__ void sample_position(const float* Pm, float X, float 
 int launch_conv0z(bool f32, const void* in, const float* wimg, const float* bias, void* out, int n, int D, int H, int W,
                   hipStream_t s);
 
+// conv9 + conv0 skip + prob of CostRegNet as a depth march (conv9z.hip): u8 [n][2][hi, lo][D/2][H/2][W/2] and the conv0 skip
+// [n][hi, lo][D][H][W] (split layouts) -> x_reg [n, D, H, W]; `wbf` = the split-bf16 image of conv9 (costreg.hip, c9bf),
+// `wprob` = the pair-interleaved prob weights
+int launch_conv9z(const void* u8_split, const void* c0_split, const float* wbf, const float* bias9, const float* wprob,
+                  const float* bprob, float* out, int n, int D, int H, int W, hipStream_t s);
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 

@@ -17,6 +17,7 @@ NAMES = ['M: wait at B', "M: MFMA phase (B', stores inside)", "H: wait at B'", '
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--refs', type=int, default=64)
+    ap.add_argument('--kernel', default='conv0z', choices=('conv0z', 'conv9z'))
     args = ap.parse_args()
     libm = importlib.import_module('3dvnet_amd._lib')
     if os.environ.get('V3D_LIB_OVERRIDE'):
@@ -25,7 +26,7 @@ def main():
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
     Batch = importlib.import_module('3dvnet_amd.batch').Batch
     lib = libm.load()
-    fn = lib.v3d_debug_conv0z_phase_read
+    fn = getattr(lib, 'v3d_debug_%s_phase_read' % args.kernel)
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     dev = torch.device('cuda:0')
@@ -43,8 +44,9 @@ def main():
     buf = (ctypes.c_ulonglong * 8)()
     fn(buf, 1024)
     tot = sum(buf)
-    print('conv0z phases (cycles of wave 0, %d workgroups): total %.3e' % (256, tot))
-    for n, v in zip(NAMES, buf):
+    print(args.kernel + ' phases (cycles of wave 0, %d workgroups): total %.3e' % (256, tot))
+    names = NAMES if args.kernel == 'conv0z' else ['P: wait vmcnt', 'P: wait at B', 'P: issue DMA', 'P: MFMA', 'P: emit u9', 'C: prob conv + stores', 'C: wait at B', 'C: task tail']
+    for n, v in zip(names, buf):
         print('  %-34s %6.1f %%  %.3e' % (n, 100.0 * v / max(tot, 1), v))
 
 
