@@ -1679,29 +1679,33 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   {
     const int z = wave >> 1, y = (wave & 1) * 4 + (lane >> 4), xp = lane & 15;
     if (xp < C9::TW / 2) {
-      f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+      // six accumulation chains (one pair per kz, added at the end) instead of two: a dependent v_pk_fma_f32 costs ~20 cycles
+      // (measured on the depth-march experiment, conv9z.hip, which sums in the same order)
+      f32x2 o0[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, o1[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
       const f32x2* wp2 = reinterpret_cast<const f32x2*>(p.wprob);       // [4 pairs][27 taps][2]
 #pragma unroll 1
       for (int cp = 0; cp < (V3D_C9_ABLATE == 1 ? 0 : V3D_C9_ABLATE == 2 ? 1 : 4); ++cp) {
 #pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
+        for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
+          for (int kz = 0; kz < 3; ++kz) {
             const f32x2* row = reinterpret_cast<const f32x2*>(u9s) +
                                (cp * (C9::HD * C9::HH) + (z + kz) * C9::HH + (y + ky)) * C9::RS + 2 * xp;
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 2);
             const f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w};
             const f32x2* wk = wp2 + (cp * 27 + (kz * 3 + ky) * 3);           // wave-uniform -> s_load
             const f32x2 w0 = wk[0], w1 = wk[1], w2 = wk[2];
-            o0 += a0 * w0; o0 += a1 * w1; o0 += a2 * w2;
-            o1 += a1 * w0; o1 += a2 * w1; o1 += a3 * w2;
+            o0[kz] += a0 * w0; o1[kz] += a1 * w0;
+            o0[kz] += a1 * w1; o1[kz] += a2 * w1;
+            o0[kz] += a2 * w2; o1[kz] += a3 * w2;
           }
         }
       }
+      const f32x2 s0 = (o0[0] + o0[1]) + o0[2], s1 = (o1[0] + o1[1]) + o1[2];
       const int gz = oz0 + z, gy = oy0 + y, gx = ox0 + 2 * xp;
       if (gz < p.D && gy < p.H && gx < p.W) {
         const float bsv = p.bprob[0];
-        const f32x2 res = {o0.x + o0.y + bsv, o1.x + o1.y + bsv};
+        const f32x2 res = {s0.x + s0.y + bsv, s1.x + s1.y + bsv};
         float* o = p.out + (size_t)n * out_plane + ((size_t)gz * p.H + gy) * p.W + gx;
         if (gx + 1 < p.W && (p.W & 1) == 0) {
           *reinterpret_cast<f32x2*>(o) = res;

@@ -36,4 +36,5 @@ b2 = Batch(None, R, tv, K, None, edges).to(dev)
 with torch.no_grad():
     depth, _, reg = net2.cost_volume_depth(feat.to(dev), b2, 0.5, 0.1, D, plane_size, return_intermediates=True)
 out['depth_b'], out['reg_b'] = depth.cpu().numpy(), reg.cpu().numpy()
+out['kernel'] = 'conv9z_kernel' if os.environ.get('V3D_C9_MARCH') else 'conv9_prob_kernel'
 np.savez(sys.argv[1], **out)
