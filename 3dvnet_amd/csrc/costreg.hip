@@ -950,7 +950,10 @@ struct CG {
   static constexpr bool FLAT = FLAT_;
   static constexpr int NCH = CIN / 8, NCG = COUT / 16;
   static constexpr int NRB = 16 / WB;                                  // output rows per MFMA column block
-  static constexpr int TD = S == 2 ? 2 : 4, TH = 4 * NRB, TW = WB;
+#ifndef V3D_FLAT_TD
+#define V3D_FLAT_TD 8        // images per tile of the FLAT (conv2d) layers (developer A/B)
+#endif
+  static constexpr int TD = FLAT ? V3D_FLAT_TD : S == 2 ? 2 : 4, TH = 4 * NRB, TW = WB;
   static constexpr int NKZ = FLAT ? 1 : 3;                             // z taps
   static constexpr int ID = FLAT ? TD : S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
   static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;         // idle lanes read a few slots past a row

@@ -218,9 +218,11 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
   const int wave = wave_id & 3;            // row quarter: output channels 32 wave .. 32 wave + 31
   const int cb0 = (wave_id >> 2) * kFNB;   // first of this wave's 4 column blocks
   int kq = lane >> 4, jn = lane & 15;
-  const int n_hyp = p.n_hyp, rows = kFPts * n_hyp;
+  // query points per tile: as many whole hypothesis groups as the kFRows columns hold (7 hypotheses: 9 points = 63 of 64
+  // columns; with a fixed 8 points per tile an eighth of every MFMA's columns was padding)
+  const int n_hyp = p.n_hyp, npt = kFRows / n_hyp, rows = npt * n_hyp;
   const long long n_q = (long long)p.n_pts * n_hyp;
-  const int n_tiles = (p.n_pts + kFPts - 1) / kFPts;
+  const int n_tiles = (p.n_pts + npt - 1) / npt;
   // The workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host launches as many workgroups as the chip holds at
   // once): everything that does not depend on the tile -- biases, head weights, the weight-fragment ring -- is set up once, and
   // the corner table of the NEXT tile is looked up while the matrix pipe works on layers 2 and 3 of the current one.
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
     unsigned slot[3][kFProbeRows];
   };
   auto ct_points = [&](Probe& c, int tile) __attribute__((always_inline)) {
-    const int tp0 = tile * kFPts;
+    const int tp0 = tile * npt;
     const long long tq0 = (long long)tp0 * n_hyp;
 #pragma unroll
     for (int i = 0; i < kFProbeRows; ++i) {
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
 #pragma unroll 1
   for (; tile < tile_end; tile += tile_step) {
     refresh_lane_ids();
-    pt0 = tile * kFPts;
+    pt0 = tile * npt;
     q0 = (long long)pt0 * n_hyp;
     has_next = tile + tile_step < tile_end;
     // every wave is past the barrier behind layer 3 of the previous tile: the second buffer (staging tiles, corner table) is free
@@ -698,12 +700,15 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) { hw0[k] = chead[(hc0 + k) * 3]; hw1[k] = chead[(hc0 + k) * 3 + 1]; hw2[k] = chead[(hc0 + k) * 3 + 2]; }
       const float head_b = chead[3 * kFH];
+      // (32 lanes per point, kFThreads / 32 points per pass: a tile of 9 points takes a second pass for its last one)
+#pragma unroll 1
+      for (int hp = hpt; hp < npt; hp += kFThreads / 32) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) score[h] = 0.f;
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         if (h < n_hyp) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(of + ((hpt < kFPts ? hpt : 0) * n_hyp + h) * kFH + hc0);
+          const f32x4 x = *reinterpret_cast<const f32x4*>(of + (hp * n_hyp + h) * kFH + hc0);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             // out[h'] = sum_t in[h' + t - 1] w[t]  =>  in[h] feeds out[h+1] (t=0), out[h] (t=1), out[h-1] (t=2)
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
         score[h] = v + head_b;
       }
-      if (hl32 == 0 && hpt < kFPts && pt0 + hpt < p.n_pts) {
+      if (hl32 == 0 && pt0 + hp < p.n_pts) {
         float m = -INFINITY;
 #pragma unroll
         for (int h = 0; h < 8; ++h) if (h < n_hyp) m = fmaxf(m, score[h]);
@@ -735,11 +740,12 @@ __global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(
         for (int h = 0; h < 8; ++h) {
           if (h < n_hyp) {
             const float pr = ex[h] / sum;
-            p.preds[(size_t)(pt0 + hpt) * n_hyp + h] = pr;
+            p.preds[(size_t)(pt0 + hp) * n_hyp + h] = pr;
             e += chead[3 * kFH + 4 + h] * pr;         // (offset values parked in LDS: a global load per hypothesis sat in this chain)
           }
         }
-        if (p.expect) p.expect[pt0 + hpt] = e;
+        if (p.expect) p.expect[pt0 + hp] = e;
+      }
       }
     }
     FPHASE_MARK(6);
@@ -849,7 +855,8 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   const int resident = resident_of[dev];
   {
     // persistent tile walk: workgroup b takes tiles b, b + grid, ... (equal work per tile, so a static split is balanced)
-    const int n_tiles = (n_pts + kFPts - 1) / kFPts;
+    const int npt = kFRows / n_hyp;                    // as in the kernel
+    const int n_tiles = (n_pts + npt - 1) / npt;
     v3d::TimedScope ts("decoder_fused", s);
     decoder_fused_kernel<<<n_tiles < resident ? n_tiles : resident, kFThreads, lds_bytes, s>>>(p);
   }

@@ -23,8 +23,9 @@ LLVM = os.environ.get('V3D_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 KERNEL = 'decoder_fused_kernel'
 # signature of the build verified on MI355X (hipcc of ROCm 7.2.0): corner-table reads are the 4-byte kinds
 # (ds_read_b32 / ds_read2_b32 / ds_read2st64_b32); the 16-byte reads are the B fragments of the three layers.
-PINNED = {'ds_read_b128': 129, 'ds_read_b96': 1, 'ds_read_b64': 1, 'ds_read2_b64': 0, 'ds_read2st64_b64': 0,
-          'ds_read_b32': 44, 'ds_read2_b32': 9, 'ds_read2st64_b32': 7}
+# (re-pinned in round 4 after the points-per-tile change of the head phase; the determinism and golden tests passed on this build)
+PINNED = {'ds_read_b128': 128, 'ds_read_b96': 0, 'ds_read_b64': 2, 'ds_read2_b64': 0, 'ds_read2st64_b64': 0,
+          'ds_read_b32': 43, 'ds_read2_b32': 12, 'ds_read2st64_b32': 7}
 
 
 def signature(obj):
