@@ -433,7 +433,7 @@ def bench_scene(args, rank, world, dev, dist):
             a = flops / (st[dom][0] * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             roofline = dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak, kernel=dom,
-                            avg_ms=st[dom][0] / st[dom][1], traffic=None)
+                            avg_ms=st[dom][0] / st[dom][1], traffic=traffic_for(dom, refs, 'cfg3'))
     # ---- parity of the refinement leg: a 4-view scene of the same shapes / weights through the same driver, HIP against the
     # oracle-backed net (CPU; rows A1-A4 with the pinned orders), final depths after 2 x (scene model + 3 sweeps)
     parity, cpu_baseline = None, None

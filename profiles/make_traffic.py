@@ -23,7 +23,9 @@ NAMES = [('psv_variance_window_kernel<true, false>', 'psv_variance'), ('psv_vari
          ('conv0z_kernel<false>', 'costreg_conv0'), ('conv0z_kernel<true>', 'costreg_conv0_f32'), ('conv0_bf16x2_kernel', 'costreg_conv0'), ('conv9_prob_kernel', 'costreg_conv9_prob'),
          ('convg_bf16x2_kernel<CG<8, 16', 'costreg_conv1'), ('convg_bf16x2_kernel<CG<16, 16', 'costreg_conv2'),
          ('convg_bf16x2_kernel<CG<16, 32', 'costreg_conv3'), ('convg_bf16x2_kernel<CG<32, 32', 'costreg_conv4'),
-         ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin')]
+         ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin'),
+         ('decoder_fused_kernel', 'decoder_fused'), ('gemm_gather_rounds_kernel<2, 2, 4>', 'sparse_conv_gemm'),
+         ('backproject_variance_kernel', 'backproject_variance')]
 FETCH_CORRECTION = 2.0
 
 
