@@ -75,6 +75,7 @@ SIGNATURES = {
                                     ctypes.POINTER(c_int), c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'v3d_fill_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
+    'v3d_pointnet_input_f32': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     'v3d_hash_bytes': (c_size_t, [c_int]),
     'v3d_hash_build': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'v3d_hash_status': (c_int, [c_void_p, c_int, c_void_p]),

@@ -820,6 +820,39 @@ extern "C" int v3d_fill_f32(float* ptr, size_t n, float value, void* stream) {
   return V3D_OK;
 }
 
+// PointNet input rows (lightningmodel.py:180-183): x[i] = [pts[e1[i]] - anchor_pts[e0[i]] | pts_feat[e1[i]]] in one pass
+// (the reference builds it with two index gathers, a subtraction, a third gather and a torch.cat).  4 threads per row.
+namespace {
+__global__ __launch_bounds__(256) void pointnet_input_kernel(const float* __restrict__ pts, const float* __restrict__ anchor,
+                                                             const float* __restrict__ feat, const long long* __restrict__ e0,
+                                                             const long long* __restrict__ e1, int n, int C, float* __restrict__ out) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = gid >> 2;
+  const int part = (int)(gid & 3);
+  if (i >= n) return;
+  const long long a = e0[i], q = e1[i];
+  float* const o = out + (size_t)i * (3 + C);
+  if (part == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = pts[(size_t)q * 3 + d] - anchor[(size_t)a * 3 + d];
+  }
+  const float* const f = feat + (size_t)q * C;
+  for (int c = part; c < C; c += 4) o[3 + c] = f[c];
+}
+}  // namespace
+
+extern "C" int v3d_pointnet_input_f32(const float* pts, const float* anchor_pts, const float* pts_feat, const int64_t* edge_anchor,
+                                      const int64_t* edge_pt, int n_edges, int C, float* out, void* stream) {
+  V3D_REQUIRE(pts && anchor_pts && pts_feat && edge_anchor && edge_pt && out, V3D_ERR_BAD_ARG, "v3d_pointnet_input_f32: null argument");
+  V3D_REQUIRE(n_edges >= 0 && C >= 1, V3D_ERR_BAD_SHAPE, "v3d_pointnet_input_f32: bad shape");
+  if (n_edges == 0) return V3D_OK;
+  const long long threads = (long long)n_edges * 4;
+  pointnet_input_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      pts, anchor_pts, pts_feat, (const long long*)edge_anchor, (const long long*)edge_pt, n_edges, C, out);
+  V3D_CHECK_LAUNCH("pointnet_input_kernel");
+  return V3D_OK;
+}
+
 #ifdef V3D_PHASE_TIMING
 extern "C" int v3d_debug_gemm_phase_read(unsigned long long* out8_host, int n_blocks) {
   V3D_CHECK_HIP(hipDeviceSynchronize());

@@ -123,8 +123,14 @@ class PL3DVNet(nn.Module):
             pts, pts_feat, pts_batch = gather_fn(pts, pts_feat, pts_batch)
         anchor_pts, anchor_idx3d, anchor_batch, anchor_pts_edges = utils.voxelize(pts, pts_batch, self.edge_len)
         n_anchors = anchor_pts.shape[0]
-        x = torch.cat((pts[anchor_pts_edges[1]] - anchor_pts[anchor_pts_edges[0]],
-                       pts_feat[anchor_pts_edges[1]]), dim=1)
+        # x = cat(pts[e1] - anchor_pts[e0], pts_feat[e1]) (lightningmodel.py:180-183) in one kernel instead of five launches
+        e0 = anchor_pts_edges[0].to(torch.int64).contiguous()
+        e1 = anchor_pts_edges[1].to(torch.int64).contiguous()
+        pts_c, anc_c, feat_c = pts.contiguous().float(), anchor_pts.contiguous().float(), pts_feat.contiguous().float()
+        x = torch.empty((e0.shape[0], 3 + feat_c.shape[1]), dtype=torch.float32, device=pts.device)
+        _lib.check(_lib.load().v3d_pointnet_input_f32(_lib.ptr(pts_c), _lib.ptr(anc_c), _lib.ptr(feat_c), _lib.ptr(e0), _lib.ptr(e1),
+                                                      e0.shape[0], feat_c.shape[1], _lib.ptr(x), _lib.stream_ptr(pts.device)),
+                   'v3d_pointnet_input_f32')
         x = self.pointnet(x, anchor_pts_edges[0], n_anchors)
         xs = self.sparse_conv(x, anchor_pts, anchor_idx3d, anchor_batch, self.edge_len, n_batches=n_batches,
                               defer_checks=defer_checks)

@@ -238,6 +238,10 @@ int v3d_gemm_gather_f32(const v3d_gemm_weights* handle, int M, const float* cons
                         int relu_out, float* pool, const int32_t* pool_idx, int ld_pool, float* out,
                         int ld_out, int precision, void* stream);
 int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
+/* PointNet input of PL3DVNet.model_scene (mv3d/lightningmodel.py:180-183): out[i] = [pts[edge_pt[i]] - anchor_pts[edge_anchor[i]]
+ * | pts_feat[edge_pt[i]]], out [n_edges, 3 + C]; pts [*, 3], anchor_pts [*, 3], pts_feat [*, C], edges int64. */
+int v3d_pointnet_input_f32(const float* pts, const float* anchor_pts, const float* pts_feat, const int64_t* edge_anchor,
+                           const int64_t* edge_pt, int n_edges, int C, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse-tensor structure (replaces MinkowskiEngine's coordinate manager; semantics: SURVEY.md
