@@ -96,6 +96,12 @@ __device__ unsigned long long g_cz_phase[8 * 1024];
 #ifndef V3D_CZ_HPRIO
 #define V3D_CZ_HPRIO 0
 #endif
+#ifndef V3D_CZ_ROT
+#define V3D_CZ_ROT 12        // tile row r is stored rotated by V3D_CZ_ROT * r slots (0 = off; 12: the column blocks that
+#endif                       // straddle two rows then read 16 distinct bank groups); costs 14 address registers
+#ifndef V3D_CZ_PRE
+#define V3D_CZ_PRE 2         // B fragments this many items ahead of their MFMAs
+#endif
 #ifndef V3D_CZ_ABLATE
 #define V3D_CZ_ABLATE 0      // developer ablations: 1 no MFMAs, 2 no DMA, 3 no reduction / finalize
 #endif
@@ -160,12 +166,18 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
       }
     }
     // B operand of block b, column jn, k group kq: slot (y, 2 xp + kq) of the tile row y + ky (ky: immediate offset)
-    unsigned boff[CZ::NBLK];
+    unsigned boff[V3D_CZ_ROT ? 3 : 1][CZ::NBLK];
 #pragma unroll
     for (int b = 0; b < CZ::NBLK; ++b) {
       const int q = 16 * b + jn, y = q / CZ::NP, xp = q % CZ::NP;
-      boff[b] = (unsigned)(wave * CZ::RING_BYTES + (y * CZ::IWS + 2 * xp + kq) * 16);      // + the wave's ring: one VGPR per block,
-    }                                                                                       // everything else is an immediate
+      if (V3D_CZ_ROT) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          boff[V3D_CZ_ROT ? ky : 0][b] = (unsigned)(wave * CZ::RING_BYTES + ((y + ky) * CZ::IWS + ((2 * xp + kq + V3D_CZ_ROT * (y + ky)) & 31)) * 16);
+      } else {
+        boff[0][b] = (unsigned)(wave * CZ::RING_BYTES + (y * CZ::IWS + 2 * xp + kq) * 16);   // + the wave's ring: one VGPR per block,
+      }                                                                                     // everything else is an immediate
+    }
     f32x4 acc[3][CZ::NBLK];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -190,12 +202,13 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
           const unsigned char* const rb = smem + U * CZ::PLANE_BYTES;
           // 21 (ky, block) items, each 2 ds_read_b128 -> 9 MFMAs; the B fragments run kPre items ahead of the MFMAs, the
           // scheduler is pinned to that order
-          constexpr int NI = 3 * CZ::NBLK, kPre = 2;
+          constexpr int NI = 3 * CZ::NBLK, kPre = V3D_CZ_PRE;
           u32x4 bh_[NI], bl_[NI];
           auto load = [&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value, ky = i / CZ::NBLK, b = i % CZ::NBLK;
-            bh_[i] = *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16));
-            bl_[i] = *reinterpret_cast<const u32x4*>(rb + boff[b] + ky * (CZ::IWS * 16) + CZ::HL_BYTES);
+            const unsigned bo = V3D_CZ_ROT ? boff[V3D_CZ_ROT ? ky : 0][b] : boff[0][b] + ky * (CZ::IWS * 16);
+            bh_[i] = *reinterpret_cast<const u32x4*>(rb + bo);
+            bl_[i] = *reinterpret_cast<const u32x4*>(rb + bo + CZ::HL_BYTES);
           };
           // Out plane zi - 1 (slot A2) is complete block by block during the ky = 2 items (block b after item 14 + b).  Its
           // partial sums leave for LDS behind the LAST B-fragment reads (issued with item NI - 1 - kPre): lgkmcnt counts in
@@ -253,8 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
               __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                // the item's MFMAs
             }
           };
-          load(std::integral_constant<int, 0>{});
-          load(std::integral_constant<int, 1>{});
+          cz_static_for<0, kPre>(load);
           __builtin_amdgcn_sched_group_barrier(0x100, 2 * kPre, 0);
           cz_static_for<0, NI - 2>(item);
           // B'(s), in front of the first store into `red`: a bare s_barrier -- nothing of this wave's memory traffic has to be
@@ -306,10 +318,11 @@ __global__ __launch_bounds__(512, 2) void conv0z_kernel(CZParams p) {
       unsigned voff[CZ::NPIECE];
       unsigned long long vmask[CZ::NPIECE];
       {
-        const int j = lane >> 5, col = lane & 31;
-        const int gx = q.ox0 - 1 + col;
+        const int j = lane >> 5, col0 = lane & 31;
 #pragma unroll
         for (int i = 0; i < CZ::NPIECE; ++i) {
+          const int col = (col0 - V3D_CZ_ROT * (2 * i + j)) & 31;      // the tile column this lane's slot holds
+          const int gx = q.ox0 - 1 + col;
           const int gy = q.oy0 - 1 + 2 * i + j;
           const bool ok = col < CZ::TW + 2 && gx >= 0 && gx < p.W && gy >= 0 && gy < p.H;
           voff[i] = ok ? (unsigned)((gy * p.W + gx) * 16) : 0u;

@@ -10,6 +10,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+libm = importlib.import_module('3dvnet_amd._lib')
+if os.environ.get('V3D_LIB_OVERRIDE'):      # a variant build (scripts/build_variant.py)
+    libm.LIB_PATH = os.environ['V3D_LIB_OVERRIDE']
 syn = importlib.import_module('3dvnet_amd.synthetic')
 mvs = importlib.import_module('3dvnet_amd.mvsnet')
 Batch = importlib.import_module('3dvnet_amd.batch').Batch
