@@ -953,7 +953,13 @@ struct CG {
 #ifndef V3D_FLAT_TD
 #define V3D_FLAT_TD 8        // images per tile of the FLAT (conv2d) layers (developer A/B)
 #endif
-  static constexpr int TD = FLAT ? V3D_FLAT_TD : S == 2 ? 2 : 4, TH = 4 * NRB, TW = WB;
+#ifndef V3D_CG_TD_S1
+#define V3D_CG_TD_S1 4       // output planes per tile, stride-1 layers at 14-wide rows (developer A/B)
+#endif
+#ifndef V3D_CG_TD_S2
+#define V3D_CG_TD_S2 3       // ... stride-2 layers (2 -> 3: conv1 0.207 -> 0.186 ms, conv3 0.116 -> 0.103; 4 leaves one workgroup per CU: 0.255)
+#endif
+  static constexpr int TD = FLAT ? V3D_FLAT_TD : WB != 14 ? (S == 2 ? 2 : 4) : S == 2 ? V3D_CG_TD_S2 : V3D_CG_TD_S1, TH = 4 * NRB, TW = WB;
   static constexpr int NKZ = FLAT ? 1 : 3;                             // z taps
   static constexpr int ID = FLAT ? TD : S * (TD - 1) + 3, IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
   static constexpr int NVOX = ID * IH * IW, NVOXP = NVOX + 8;         // idle lanes read a few slots past a row
@@ -1079,7 +1085,10 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
       PHASE_MARK(1);
       if (chunk + 1 < C::NCH) issue(cur, chunk + 1);
       else if (XPRE && has_next) issue(nxt, 0);
-#pragma unroll 1
+#ifndef V3D_CG_KYU
+#define V3D_CG_KYU 1
+#endif
+#pragma unroll V3D_CG_KYU
       for (int ky = 0; ky < 3; ++ky) {
         bf16x8 a_hi[C::NKZ], a_lo[C::NKZ];
 #pragma unroll
