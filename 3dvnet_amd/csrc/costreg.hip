@@ -1202,9 +1202,13 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
 // (pz, dz) combinations (0,0), (1,0), (1,1) x 4 (py, px) parities = 12 blocks of weights (zero where a parity does not
 // see an input).  A wave keeps the B fragments of its two cell rows in registers and walks the 12 blocks.
 // Input: split channel-last layout; output = ReLU(BN(deconv)) + skip (fp32 [n, COUT, D, H, W]) as fp32 or split.
-template <int CIN_, int COUT_, int WB_, int OUT_>
+// SKIP_SPLIT (the fused chain): the skip tensor comes in the split layout its producer (conv2 / conv4) hands to the next encoder
+// layer anyway -- skip = hi + lo, the 16 mantissa bits every other operand of this mode has, as conv9+prob reads the conv0
+// skip -- so that the encoder layer does not write a second, fp32 copy of its output (conv2: 308 of 924 MB per 64 cfg2 views).
+template <int CIN_, int COUT_, int WB_, int OUT_, bool SKIP_SPLIT_ = false>
 struct DG {
   static constexpr int CIN = CIN_, COUT = COUT_, WB = WB_, OUT = OUT_;
+  static constexpr bool SKIP_SPLIT = SKIP_SPLIT_;
   static constexpr int NCH = CIN / 8, NCG = COUT / 16;
   static constexpr int NRB = 16 / WB;                         // cell rows per MFMA column block
   static constexpr int CZ = 2, CY = 4 * NRB, CX = WB;         // cells per tile; wave w = cell rows w*NRB .. of both cz
@@ -1222,7 +1226,7 @@ struct DeconvGParams {
   const void* in;      // split layout [n][CIN/8][hi, lo][Di][Hi][Wi]
   const void* wp;      // [NCG][NCH][12][hi, lo][64 lanes][4 words]
   const float* bias;   // [COUT]
-  const float* skip;   // [n, COUT, 2Di, 2Hi, 2Wi] fp32
+  const float* skip;   // [n, COUT, 2Di, 2Hi, 2Wi] fp32 -- or, SKIP_SPLIT, the split layout [n][COUT/8][hi, lo][2Di][2Hi][2Wi]
   float* out_f32;      // same shape, or null
   void* out_split;     // split layout, or null
   int n, Di, Hi, Wi, ntz, nty, ntx;
@@ -1336,12 +1340,28 @@ __global__ __launch_bounds__(256, 2) void deconvg_bf16x2_kernel(DeconvGParams p)
         const int pz = pzy >> 1, py = pzy & 1;
         const size_t sp = ((size_t)(2 * gcz + pz) * Ho + (2 * gcy + py)) * Wo + 2 * gcx;
         float v0[4], v1[4];
+        float sk0[4], sk1[4];
+        if constexpr (C::SKIP_SPLIT) {
+          // channels 4 kq .. 4 kq + 3 of group cg * 2 + (kq >> 1): one 8-byte half of the hi / lo slots of the two voxels
+          const u32x2* const ss = reinterpret_cast<const u32x2*>(p.skip) +
+                                  (((size_t)n * (C::COUT / 8) + cg * 2 + (kq >> 1)) * 2 * out_plane) * 2 + (kq & 1);
+          const u32x2 h0 = ss[sp * 2], h1 = ss[(sp + 1) * 2], l0 = ss[(out_plane + sp) * 2], l1 = ss[(out_plane + sp + 1) * 2];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned sh = (r & 1) ? 0u : 16u, mk = (r & 1) ? 0xffff0000u : 0xffffffffu;
+            sk0[r] = __uint_as_float((h0[r >> 1] << sh) & mk) + __uint_as_float((l0[r >> 1] << sh) & mk);
+            sk1[r] = __uint_as_float((h1[r >> 1] << sh) & mk) + __uint_as_float((l1[r >> 1] << sh) & mk);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t o = ((size_t)n * C::COUT + cg * 16 + 4 * kq + r) * out_plane + sp;
-          const float2 sk = *reinterpret_cast<const float2*>(p.skip + o);
-          v0[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 0][r] + bias[r], 0.f) + sk.x;
-          v1[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 1][r] + bias[r], 0.f) + sk.y;
+          if constexpr (!C::SKIP_SPLIT) {
+            const float2 sk = *reinterpret_cast<const float2*>(p.skip + o);
+            sk0[r] = sk.x; sk1[r] = sk.y;
+          }
+          v0[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 0][r] + bias[r], 0.f) + sk0[r];
+          v1[r] = fmaxf(acc[cz][pz * 4 + py * 2 + 1][r] + bias[r], 0.f) + sk1[r];
           if constexpr ((C::OUT & kOutF32) != 0) *reinterpret_cast<float2*>(p.out_f32 + o) = make_float2(v0[r], v1[r]);
         }
         if constexpr ((C::OUT & kOutSplit) != 0) {
@@ -2498,9 +2518,13 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
 #else
 #define V3D_STOP(l)
 #endif
-    // conv1..conv6 hand their activations on in the split layout; conv2 and conv4 also leave the fp32 tensors that
-    // the transposed convolutions (per-layer kernels) add as skips.  The split copies live in the u9 slot of the
-    // workspace, which the fused conv9+prob kernel no longer needs.
+    // conv1..conv6 hand their activations on in the split layout; the transposed convolutions read their skips (conv2, conv4)
+    // from the same split copies (DG::SKIP_SPLIT; until round 4 conv2 / conv4 wrote a second, fp32 tensor for them).  The
+    // split copies live in the u9 slot of the workspace, which the fused conv9+prob kernel no longer needs.
+#ifndef V3D_SKIP_SPLIT
+#define V3D_SKIP_SPLIT true      // developer A/B: false = conv2 / conv4 also write fp32 tensors, the skips of conv8 / conv7 (rounds 2-3)
+#endif
+    constexpr int V3D_SKIP_OUT = V3D_SKIP_SPLIT ? kOutSplit : (kOutF32 | kOutSplit);
     float* const c2s = F(ws.u9);
     float* const c4s = c2s + (size_t)n * 16 * (D / 2) * (H / 2) * (W / 2);
     auto W_ = [&](int l) { return h->dev + h->cgbf_ofs[l]; };
@@ -2509,14 +2533,14 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     if ((rc = launch_convg<CG<8, 16, 2, 14, kOutSplit>>("costreg_conv1", F(ws.c0), W_(1), B_(1), nullptr, F(ws.c1), n, D, H, W,
                                                         s)) != V3D_OK) return rc;
     V3D_STOP(1);
-    if ((rc = launch_convg<CG<16, 16, 1, 14, kOutF32 | kOutSplit>>("costreg_conv2", F(ws.c1), W_(2), B_(2), F(ws.c2), c2s, n,
-                                                                   D / 2, H / 2, W / 2, s)) != V3D_OK) return rc;
+    if ((rc = launch_convg<CG<16, 16, 1, 14, V3D_SKIP_OUT>>("costreg_conv2", F(ws.c1), W_(2), B_(2), F(ws.c2), c2s, n,
+                                                            D / 2, H / 2, W / 2, s)) != V3D_OK) return rc;
     V3D_STOP(2);
     if ((rc = launch_convg<CG<16, 32, 2, 14, kOutSplit>>("costreg_conv3", c2s, W_(3), B_(3), nullptr, F(ws.c3), n, D / 2, H / 2,
                                                          W / 2, s)) != V3D_OK) return rc;
     V3D_STOP(3);
-    if ((rc = launch_convg<CG<32, 32, 1, 14, kOutF32 | kOutSplit>>("costreg_conv4", F(ws.c3), W_(4), B_(4), F(ws.c4), c4s, n,
-                                                                   D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
+    if ((rc = launch_convg<CG<32, 32, 1, 14, V3D_SKIP_OUT>>("costreg_conv4", F(ws.c3), W_(4), B_(4), F(ws.c4), c4s, n,
+                                                            D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
     V3D_STOP(4);
     if ((rc = launch_convg<CG<32, 64, 2, 8, kOutSplit>>("costreg_conv5", c4s, W_(5), B_(5), nullptr, F(ws.c5), n, D / 4, H / 4,
                                                         W / 4, s)) != V3D_OK) return rc;
@@ -2525,11 +2549,13 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
                                                         H / 8, W / 8, s)) != V3D_OK) return rc;
     V3D_STOP(6);
     // conv4 + conv7(x) (mvsnet.py:159), conv2 + conv8(x) (:160)
-    if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit>>("costreg_conv7", F(ws.c6), h->dev + h->dgbf_ofs[0], B_(7), F(ws.c4),
-                                                       nullptr, F(ws.u7), n, D / 8, H / 8, W / 8, s)) != V3D_OK) return rc;
+    if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit, V3D_SKIP_SPLIT>>("costreg_conv7", F(ws.c6), h->dev + h->dgbf_ofs[0], B_(7),
+                                                                       V3D_SKIP_SPLIT ? c4s : F(ws.c4), nullptr, F(ws.u7), n, D / 8,
+                                                                       H / 8, W / 8, s)) != V3D_OK) return rc;
     V3D_STOP(7);
-    if ((rc = launch_deconvg<DG<32, 16, 14, kOutSplit>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8), F(ws.c2),
-                                                        nullptr, F(ws.u8), n, D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
+    if ((rc = launch_deconvg<DG<32, 16, 14, kOutSplit, V3D_SKIP_SPLIT>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8),
+                                                                        V3D_SKIP_SPLIT ? c2s : F(ws.c2), nullptr, F(ws.u8), n, D / 4,
+                                                                        H / 4, W / 4, s)) != V3D_OK) return rc;
     V3D_STOP(8);
 #undef V3D_STOP
   }
