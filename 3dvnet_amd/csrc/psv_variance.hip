@@ -42,7 +42,20 @@ struct PsvParams {
   const float* camp;   // [n_img][kCamStride] per-image camera block, see cam_setup_kernel
   int n_img, n_ref, Hf, Wf, H, W, D, h, w, n_ptile;
   double x_step, y_step, z_start, z_step, z_end;
+  // window kernel: launch constants the host works out once -- per wave they were two IEEE f64 divisions and three integer
+  // divisions through v_rcp_iflag_f32 (round 4: ~110 of the ~2 100 VALU issue slots of a wave at cfg2)
+  float rWm1, rHm1;                        // (float)(1.0 / (double)(W - 1)), (float)(1.0 / (double)(H - 1))
+  unsigned m_dchunk, m_ptile, m_w;         // psv_magic() of the plane-chunk count, of n_ptile and of w (0: divide)
 };
+
+// q = floor(x / d) as mulhi(x, ceil(2^32 / d)): exact while x * (m * d - 2^32) < 2^32, which holds for x <= x_max when
+// x_max * d < 2^32 (m * d - 2^32 < d); otherwise 0 = "divide"
+static unsigned psv_magic(unsigned long long x_max, unsigned d) {
+  if (d == 0 || x_max * d >= (1ull << 32)) return 0u;
+  if (d == 1) return 0u;                   // ceil(2^32 / 1) does not fit
+  return (unsigned)(((1ull << 32) + d - 1) / d);
+}
+__device__ __forceinline__ unsigned psv_udiv(unsigned x, unsigned d, unsigned m) { return m ? __umulhi(x, m) : x / d; }
 
 // [n_img, C, HW] -> [n_img, HW, C]
 template <int C>
@@ -695,10 +708,11 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   float (*const s_P)[12] = s_P_[wv];
   int* const s_base = s_base_[wv];
   const int n_dchunk = (p.D + kRDB - 1) / kRDB;
-  int b = v3d::xcd_contiguous_block();
-  const int dchunk = b % n_dchunk; b /= n_dchunk;            // plane chunks fastest (see the reuse kernel)
-  const int ptile = (b % p.n_ptile) * WPB + wv;
-  const int r = b / p.n_ptile;
+  const unsigned b = (unsigned)v3d::xcd_contiguous_block();
+  const unsigned b1 = psv_udiv(b, (unsigned)n_dchunk, p.m_dchunk), b2 = psv_udiv(b1, (unsigned)p.n_ptile, p.m_ptile);
+  const int dchunk = (int)(b - b1 * (unsigned)n_dchunk);     // plane chunks fastest (see the reuse kernel)
+  const int ptile = (int)(b1 - b2 * (unsigned)p.n_ptile) * WPB + wv;
+  const int r = (int)b2;
   const int P = p.h * p.w;
   const int e_begin = p.edge_ofs[r], e_end = p.edge_ofs[r + 1];
   const int ne = e_end - e_begin;
@@ -712,15 +726,26 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   const int d1 = dchunk * kRDB + pl1;
   float X, Y, Z;
   {
-    const int gy = gp1 / p.w, gx = gp1 % p.w;
+    // row / column of the lane's pixel: the wave's first pixel is divided once (wave-uniform), the lane adds its offset
+    // (rows of at least kRPix pixels wrap at most once)
+    int gy, gx;
+    if (p.w >= kRPix) {
+      const unsigned g0 = (unsigned)(ptile * kRPix), gy0 = psv_udiv(g0, (unsigned)p.w, p.m_w);
+      gx = (int)(g0 - gy0 * (unsigned)p.w) + px1;
+      gy = (int)gy0;
+      if (gx >= p.w) { gx -= p.w; ++gy; }
+    } else {
+      gy = gp1 / p.w; gx = gp1 % p.w;
+    }
     const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
     const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
     const float z = (d1 == p.D - 1 && p.D > 1) ? (float)p.z_end : (float)(p.z_start + (double)d1 * p.z_step);
     v3d::world_point(s_ref, xf, yf, z, X, Y, Z);
   }
   const bool live1 = gp1 < P && d1 < p.D;                   // lane 0 is always live
+  const bool all_live = __all(live1);
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1);
-  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
+  const float rWm1 = p.rWm1, rHm1 = p.rHm1;
   const float Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
   const int Wp = p.Wf + 2;
   const float Wff = (float)p.Wf, Hff = (float)p.Hf;
@@ -791,9 +816,12 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     yb = (int)y0 + 1;
     // lanes beyond the plane grid / the last plane must not stretch the box: they take lane 0's cell (always live) -- read
     // under full exec (inside a branch on !live1 readfirstlane would return the first DEAD lane's own value)
-    const int xb0 = __builtin_amdgcn_readlane(xb, 0), yb0 = __builtin_amdgcn_readlane(yb, 0);
-    xb = live1 ? xb : xb0;
-    yb = live1 ? yb : yb0;
+    // (wave-uniform skip: only the waves on the last pixels of the plane grid / the last planes have such lanes)
+    if (!all_live) {
+      const int xb0 = __builtin_amdgcn_readlane(xb, 0), yb0 = __builtin_amdgcn_readlane(yb, 0);
+      xb = live1 ? xb : xb0;
+      yb = live1 ? yb : yb0;
+    }
   };
   // Software pipeline over the edges: the samples of edge e + 1 are projected while the window of edge e is on its way
   // from L2 to LDS (the copy's latency was 0.27 of 1.59 ms when the wave simply waited for it)
@@ -886,6 +914,8 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
         sn = s_slot[(pl + 1) * kRPix + gpx];
       }
       if (((chg >> (8 * pl)) & 0xffull) && (V3D_PSVW_ABLATE != 2 || (pl == 0 && e == 0))) {      // wave-uniform: all pixels reload together (a load costs the same masked or not)
+        // (a wave-uniform test "no sample of this plane is outside the window" -- one ballot per pass -- in front of the per-lane
+        // sign test saves a v_cmp and the exec-mask juggling in 95 % of the planes and measured 0.6 % SLOWER, round 4)
         if (V3D_PSVW_ABLATE != 6 && (int)so_pl < 0) {
           const unsigned b00 = so_pl & 0x7fffffffu;
           t00 = *reinterpret_cast<const f32x4*>(fb + (size_t)(b00 + cgb));
@@ -915,6 +945,9 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     const int chunk = cg >> 1, half = cg & 1;
     u32x4* const out = reinterpret_cast<u32x4*>(p.var);
     const int gp = ptile * kRPix + gpx;
+    // the lane's slot on the chunk's first plane; plane pl is pl * P slots further (a wave-uniform stride: with the whole
+    // index spelled out per plane the compiler rebuilt the 64-bit product -- two v_mul_lo_u32 and a v_mad_u64_u32 -- eight times)
+    u32x4* const obase = out + (((size_t)r * 8 + chunk * 2 + half) * p.D + (size_t)dchunk * kRDB) * P + gp;
     // x / cnt is an IEEE division; for a power-of-two count x * (1 / cnt) is the same number exactly.  ONE wave-uniform
     // branch around the whole epilogue (the reuse kernel tests it per value: 64 branches)
 #define V3D_PSV_EMIT(MEAN)                                                                                              \
@@ -930,7 +963,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
       /* channels 4 cg .. 4 cg + 3 = half `half` of the voxel's channel group `chunk`: the lane's own 16 bytes */         \
       const u32x4 slot = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};  \
       if (gp < P && d < p.D)                                                                                            \
-        __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);               \
+        __builtin_nontemporal_store(slot, obase + (size_t)pl * (unsigned)P);                                             \
     } else {                                                                                                            \
     const unsigned h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);                                        \
     const unsigned l01 = pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));     \
@@ -940,7 +973,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, true);                              \
     const u32x4 slot = half ? (u32x4){r0, r1, l01, l23} : (u32x4){h01, h23, r0, r1};                                    \
     if (gp < P && d < p.D && (V3D_PSVW_ABLATE != 5 || slot[0] == 0x12345u))                                             \
-      __builtin_nontemporal_store(slot, &out[(((size_t)r * 8 + chunk * 2 + half) * p.D + d) * P + gp]);                 \
+      __builtin_nontemporal_store(slot, obase + (size_t)pl * (unsigned)P);                                               \
     }                                                                                                                   \
   }
 #define V3D_MEAN_MUL(x) ((x) * cnt_inv)
@@ -1110,6 +1143,16 @@ static int psv_variance_impl(int mode, const float* feat, const float* K, const 
       const bool no_window = reuse_env || psv_feat_bytes(n_img, C, Hf, Wf) >= ((size_t)1 << 31);
       V3D_REQUIRE(!cl8 || !no_window, V3D_ERR_UNSUPPORTED,
                   "v3d_psv_variance_cl8: only the window kernel writes this layout (feature maps < 2 GB, no developer switch)");
+      {      // launch constants of the window kernel (PsvParams)
+        const unsigned ndc = (unsigned)((D + kRDB - 1) / kRDB);
+        const unsigned npt = (unsigned)(split || cl8 ? p.n_ptile : (p.n_ptile + 3) / 4);
+        const unsigned long long nblk = (unsigned long long)n_ref * ndc * npt;
+        p.rWm1 = (float)(1.0 / (double)(W - 1));
+        p.rHm1 = (float)(1.0 / (double)(H - 1));
+        p.m_dchunk = psv_magic(nblk, ndc);
+        p.m_ptile = psv_magic(nblk / ndc + 1, npt);
+        p.m_w = psv_magic((unsigned long long)h * w + 4 * kRPix, (unsigned)w);
+      }
       if (cl8) {
         psv_variance_window_kernel<true, true><<<(unsigned)rblocks, 64, 0, s>>>(p);
       } else if (split) {
