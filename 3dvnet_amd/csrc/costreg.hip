@@ -1528,8 +1528,14 @@ struct C9Params {
   float* out;          // [n, D, H, W]
   int n, D, H, W, ntz, nty, ntx;
   int zy_order;        // tile_order(): 1 = x, z, y
+  unsigned m_tx, m_t1, m_t2;   // v3d::magic_u32() of ntx and of the two tile counts divided after it (in zy_order's order)
 };
 
+// Address arithmetic (round 4).  A workgroup lives for one tile, so its prologue -- tile index -> (n, tz, ty, tx), the clamped
+// addresses of 3 input slots and 16 skip half-slots per lane -- is paid per tile: written with size_t indices it was 46
+// quarter-rate integer instructions (v_mad_u64_u32, v_mul_lo_u32, five v_rcp_iflag_f32 division sequences) among ~850 VALU
+// instructions of a wave, as many issue slots as the prob conv's FMAs.  Now: host magic numbers for the tile index, 24-bit
+// multiplies, wave-uniform row bases in SGPRs + 32-bit lane offsets (the host checks that a view's tensors stay below 4 GB).
 // 8 waves per workgroup, <= 128 VGPRs: two workgroups = 16 waves per CU (round 1's 4-wave version needed 218 VGPRs, i.e.
 // 8 waves per CU, and spent most of its time waiting for its own loads, barriers and LDS round trips: 0.55 -> 0.45 ms).  The weight fragments
 // are parked in LDS next to the input tile (both are dead before the u9 tile overwrites them) instead of 72 registers, a
@@ -1551,11 +1557,18 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
-  int b = v3d::xcd_contiguous_block();
-  const int tx = b % p.ntx; b /= p.ntx;
+  const unsigned b0 = (unsigned)v3d::xcd_contiguous_block();
+  const unsigned b1 = v3d::udiv_magic(b0, (unsigned)p.ntx, p.m_tx);
+  const int tx = (int)(b0 - b1 * (unsigned)p.ntx);
   int ty, tz, n;
-  if (p.zy_order) { tz = b % p.ntz; b /= p.ntz; ty = b % p.nty; n = b / p.nty; }
-  else { ty = b % p.nty; b /= p.nty; tz = b % p.ntz; n = b / p.ntz; }
+  {
+    const unsigned d1 = (unsigned)(p.zy_order ? p.ntz : p.nty), d2 = (unsigned)(p.zy_order ? p.nty : p.ntz);
+    const unsigned b2 = v3d::udiv_magic(b1, d1, p.m_t1), b3 = v3d::udiv_magic(b2, d2, p.m_t2);
+    const int t1 = (int)(b1 - b2 * d1), t2 = (int)(b2 - b3 * d2);
+    tz = p.zy_order ? t1 : t2;
+    ty = p.zy_order ? t2 : t1;
+    n = (int)b3;
+  }
   const int oz0 = tz * C9::TD, oy0 = ty * C9::TH, ox0 = tx * C9::TW;
   const int D2 = p.D >> 1, H2 = p.H >> 1, W2 = p.W >> 1;
   const int iz0 = (oz0 >> 1) - 1, iy0 = (oy0 >> 1) - 1, ix0 = (ox0 >> 1) - 1;
@@ -1567,16 +1580,21 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   // [D/2][H/2][W/2] slots: 2 x 2 x 384 slots, three 16-byte copies per thread) and the weight fragments
   u32x4 pre[3], wpre[3];
   {
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.u8) + (size_t)n * 4 * in_plane;
+    const char* const src = reinterpret_cast<const char*>(reinterpret_cast<const u32x4*>(p.u8) + (size_t)n * 4 * in_plane);
+    const int vx = tid & 15;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int it = tid + NT * i;
-      const int gp = it / 384, vox = it % 384;                       // gp = group * 2 + part
-      const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
+      // slot it = tid + NT * i of the [4 (group, part)][VZ][VY][16] tile: row R = it / 16 = (gp * VZ + vz) * VY + vy
+      const unsigned R = (unsigned)(tid >> 4) + 32u * i;                // 32 i .. 32 i + 31
+      const bool up = R >= 24u * (i + 1);                                // gp = R / 24 = i or i + 1
+      const unsigned rem = R - (up ? 24u * (i + 1) : 24u * i);           // R % 24
+      const unsigned uz = __umul24(rem, 43u) >> 8;                       // rem / 6 (exact below 24)
+      const int vz = (int)uz, vy = (int)(rem - __umul24(uz, 6u));
       const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
       const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
       const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1), xc = min(max(gx, 0), W2 - 1);
-      const u32x4 val = V3D_C9_ABLATE == 5 ? (u32x4){1u, 2u, 3u, (unsigned)tid} : src[(size_t)gp * in_plane + ((size_t)zc * H2 + yc) * W2 + xc];
+      const unsigned idx = (unsigned)in_plane * i + (up ? (unsigned)in_plane : 0u) + __umul24(__umul24(zc, H2) + yc, W2) + xc;   // < 2^28 (host check)
+      const u32x4 val = V3D_C9_ABLATE == 5 ? (u32x4){1u, 2u, 3u, (unsigned)tid} : *reinterpret_cast<const u32x4*>(src + idx * 16u);
       pre[i] = ok ? val : (u32x4){0u, 0u, 0u, 0u};
     }
     const u32x4* wq = reinterpret_cast<const u32x4*>(p.wbf);
@@ -1590,18 +1608,22 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   const int px = kq >> 1, cbase = 4 * (kq & 1);
   u32x2 skh[NCBI][4], skl[NCBI][4];
   {
-    const u32x2* skip = reinterpret_cast<const u32x2*>(p.c0) + ((size_t)n * 2 * out_plane) * 2 + (kq & 1);
+    const char* const skip = reinterpret_cast<const char*>(reinterpret_cast<const u32x2*>(p.c0) + ((size_t)n * 2 * out_plane) * 2);
+    // the row (z, y) of a (cell row, rb) is wave-uniform: its base stays in SGPRs, the lane adds its x slot and channel half
+    const int gx = ox0 - 1 + 2 * jn + px;
+    const unsigned lofs = (unsigned)min(max(gx, 0), p.W - 1) * 16u + (unsigned)(kq & 1) * 8u;
+    const unsigned lo_plane = (unsigned)out_plane * 16u;                  // hi slots -> lo slots, bytes (< 2^31, host check)
 #pragma unroll
     for (int cbi = 0; cbi < NCBI; ++cbi) {
       const int cb = min(wave + 8 * cbi, C9::NCB - 1);
       const int cz = cb / C9::CY, cy = cb % C9::CY;
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
-        const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1), gx = ox0 - 1 + 2 * jn + px;
-        const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1), xc = min(max(gx, 0), p.W - 1);
-        const size_t sp = ((size_t)zc * p.H + yc) * p.W + xc;
-        skh[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){(unsigned)sp, 1u} : skip[sp * 2];
-        skl[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){(unsigned)sp, 2u} : skip[(out_plane + sp) * 2];
+        const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1);
+        const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1);
+        const unsigned rofs = (unsigned)((zc * p.H + yc) * p.W) * 16u;     // wave-uniform
+        skh[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){rofs + lofs, 1u} : *reinterpret_cast<const u32x2*>(skip + rofs + lofs);
+        skl[cbi][rb] = V3D_C9_ABLATE == 4 ? (u32x2){rofs + lofs, 2u} : *reinterpret_cast<const u32x2*>(skip + lo_plane + rofs + lofs);
       }
     }
   }
@@ -1610,10 +1632,11 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   // ---- stage the input tile (slot = voxel * 2 + channel half (group), hi and lo arrays) and the weight fragments ------
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int it = tid + NT * i;
-    const int gp = it / 384, vox = it % 384;
-    const int vx = vox & 15, vy = (vox >> 4) % C9::VY, vz = vox / (16 * C9::VY);
-    const int slot = ((vz * C9::VY + vy) * C9::VX + vx) * 2 + (gp >> 1);
+    const unsigned R = (unsigned)(tid >> 4) + 32u * i;                   // as above
+    const bool up = R >= 24u * (i + 1);
+    const int gp = i + (up ? 1 : 0);
+    const unsigned rem = R - (up ? 24u * (i + 1) : 24u * i);             // vz * VY + vy
+    const int slot = (int)(__umul24(rem, (unsigned)C9::VX) + (unsigned)(tid & 15)) * 2 + (gp >> 1);
     ((gp & 1) ? xl : xh)[slot] = pre[i];
   }
 #pragma unroll
@@ -1738,7 +1761,7 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
       if (gz < p.D && gy < p.H && gx < p.W) {
         const float bsv = p.bprob[0];
         const f32x2 res = {s0.x + s0.y + bsv, s1.x + s1.y + bsv};
-        float* o = p.out + (size_t)n * out_plane + ((size_t)gz * p.H + gy) * p.W + gx;
+        float* o = p.out + ((size_t)n * out_plane + (size_t)(gz * p.H) * p.W) + (unsigned)(__umul24(gy, p.W) + gx);   // uniform base + lane offset
         if (gx + 1 < p.W && (p.W & 1) == 0) {
           *reinterpret_cast<f32x2*>(o) = res;
         } else {
@@ -2583,6 +2606,12 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     q.zy_order = tile_order(q.ntx, q.nty);
     const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
     V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
+    // 32-bit byte offsets inside one view's tensors (conv0 skip: 2 x 16 bytes per voxel)
+    V3D_REQUIRE((long long)D * H * W < (1ll << 26) && D < (1 << 12) && H < (1 << 12) && W < (1 << 12), V3D_ERR_BAD_SHAPE,
+                "conv9+prob: volume %d x %d x %d too large for 32-bit offsets", D, H, W);
+    q.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)q.ntx);
+    q.m_t1 = v3d::magic_u32((unsigned long long)blocks / q.ntx + 1, (unsigned)(q.zy_order ? q.ntz : q.nty));
+    q.m_t2 = v3d::magic_u32((unsigned long long)blocks / q.ntx / (q.zy_order ? q.ntz : q.nty) + 1, (unsigned)(q.zy_order ? q.nty : q.ntz));
     {
       v3d::TimedScope ts("costreg_conv9_prob", s);
       conv9_prob_kernel<<<(unsigned)blocks, 512, 0, s>>>(q);

@@ -45,17 +45,9 @@ struct PsvParams {
   // window kernel: launch constants the host works out once -- per wave they were two IEEE f64 divisions and three integer
   // divisions through v_rcp_iflag_f32 (round 4: ~110 of the ~2 100 VALU issue slots of a wave at cfg2)
   float rWm1, rHm1;                        // (float)(1.0 / (double)(W - 1)), (float)(1.0 / (double)(H - 1))
-  unsigned m_dchunk, m_ptile, m_w;         // psv_magic() of the plane-chunk count, of n_ptile and of w (0: divide)
+  unsigned m_dchunk, m_ptile, m_w;         // v3d::magic_u32() of the plane-chunk count, of n_ptile and of w (0: divide)
 };
 
-// q = floor(x / d) as mulhi(x, ceil(2^32 / d)): exact while x * (m * d - 2^32) < 2^32, which holds for x <= x_max when
-// x_max * d < 2^32 (m * d - 2^32 < d); otherwise 0 = "divide"
-static unsigned psv_magic(unsigned long long x_max, unsigned d) {
-  if (d == 0 || x_max * d >= (1ull << 32)) return 0u;
-  if (d == 1) return 0u;                   // ceil(2^32 / 1) does not fit
-  return (unsigned)(((1ull << 32) + d - 1) / d);
-}
-__device__ __forceinline__ unsigned psv_udiv(unsigned x, unsigned d, unsigned m) { return m ? __umulhi(x, m) : x / d; }
 
 // [n_img, C, HW] -> [n_img, HW, C]
 template <int C>
@@ -709,7 +701,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
   int* const s_base = s_base_[wv];
   const int n_dchunk = (p.D + kRDB - 1) / kRDB;
   const unsigned b = (unsigned)v3d::xcd_contiguous_block();
-  const unsigned b1 = psv_udiv(b, (unsigned)n_dchunk, p.m_dchunk), b2 = psv_udiv(b1, (unsigned)p.n_ptile, p.m_ptile);
+  const unsigned b1 = v3d::udiv_magic(b, (unsigned)n_dchunk, p.m_dchunk), b2 = v3d::udiv_magic(b1, (unsigned)p.n_ptile, p.m_ptile);
   const int dchunk = (int)(b - b1 * (unsigned)n_dchunk);     // plane chunks fastest (see the reuse kernel)
   const int ptile = (int)(b1 - b2 * (unsigned)p.n_ptile) * WPB + wv;
   const int r = (int)b2;
@@ -730,7 +722,7 @@ __global__ __launch_bounds__(SPLIT ? 64 : 256, V3D_PSV_WAVES) void psv_variance_
     // (rows of at least kRPix pixels wrap at most once)
     int gy, gx;
     if (p.w >= kRPix) {
-      const unsigned g0 = (unsigned)(ptile * kRPix), gy0 = psv_udiv(g0, (unsigned)p.w, p.m_w);
+      const unsigned g0 = (unsigned)(ptile * kRPix), gy0 = v3d::udiv_magic(g0, (unsigned)p.w, p.m_w);
       gx = (int)(g0 - gy0 * (unsigned)p.w) + px1;
       gy = (int)gy0;
       if (gx >= p.w) { gx -= p.w; ++gy; }
@@ -1149,9 +1141,9 @@ static int psv_variance_impl(int mode, const float* feat, const float* K, const 
         const unsigned long long nblk = (unsigned long long)n_ref * ndc * npt;
         p.rWm1 = (float)(1.0 / (double)(W - 1));
         p.rHm1 = (float)(1.0 / (double)(H - 1));
-        p.m_dchunk = psv_magic(nblk, ndc);
-        p.m_ptile = psv_magic(nblk / ndc + 1, npt);
-        p.m_w = psv_magic((unsigned long long)h * w + 4 * kRPix, (unsigned)w);
+        p.m_dchunk = v3d::magic_u32(nblk, ndc);
+        p.m_ptile = v3d::magic_u32(nblk / ndc + 1, npt);
+        p.m_w = v3d::magic_u32((unsigned long long)h * w + 4 * kRPix, (unsigned)w);
       }
       if (cl8) {
         psv_variance_window_kernel<true, true><<<(unsigned)rblocks, 64, 0, s>>>(p);

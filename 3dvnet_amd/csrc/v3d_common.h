@@ -86,6 +86,17 @@ __device__ __forceinline__ int xcd_contiguous_block() {
   return x * per + (x < rem ? x : rem) + i;
 }
 
+// Division of a (usually wave-uniform) index by a launch constant.  hipcc expands x / d for a run-time d into a float
+// reciprocal sequence on the VECTOR unit (v_cvt, v_rcp_iflag_f32, v_mul_hi_u32, fix-ups: ~12 instructions, several at quarter
+// rate) even when x is in SGPRs; with m = magic_u32(x_max, d) from the host it is one s_mul_hi_u32.
+//   q = mulhi(x, ceil(2^32 / d)) is exact while x * (m * d - 2^32) < 2^32, i.e. for all x <= x_max when x_max * d < 2^32
+//   (m * d - 2^32 < d); magic_u32 returns 0 = "divide" when that does not hold (or d == 1: 2^32 does not fit).
+inline unsigned magic_u32(unsigned long long x_max, unsigned d) {
+  if (d <= 1 || x_max * d >= (1ull << 32)) return 0u;
+  return (unsigned)(((1ull << 32) + d - 1) / d);
+}
+__device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned m) { return m ? __umulhi(x, m) : x / d; }
+
 // Persistent kernels: the grid is the number of workgroups resident at once (a multiple of 8, see persistent_grid()).
 // Workgroup (XCD x = id & 7, slot i = id >> 3) walks tiles first_x + i, first_x + i + G, ... of its XCD's contiguous run of the
 // logical tile order (G = workgroups per XCD), so at any moment an XCD's workgroups sit on G consecutive tiles.
