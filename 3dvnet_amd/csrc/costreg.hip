@@ -978,6 +978,7 @@ struct CG {
   // (the output staging starts at the LDS base: behind the last barrier the weight fragments are as dead as the input tile)
   static_assert((size_t)NVO * 64 <= LDS_BYTES, "split output staging fits in the workgroup's LDS");
   static_assert((size_t)16 * (NVO + 2) * 4 <= LDS_BYTES, "fp32 output staging fits in the workgroup's LDS");
+  static_assert((NROWS + RPI) * ID * IH < (1 << 20) && 4 * NVO * NVO < (1 << 20), "v3d::small_div ranges of the staging / output index");
 };
 
 struct ConvGParams {
@@ -1030,16 +1031,21 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
     const int iz0 = C::FLAT ? q.oz0 : C::S * q.oz0 - 1, iy0 = C::S * q.oy0 - 1, sgx = C::S * q.ox0 - 1 + lx;
     const bool xin = xok && sgx >= 0 && sgx < p.Wi;
     const int sxc = min(max(sgx, 0), p.Wi - 1);
-    const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)q.n * C::NCH * 2 * in_plane;
+    // (wave-uniform 64-bit base of the chunk's hi plane + a 32-bit lane offset built from 24-bit multiplies: with size_t
+    // indices every row cost a v_mad_u64_u32 and two v_mul_lo_u32, quarter-rate instructions; the host checks the range)
+    const char* const ins = reinterpret_cast<const char*>(reinterpret_cast<const u32x4*>(p.in) +
+                                                          ((size_t)q.n * C::NCH + chunk) * 2 * in_plane);
     const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)q.cg * C::NCH * C::WQ;
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
-      const int rr = it * C::RPI + lrow;
-      const int part = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
-      const int gz = iz0 + rem / C::IH, gy = iy0 + rem % C::IH;
+      const unsigned rr = (unsigned)(it * C::RPI + lrow);
+      const unsigned part = v3d::small_div<C::ID * C::IH>(rr), rem = rr - part * (C::ID * C::IH);
+      const unsigned rz = v3d::small_div<C::IH>(rem), ry = rem - rz * C::IH;
+      const int gz = iz0 + (int)rz, gy = iy0 + (int)ry;
       const bool ok = rr < C::NROWS && xin && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi;
       const int zc = min(max(gz, 0), p.Di - 1), yc = min(max(gy, 0), p.Hi - 1);
-      const u32x4 v = ins[(size_t)(chunk * 2 + min(part, 1)) * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + sxc];
+      const unsigned idx = (part ? (unsigned)in_plane : 0u) + __umul24(__umul24(zc, p.Hi) + yc, p.Wi) + sxc;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ins + idx * 16u);
       pre[it] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
     }
 #pragma unroll
@@ -1049,8 +1055,8 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
-      const int rr = it * C::RPI + lrow;
-      const int part = rr / (C::ID * C::IH), rem = rr % (C::ID * C::IH);
+      const unsigned rr = (unsigned)(it * C::RPI + lrow);
+      const unsigned part = v3d::small_div<C::ID * C::IH>(rr), rem = rr - part * (C::ID * C::IH);
       if (rr < C::NROWS && xok) xs[part * C::NVOXP + rem * C::IW + lx] = pre[it];
     }
 #pragma unroll
@@ -1158,12 +1164,16 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
         sp2[((((kq >> 1) * 2 + 1) * C::NVO) + vox) * 2 + (kq & 1)] = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
       }
       __syncthreads();
-      u32x4* const outs = reinterpret_cast<u32x4*>(p.out_split) + ((size_t)n * (C::COUT / 8) + cg * 2) * 2 * out_plane;
+      char* const outs = reinterpret_cast<char*>(reinterpret_cast<u32x4*>(p.out_split) + ((size_t)n * (C::COUT / 8) + cg * 2) * 2 * out_plane);
       const u32x4* const sq = reinterpret_cast<const u32x4*>(smem);
       for (int i = tid; i < 4 * C::NVO; i += 256) {
-        const int gp = i / C::NVO, vox = i % C::NVO;
-        const int gz = oz0 + vox / (C::TH * C::TW), gy = oy0 + (vox / C::TW) % C::TH, gx = ox0 + vox % C::TW;
-        if (gz < p.Do && gy < p.Ho && gx < p.Wo) outs[(size_t)gp * out_plane + ((size_t)gz * p.Ho + gy) * p.Wo + gx] = sq[i];
+        const unsigned gp = v3d::small_div<C::NVO>((unsigned)i), vox = (unsigned)i - gp * C::NVO;
+        const unsigned vz = v3d::small_div<C::TH * C::TW>(vox), vr = vox - vz * (C::TH * C::TW);
+        const unsigned vy = v3d::small_div<C::TW>(vr), vx = vr - vy * C::TW;
+        const int gz = oz0 + (int)vz, gy = oy0 + (int)vy, gx = ox0 + (int)vx;
+        // (32-bit slot index on the wave-uniform base of the item's first plane, as in the staging loads)
+        const unsigned idx = __umul24(gp, (unsigned)out_plane) + __umul24(__umul24(gz, p.Ho) + gy, p.Wo) + gx;
+        if (gz < p.Do && gy < p.Ho && gx < p.Wo) *reinterpret_cast<u32x4*>(outs + idx * 16u) = sq[i];
       }
       if constexpr ((C::OUT & kOutF32) != 0) __syncthreads();
     }
@@ -1955,6 +1965,10 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
   V3D_REQUIRE(((C::OUT & kOutF32) == 0 || out_f32) && ((C::OUT & kOutSplit) == 0 || out_split), V3D_ERR_BAD_ARG,
               "%s: missing output buffer", name);
+  // 32-bit slot offsets inside one (view, channel group): 24-bit multiplies on the axes, 2 (hi, lo) x plane x 16 bytes < 4 GB;
+  // the output side indexes 4 planes from the item's base
+  V3D_REQUIRE(Di < (1 << 12) && Hi < (1 << 12) && Wi < (1 << 12) && (long long)Di * Hi * Wi < (1ll << 24), V3D_ERR_BAD_SHAPE,
+              "%s: volume %d x %d x %d too large for 32-bit slot offsets", name, Di, Hi, Wi);
   static bool attr_set = false;
   if (!attr_set) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)convg_bf16x2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,

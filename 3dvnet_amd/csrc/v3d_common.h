@@ -97,6 +97,14 @@ inline unsigned magic_u32(unsigned long long x_max, unsigned d) {
 }
 __device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned m) { return m ? __umulhi(x, m) : x / d; }
 
+// x / D for a compile-time D >= 2 and a small x (x * D < 2^20): one full-rate 24-bit multiply and a shift -- for such a
+// division hipcc emits v_mul_hi_u32, a quarter-rate instruction
+template <int D>
+__device__ __forceinline__ unsigned small_div(unsigned x) {
+  static_assert(D >= 2 && D < 1024, "small_div: divisor range");
+  return __umul24(x, (unsigned)((1 << 20) / D + 1)) >> 20;
+}
+
 // Persistent kernels: the grid is the number of workgroups resident at once (a multiple of 8, see persistent_grid()).
 // Workgroup (XCD x = id & 7, slot i = id >> 3) walks tiles first_x + i, first_x + i + G, ... of its XCD's contiguous run of the
 // logical tile order (G = workgroups per XCD), so at any moment an XCD's workgroups sit on G consecutive tiles.
