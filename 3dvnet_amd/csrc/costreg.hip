@@ -988,6 +988,7 @@ struct ConvGParams {
   float* out_f32;      // [n, COUT, Do, Ho, Wo] or null
   void* out_split;     // split layout, COUT / 8 groups, or null
   int n, Di, Hi, Wi, Do, Ho, Wo, ntz, nty, ntx;
+  unsigned m_tx, m_ty, m_tz;   // v3d::magic_u32() of ntx, nty, ntz for the item index (0: divide)
 };
 
 // PERSISTENT: the grid is the number of workgroups the chip holds; a workgroup walks (tile, output channel group) items
@@ -1010,13 +1011,16 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
   const size_t out_plane = (size_t)p.Do * p.Ho * p.Wo;
 
   struct Item { int cg, n, oz0, oy0, ox0; };
-  auto decode = [&](int t) __attribute__((always_inline)) {
+  auto decode = [&](int t) __attribute__((always_inline)) {      // (wave-uniform: host magic numbers keep it on the scalar unit)
     Item q;
-    q.cg = t % C::NCG; t /= C::NCG;
-    const int tx = t % p.ntx; t /= p.ntx;
-    const int ty = t % p.nty; t /= p.nty;
-    q.oz0 = (t % p.ntz) * C::TD; q.n = t / p.ntz;
-    q.oy0 = ty * C::TH; q.ox0 = tx * C::TW;
+    const unsigned t0 = (unsigned)t / C::NCG;
+    q.cg = (int)((unsigned)t - t0 * C::NCG);
+    const unsigned t1 = v3d::udiv_magic(t0, (unsigned)p.ntx, p.m_tx), t2 = v3d::udiv_magic(t1, (unsigned)p.nty, p.m_ty);
+    const unsigned t3 = v3d::udiv_magic(t2, (unsigned)p.ntz, p.m_tz);
+    q.ox0 = (int)(t0 - t1 * (unsigned)p.ntx) * C::TW;
+    q.oy0 = (int)(t1 - t2 * (unsigned)p.nty) * C::TH;
+    q.oz0 = (int)(t2 - t3 * (unsigned)p.ntz) * C::TD;
+    q.n = (int)t3;
     return q;
   };
   const v3d::TileWalk walk = v3d::xcd_tile_walk(p.n * p.ntz * p.nty * p.ntx * C::NCG);
@@ -1240,6 +1244,7 @@ struct DeconvGParams {
   float* out_f32;      // same shape, or null
   void* out_split;     // split layout, or null
   int n, Di, Hi, Wi, ntz, nty, ntx;
+  unsigned m_tx, m_ty, m_tz;   // v3d::magic_u32() of ntx, nty, ntz for the tile index (0: divide)
 };
 
 template <class C>
@@ -1251,11 +1256,11 @@ __global__ __launch_bounds__(256, 2) void deconvg_bf16x2_kernel(DeconvGParams p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, jn = lane & 15;
   const int cg = blockIdx.y;
-  int b = v3d::xcd_contiguous_block();
-  const int tx = b % p.ntx; b /= p.ntx;
-  const int ty = b % p.nty; b /= p.nty;
-  const int tz = b % p.ntz;
-  const int n = b / p.ntz;
+  const unsigned b0 = (unsigned)v3d::xcd_contiguous_block();
+  const unsigned b1 = v3d::udiv_magic(b0, (unsigned)p.ntx, p.m_tx), b2 = v3d::udiv_magic(b1, (unsigned)p.nty, p.m_ty);
+  const unsigned b3 = v3d::udiv_magic(b2, (unsigned)p.ntz, p.m_tz);
+  const int tx = (int)(b0 - b1 * (unsigned)p.ntx), ty = (int)(b1 - b2 * (unsigned)p.nty), tz = (int)(b2 - b3 * (unsigned)p.ntz);
+  const int n = (int)b3;
   const int cz0 = tz * C::CZ, cy0 = ty * C::CY, cx0 = tx * C::CX;   // first cell = first input voxel of the tile
   const int Do = 2 * p.Di, Ho = 2 * p.Hi, Wo = 2 * p.Wi;
   const size_t in_plane = (size_t)p.Di * p.Hi * p.Wi;
@@ -1264,15 +1269,21 @@ __global__ __launch_bounds__(256, 2) void deconvg_bf16x2_kernel(DeconvGParams p)
   const u32x4* const ins = reinterpret_cast<const u32x4*>(p.in) + (size_t)n * C::NCH * 2 * in_plane;
   const u32x4* const wg = reinterpret_cast<const u32x4*>(p.wp) + (size_t)cg * C::NCH * C::WQ;
   u32x4 pre[C::NIT], wreg[C::NWIT];
+  static_assert(C::NIT * 256 * C::NVOX < (1 << 20), "v3d::small_div range of the staging index");
   auto issue = [&](int chunk) __attribute__((always_inline)) {
+    // (32-bit slot offsets on the chunk's wave-uniform base, as in convg_bf16x2_kernel; the host checks the range)
+    const char* const insc = reinterpret_cast<const char*>(ins + (size_t)chunk * 2 * in_plane);
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
-      const int i = it * 256 + tid;
-      const int part = i / C::NVOX, v = i % C::NVOX;
-      const int gz = cz0 + v / (C::VY * C::VX), gy = cy0 + (v / C::VX) % C::VY, gx = cx0 + v % C::VX;
+      const unsigned i = (unsigned)(it * 256 + tid);
+      const unsigned part = v3d::small_div<C::NVOX>(i), v = i - part * C::NVOX;
+      const unsigned vz = v3d::small_div<C::VY * C::VX>(v), vr = v - vz * (C::VY * C::VX);
+      const unsigned vy = v3d::small_div<C::VX>(vr), vx = vr - vy * C::VX;
+      const int gz = cz0 + (int)vz, gy = cy0 + (int)vy, gx = cx0 + (int)vx;
       const bool ok = i < C::NSLOT && gz < p.Di && gy < p.Hi && gx < p.Wi;       // inputs past the volume do not exist
       const int zc = min(gz, p.Di - 1), yc = min(gy, p.Hi - 1), xc = min(gx, p.Wi - 1);
-      const u32x4 val = ins[(size_t)(chunk * 2 + min(part, 1)) * in_plane + ((size_t)zc * p.Hi + yc) * p.Wi + xc];
+      const unsigned idx = (part ? (unsigned)in_plane : 0u) + __umul24(__umul24(zc, p.Hi) + yc, p.Wi) + xc;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(insc + idx * 16u);
       pre[it] = ok ? val : (u32x4){0u, 0u, 0u, 0u};
     }
 #pragma unroll
@@ -1282,8 +1293,8 @@ __global__ __launch_bounds__(256, 2) void deconvg_bf16x2_kernel(DeconvGParams p)
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
-      const int i = it * 256 + tid;
-      if (i < C::NSLOT) xs[(i / C::NVOX) * C::NVOXP + i % C::NVOX] = pre[it];
+      const unsigned i = (unsigned)(it * 256 + tid), part = v3d::small_div<C::NVOX>(i);
+      if (i < C::NSLOT) xs[part * C::NVOXP + (i - part * C::NVOX)] = pre[it];
     }
 #pragma unroll
     for (int i = 0; i < C::NWIT; ++i)
@@ -1965,6 +1976,9 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
   V3D_REQUIRE(((C::OUT & kOutF32) == 0 || out_f32) && ((C::OUT & kOutSplit) == 0 || out_split), V3D_ERR_BAD_ARG,
               "%s: missing output buffer", name);
+  p.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)p.ntx);
+  p.m_ty = v3d::magic_u32((unsigned long long)blocks / p.ntx + 1, (unsigned)p.nty);
+  p.m_tz = v3d::magic_u32((unsigned long long)blocks / p.ntx / p.nty + 1, (unsigned)p.ntz);
   // 32-bit slot offsets inside one (view, channel group): 24-bit multiplies on the axes, 2 (hi, lo) x plane x 16 bytes < 4 GB;
   // the output side indexes 4 planes from the item's base
   V3D_REQUIRE(Di < (1 << 12) && Hi < (1 << 12) && Wi < (1 << 12) && (long long)Di * Hi * Wi < (1ll << 24), V3D_ERR_BAD_SHAPE,
@@ -2006,6 +2020,11 @@ int launch_deconvg(const char* name, const void* in, const float* wbf, const flo
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "%s: bad grid", name);
   V3D_REQUIRE(skip && ((C::OUT & kOutF32) == 0 || out_f32) && ((C::OUT & kOutSplit) == 0 || out_split), V3D_ERR_BAD_ARG,
               "%s: missing buffer", name);
+  V3D_REQUIRE(Di < (1 << 12) && Hi < (1 << 12) && Wi < (1 << 12) && (long long)Di * Hi * Wi < (1ll << 24), V3D_ERR_BAD_SHAPE,
+              "%s: volume %d x %d x %d too large for 32-bit slot offsets", name, Di, Hi, Wi);
+  p.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)p.ntx);
+  p.m_ty = v3d::magic_u32((unsigned long long)blocks / p.ntx + 1, (unsigned)p.nty);
+  p.m_tz = v3d::magic_u32((unsigned long long)blocks / p.ntx / p.nty + 1, (unsigned)p.ntz);
   {
     v3d::TimedScope ts(name, s);
     deconvg_bf16x2_kernel<C><<<dim3((unsigned)blocks, C::NCG), 256, 0, s>>>(p);
