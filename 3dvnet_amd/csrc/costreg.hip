@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256, C::OCC) void convg_bf16x2_kernel(ConvGParams p
 // Input: split channel-last layout; output = ReLU(BN(deconv)) + skip (fp32 [n, COUT, D, H, W]) as fp32 or split.
 // SKIP_SPLIT (the fused chain): the skip tensor comes in the split layout its producer (conv2 / conv4) hands to the next encoder
 // layer anyway -- skip = hi + lo, the 16 mantissa bits every other operand of this mode has, as conv9+prob reads the conv0
-// skip -- so that the encoder layer does not write a second, fp32 copy of its output (conv2: 308 of 924 MB per 64 cfg2 views).
+// skip -- so that the encoder layer does not write a second, fp32 copy of its output (conv2: 154 of 463 MB per 64 cfg2 views).
 template <int CIN_, int COUT_, int WB_, int OUT_, bool SKIP_SPLIT_ = false>
 struct DG {
   static constexpr int CIN = CIN_, COUT = COUT_, WB = WB_, OUT = OUT_;
