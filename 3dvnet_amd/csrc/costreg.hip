@@ -1537,12 +1537,17 @@ struct C9 {
   static constexpr int LDS_BYTES = U9_BYTES > IN_BYTES ? U9_BYTES : IN_BYTES;
   static constexpr int NCB = CZ * CY;                              // 15 cell rows = MFMA column blocks
   static constexpr int WU32 = 9 * 2 * 64 * 4;                      // weight image words
+  // exact-fp32 variant (conv9_prob_kernel<true>): the input tile as [16 channels][VZ][VY][VX] floats at a channel stride of
+  // FS floats (== 16 mod 64: the four k lane groups of a B fragment read four channels' rows from four different bank
+  // quarters), the weight fragments as [9 blocks][2 halves][64 lanes][4 k slices] floats
+  static constexpr int FS = 464, WF32 = 9 * 64 * 8;
+  static_assert(FS >= NVOX && FS % 64 == 16 && (16 * FS + WF32) * 4 <= U9_BYTES, "fp32 input tile + weights share the u9 region");
 };
 
 struct C9Params {
-  const float* u8;     // conv8 output in the split layout [n][2 groups][hi, lo][D/2][H/2][W/2][8 bf16]
-  const float* c0;     // conv0 output (skip) in the split channel-last layout [n][hi, lo][D][H][W][8 bf16]
-  const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)
+  const float* u8;     // conv8 output in the split layout [n][2 groups][hi, lo][D/2][H/2][W/2][8 bf16]   (F32: fp32 [n, 16, D/2, H/2, W/2])
+  const float* c0;     // conv0 output (skip) in the split channel-last layout [n][hi, lo][D][H][W][8 bf16]  (F32: fp32 [n, 8, D, H, W])
+  const float* wbf;    // split-bf16 fragment image of the deconv weights (BN scale folded)                 (F32: fp32 fragments, C9::WF32)
   const float* bias9;  // [8] folded BN bias
   const float* wprob;  // [4 channel pairs, 27, 2]
   const float* bprob;  // [1]
@@ -1566,11 +1571,17 @@ struct C9Params {
 #ifndef V3D_C9_ABLATE
 #define V3D_C9_ABLATE 0      // developer ablations (scripts/ab_build.sh): 1 no prob loop, 2 one channel pair only, 3 no MFMAs, 4 no skip loads, 5 no input loads
 #endif
+// F32 (round 4, the exact-fp32 chain): the same tile structure on v_mfma_f32_16x16x4_f32 -- fp32 tensors in the reference
+// layout in, eight k slices of 4 per block where the split path has three bf16 products of 32 -- instead of the generic
+// per-layer conv9 kernel + prob_conv_kernel, which wrote and re-read the 8-channel full-resolution tensor (0.82 + 0.30 ms).
+template <bool F32>
 __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[C9::LDS_BYTES];
   u32x4* const xh = reinterpret_cast<u32x4*>(smem);             // [NVOX][2 halves] hi slots
   u32x4* const xl = xh + C9::NVOX * 2;                          // lo slots
   u32x4* const wfr = xl + C9::NVOX * 2;                         // [9 blocks][hi, lo][64 lanes] weight fragments
+  float* const xf = reinterpret_cast<float*>(smem);             // F32: [16][FS] input tile
+  float* const wff = xf + 16 * C9::FS;                          // F32: [9 blocks][2 halves][64 lanes][4 k slices] weight fragments
   float* const u9s = reinterpret_cast<float*>(smem);            // [8][HD][HH][RS], reuses the input tile
   static_assert(C9::IN_BYTES + C9::WU32 * 4 <= C9::U9_BYTES, "input tile + weight fragments share the u9 region");
   constexpr int NT = 512, NCBI = 2;                             // threads, cell rows per wave (15 rows over 8 waves)
@@ -1600,7 +1611,32 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   // ---- global reads with clamped addresses (no branches): (a) the 4 x 6 x 16 x 16ch input tile ([n][2 groups][hi, lo]
   // [D/2][H/2][W/2] slots: 2 x 2 x 384 slots, three 16-byte copies per thread) and the weight fragments
   u32x4 pre[3], wpre[3];
-  {
+  constexpr int NF = (16 * C9::VZ * C9::VY * 16 + NT - 1) / NT;      // F32: floats per thread of the 16 x 4 x 6 x 16 tile (column 16 is idle)
+  constexpr int NWF = C9::WF32 / 4 / NT + 1;                        // F32: 16-byte pieces of the weight image per thread
+  float pref[F32 ? NF : 1];
+  u32x4 wpref[F32 ? NWF : 1];
+  if constexpr (F32) {
+    // rows of 16 floats: row R = (ci * VZ + vz) * VY + vy, 32 rows per pass of the workgroup
+    const char* const src = reinterpret_cast<const char*>(p.u8 + (size_t)n * 16 * in_plane);
+    const int vx = tid & 15;
+    const int gx = ix0 + vx;
+    const int xc = min(max(gx, 0), W2 - 1);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const unsigned R = (unsigned)(tid >> 4) + 32u * i;                 // < 16 * 24 = 384
+      const unsigned ci = v3d::small_div<C9::VZ * C9::VY>(R), rem = R - ci * (C9::VZ * C9::VY);
+      const unsigned uz = v3d::small_div<C9::VY>(rem);
+      const int gz = iz0 + (int)uz, gy = iy0 + (int)(rem - uz * C9::VY);
+      const bool ok = gz >= 0 && gz < D2 && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+      const int zc = min(max(gz, 0), D2 - 1), yc = min(max(gy, 0), H2 - 1);
+      const unsigned idx = __umul24(ci, (unsigned)in_plane) + __umul24(__umul24(zc, H2) + yc, W2) + xc;
+      const float val = *reinterpret_cast<const float*>(src + idx * 4u);
+      pref[i] = ok ? val : 0.f;
+    }
+    const u32x4* wq = reinterpret_cast<const u32x4*>(p.wbf);
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) wpref[i] = wq[min(tid + NT * i, C9::WF32 / 4 - 1)];
+  } else {
     const char* const src = reinterpret_cast<const char*>(reinterpret_cast<const u32x4*>(p.u8) + (size_t)n * 4 * in_plane);
     const int vx = tid & 15;
 #pragma unroll
@@ -1628,7 +1664,27 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   // slot and 8 bytes of the lo slot
   const int px = kq >> 1, cbase = 4 * (kq & 1);
   u32x2 skh[NCBI][4], skl[NCBI][4];
-  {
+  float skf[F32 ? NCBI : 1][4][4];
+  if constexpr (F32) {
+    // fp32 [n, 8, D, H, W]: the lane's four channels are four planes apart
+    const char* const skip = reinterpret_cast<const char*>(p.c0 + ((size_t)n * 8 + cbase) * out_plane);
+    const int gx = ox0 - 1 + 2 * jn + px;
+    const unsigned lofs = (unsigned)min(max(gx, 0), p.W - 1) * 4u;
+    const unsigned cpl = (unsigned)out_plane * 4u;                       // bytes per channel plane (< 2^28, host check)
+#pragma unroll
+    for (int cbi = 0; cbi < NCBI; ++cbi) {
+      const int cb = min(wave + 8 * cbi, C9::NCB - 1);
+      const int cz = cb / C9::CY, cy = cb % C9::CY;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int gz = oz0 - 1 + 2 * cz + (rb >> 1), gy = oy0 - 1 + 2 * cy + (rb & 1);
+        const int zc = min(max(gz, 0), p.D - 1), yc = min(max(gy, 0), p.H - 1);
+        const unsigned rofs = (unsigned)((zc * p.H + yc) * p.W) * 4u;      // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 4; ++r) skf[cbi][rb][r] = *reinterpret_cast<const float*>(skip + (size_t)r * cpl + rofs + lofs);
+      }
+    }
+  } else {
     const char* const skip = reinterpret_cast<const char*>(reinterpret_cast<const u32x2*>(p.c0) + ((size_t)n * 2 * out_plane) * 2);
     // the row (z, y) of a (cell row, rb) is wave-uniform: its base stays in SGPRs, the lane adds its x slot and channel half
     const int gx = ox0 - 1 + 2 * jn + px;
@@ -1651,6 +1707,22 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- stage the input tile (slot = voxel * 2 + channel half (group), hi and lo arrays) and the weight fragments ------
+  if constexpr (F32) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const unsigned R = (unsigned)(tid >> 4) + 32u * i;
+      const unsigned ci = v3d::small_div<C9::VZ * C9::VY>(R), rem = R - ci * (C9::VZ * C9::VY);      // rem = vz * VY + vy
+      if (R < 16 * C9::VZ * C9::VY) xf[ci * C9::FS + rem * C9::VX + (tid & 15)] = pref[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NWF; ++i)
+      if (tid + NT * i < C9::WF32 / 4) reinterpret_cast<u32x4*>(wff)[tid + NT * i] = wpref[i];
+    // the idle 17th voxel of every row is read by column 15: keep it finite
+    for (int i = tid; i < 16 * C9::VZ * C9::VY; i += NT) {
+      const unsigned ci = v3d::small_div<C9::VZ * C9::VY>((unsigned)i), rem = (unsigned)i - ci * (C9::VZ * C9::VY);
+      xf[ci * C9::FS + rem * C9::VX + 16] = 0.f;
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const unsigned R = (unsigned)(tid >> 4) + 32u * i;                   // as above
@@ -1667,6 +1739,7 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
     const int slot = ((tid >> 1) * C9::VX + 16) * 2 + (tid & 1);
     xh[slot] = (u32x4){0u, 0u, 0u, 0u};
     xl[slot] = (u32x4){0u, 0u, 0u, 0u};
+  }
   }
   PHASE_MARK(0);
   __syncthreads();
@@ -1688,6 +1761,28 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
       for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
+          if constexpr (F32) {
+            // k slice s, lane group kq: k = 4 s + kq = dx * 16 + ci  =>  dx = s >> 2, ci = 4 (s & 3) + kq
+            float bv[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+              bv[sl] = xf[(4 * (sl & 3) + kq) * C9::FS + ((cz + dz) * C9::VY + (cy + dy)) * C9::VX + jn + (sl >> 2)];
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                if ((pz == 0 || dz == 1) && (py == 0 || dy == 1)) {
+                  const int blk = (pz == 1 ? 2 : dz) * 3 + (py == 1 ? 2 : dy);
+                  const f32x4 a0 = *reinterpret_cast<const f32x4*>(wff + ((blk * 2 + 0) * 64 + lane) * 4);
+                  const f32x4 a1 = *reinterpret_cast<const f32x4*>(wff + ((blk * 2 + 1) * 64 + lane) * 4);
+                  f32x4& c = acc[cbi][pz * 2 + py];
+#pragma unroll
+                  for (int sl = 0; sl < 8; ++sl)
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(sl < 4 ? a0[sl] : a1[sl - 4], bv[sl], c, 0, 0, 0);
+                }
+              }
+            continue;
+          }
           const int slot = (((cz + dz) * C9::VY + (cy + dy)) * C9::VX + jn + (kq >> 1)) * 2 + (kq & 1);
           const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xh[slot]);
           const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xl[slot]);
@@ -1729,11 +1824,17 @@ __global__ __launch_bounds__(512, 4) void conv9_prob_kernel(C9Params p) {
           const int hz = 2 * cz + (rb >> 1), hy = 2 * cy + (rb & 1), hx = 2 * jn + px;
           const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
           const bool inside = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-          const u32x2 sh = skh[cbi][rb], sl = skl[cbi][rb];
-          const float skv[4] = {__uint_as_float(sh.x << 16) + __uint_as_float(sl.x << 16),
-                                __uint_as_float(sh.x & 0xffff0000u) + __uint_as_float(sl.x & 0xffff0000u),
-                                __uint_as_float(sh.y << 16) + __uint_as_float(sl.y << 16),
-                                __uint_as_float(sh.y & 0xffff0000u) + __uint_as_float(sl.y & 0xffff0000u)};
+          float skv[4];
+          if constexpr (F32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) skv[r] = skf[cbi][rb][r];
+          } else {
+            const u32x2 sh = skh[cbi][rb], sl = skl[cbi][rb];
+            skv[0] = __uint_as_float(sh.x << 16) + __uint_as_float(sl.x << 16);
+            skv[1] = __uint_as_float(sh.x & 0xffff0000u) + __uint_as_float(sl.x & 0xffff0000u);
+            skv[2] = __uint_as_float(sh.y << 16) + __uint_as_float(sl.y << 16);
+            skv[3] = __uint_as_float(sh.y & 0xffff0000u) + __uint_as_float(sl.y & 0xffff0000u);
+          }
           float val[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) val[r] = inside ? fmaxf(acc[cbi][rb][r] + bias[r], 0.f) + skv[r] : 0.f;
@@ -2037,7 +2138,7 @@ int launch_deconvg(const char* name, const void* in, const float* wbf, const flo
 struct v3d_costreg_weights {
   int in_channels, base;
   float* dev;                 // one allocation holding everything below
-  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c0f32_ofs, cgbf_ofs[7], dgbf_ofs[2], c9bf_ofs, total;
+  size_t wp_ofs[10], bias_ofs[10], prob_w_ofs, prob_w2_ofs, prob_b_ofs, c0bf_ofs, c0f32_ofs, cgbf_ofs[7], dgbf_ofs[2], c9bf_ofs, c9f32_ofs, total;
 };
 
 extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* bn_w,
@@ -2166,6 +2267,20 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
           for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
         }
       }
+    // fp32 image of the same GEMM for conv9_prob_kernel<true>: [block 9][half 2][lane 64][4]; k slice sl = half * 4 + q of
+    // v_mfma_f32_16x16x4_f32, lane group kq: k = 4 sl + kq = x input * 16 + ci
+    h->c9f32_ofs = reserve((size_t)C9::WF32);
+    float* wf = host.data() + h->c9f32_ofs;
+    for (int blk = 0; blk < 9; ++blk)
+      for (int sl = 0; sl < 8; ++sl)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, px = m >> 3, co = m & 7, kq = lane >> 4, k = 4 * sl + kq, dx = k >> 4, ci = k & 15;
+          const int kz = tap3[blk / 3], ky = tap3[blk % 3];
+          const int kx = px == 0 ? (dx == 0 ? 2 : 0) : (dx == 1 ? 1 : -1);
+          const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
+          wf[(((size_t)blk * 2 + (sl >> 2)) * 64 + lane) * 4 + (sl & 3)] =
+              kx < 0 ? 0.f : conv_w[l][((size_t)ci * 8 + co) * 27 + kz * 9 + ky * 3 + kx] * sc;
+        }
   }
   for (int l = 1; l <= 6; ++l) {
     // split-bf16 images of conv1..conv6 for convg_bf16x2_kernel: [cout group][8-channel chunk][kz, ky][hi, lo][lane 64]
@@ -2623,34 +2738,35 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
     RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   }
-  if (!generic) {
-    // conv9 + skip + prob: the tile kernel below.  V3D_C9_MARCH=1 selects the depth-march experiment of round 4 (conv9z.hip:
-    // correct -- the GPU suite passes on it -- but 0.51 against 0.46 ms per 64 views, see its header; developer A/B)
-    static const bool tile_kernel = getenv("V3D_C9_MARCH") == nullptr;
-    if (!tile_kernel) {
-      if ((rc = v3d::launch_conv9z(F(ws.u8), F(ws.c0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9], h->dev + h->prob_w2_ofs,
-                                   h->dev + h->prob_b_ofs, xreg, n, D, H, W, s)) != V3D_OK) return rc;
-    } else {
+  // conv9 + skip + prob: the tile kernel (split-bf16 or exact fp32 operands).  Developer A/B: V3D_C9_MARCH=1 selects the depth-march
+  // experiment of round 4 for the split path (conv9z.hip: correct -- the GPU suite passes on it -- but 0.51 against 0.46 ms per 64
+  // views, see its header); V3D_C9_F32_UNFUSED=1 the per-layer conv9 kernel + prob_conv_kernel for the exact-fp32 path (rounds 1-3).
+  static const bool tile_kernel = getenv("V3D_C9_MARCH") == nullptr;
+  static const bool f32_unfused = getenv("V3D_C9_F32_UNFUSED") != nullptr;
+  if (!generic && !tile_kernel) {
+    if ((rc = v3d::launch_conv9z(F(ws.u8), F(ws.c0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9], h->dev + h->prob_w2_ofs,
+                                 h->dev + h->prob_b_ofs, xreg, n, D, H, W, s)) != V3D_OK) return rc;
+  } else if (!generic || !f32_unfused) {
     C9Params q;
-    q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + h->c9bf_ofs; q.bias9 = h->dev + h->bias_ofs[9];
+    q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + (generic ? h->c9f32_ofs : h->c9bf_ofs); q.bias9 = h->dev + h->bias_ofs[9];
     q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
     q.n = n; q.D = D; q.H = H; q.W = W;
     q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
     q.zy_order = tile_order(q.ntx, q.nty);
     const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
     V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
-    // 32-bit byte offsets inside one view's tensors (conv0 skip: 2 x 16 bytes per voxel)
+    // 32-bit byte offsets inside one view's tensors (conv0 skip: 2 x 16 bytes per voxel / 8 fp32 planes)
     V3D_REQUIRE((long long)D * H * W < (1ll << 26) && D < (1 << 12) && H < (1 << 12) && W < (1 << 12), V3D_ERR_BAD_SHAPE,
                 "conv9+prob: volume %d x %d x %d too large for 32-bit offsets", D, H, W);
     q.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)q.ntx);
     q.m_t1 = v3d::magic_u32((unsigned long long)blocks / q.ntx + 1, (unsigned)(q.zy_order ? q.ntz : q.nty));
     q.m_t2 = v3d::magic_u32((unsigned long long)blocks / q.ntx / (q.zy_order ? q.ntz : q.nty) + 1, (unsigned)(q.zy_order ? q.nty : q.ntz));
     {
-      v3d::TimedScope ts("costreg_conv9_prob", s);
-      conv9_prob_kernel<<<(unsigned)blocks, 512, 0, s>>>(q);
+      v3d::TimedScope ts(generic ? "costreg_conv9_prob_f32" : "costreg_conv9_prob", s);
+      if (generic) conv9_prob_kernel<true><<<(unsigned)blocks, 512, 0, s>>>(q);
+      else conv9_prob_kernel<false><<<(unsigned)blocks, 512, 0, s>>>(q);
     }
     V3D_CHECK_LAUNCH("conv9_prob_kernel");
-    }
   } else {
     RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
     {
