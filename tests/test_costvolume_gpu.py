@@ -273,7 +273,8 @@ def test_conv9_prob_depth_march_experiment_agrees_with_tile_kernel(cuda):
 
 
 def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
-    """precision='fp32' runs the regulariser on the exact-fp32 per-layer kernels (conv9 and the prob conv unfused);
+    """precision='fp32' runs the regulariser on the exact-fp32 kernels (per-layer kernels for conv0..conv8 behind
+    return_intermediates, conv9 + skip + prob fused on fp32 matrix instructions);
     the default 'split_bf16' chain runs on split-bf16 matrix cores.  Both are within 1e-4 of the oracle, hence within
     2e-4 of each other; the regularised volumes agree to 4e-4 of their range.  The choice is an argument of the C ABI
     (include/v3d.h V3D_PRECISION_*), so both run in this process."""
@@ -307,6 +308,46 @@ def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
     assert not np.array_equal(res['split_bf16'][0], res['fp32'][0])      # the argument really selected another chain
     for pr in res:
         np.testing.assert_allclose(res[pr][0], depth_o, rtol=DEPTH_RTOL, atol=0)
+
+
+def test_exact_fp32_fused_conv9_prob_partial_tiles_vs_oracle(cuda):
+    """The exact-fp32 chain's last kernel (conv9_prob_kernel<true>: transposed conv + conv0 skip + 8 -> 1 prob conv on
+    v_mfma_f32_16x16x4_f32) on a volume that is a multiple of none of its tile sizes (24 x 24 x 40: partial 4 x 8 x 28
+    prob tiles on every axis): regularised volume within 1e-5 of its range of the oracle's, depth within 2e-5; the
+    per-layer exact-fp32 conv9 kernel followed by the torch prob conv gives the same volume to 2e-6 of its range."""
+    syn = v3d('synthetic')
+    img_size, feat_size, plane_size, D = (96, 160), (24, 40), (24, 40), 24
+    R, tv, K = syn.make_cameras(12, img_size, seed=13)
+    feat = syn.make_features(12, 32, *feat_size, seed=13)
+    refs = [4] * 2 + [7] * 3 + [2] * 5
+    srcs = [3, 5] + [6, 8, 9] + [0, 1, 3, 4, 5]
+    edges = torch.tensor([refs, srcs])
+    sd = syn.costregnet_weights(seed=7, sharpen=200.0)
+    d0, dd = 0.5, 0.1
+    with torch.no_grad():
+        depth_o, var_o, reg_o = ocv.mvsnet_depth(feat, R, tv, K, edges, sd, d0, dd, D, img_size, plane_size, pinned=True)
+    net = _net(sd, cuda, img_size)
+    Batch = v3d('batch').Batch
+    b = Batch(None, R, tv, K, None, edges).to(cuda)
+    with torch.no_grad():
+        depth, var, reg = net.cost_volume_depth(feat.to(cuda), b, d0, dd, D, plane_size, return_intermediates=True,
+                                                precision='fp32')
+        # the same layers one by one: conv0..conv8 per-layer exact-fp32 kernels, conv9 per-layer, prob conv in torch
+        c = net.cnn_3d
+        x = var
+        outs = []
+        for l in range(7):
+            x = c.run_layer(l, x, precision='fp32')
+            outs.append(x)
+        u7 = c.run_layer(7, outs[6], outs[4], precision='fp32')
+        u8 = c.run_layer(8, u7, outs[2], precision='fp32')
+        u9 = c.run_layer(9, u8, outs[0], precision='fp32')
+        reg_layers = torch.nn.functional.conv3d(u9.cpu(), sd['prob.weight'], sd['prob.bias'], padding=1)[:, 0]
+    scale = float(reg_o.abs().max())
+    np.testing.assert_allclose(reg.cpu().numpy(), reg_o.numpy(), rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(reg.cpu().numpy(), reg_layers.numpy(), rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(depth.cpu().numpy(), depth_o.numpy(), rtol=2e-5, atol=0)
+    assert float(depth_o.max() - depth_o.min()) > 0.5
 
 
 def test_exact_fp32_chain_through_the_channel_last_volume(cuda):
