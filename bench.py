@@ -63,7 +63,7 @@ def kernel_roofline(name, avg_ms, shape):
         nbytes = 4.0 * (n_img * C * Hf * Wf + n_ref * C * vox)
         a = nbytes / (avg_ms * 1e-3) / 1e9
         return dict(bound='hbm', achieved=a, peak=PEAK_HBM_GBS, unit='GB/s', frac=a / PEAK_HBM_GBS)
-    if name == 'costreg_conv9_prob':
+    if name in ('costreg_conv9_prob', 'costreg_conv9_prob_f32'):
         # fused deconv9 + skip + prob: reads u8 (16 ch at half resolution) and the conv0 skip (8 ch), writes 1 ch
         nbytes = 4.0 * n_ref * (16 * (vox // 8) + 8 * vox + vox)
     elif name.startswith('costreg_conv'):
@@ -77,13 +77,13 @@ def kernel_roofline(name, avg_ms, shape):
             a = flops / (avg_ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             return dict(bound='mfma', achieved=a, peak=peak, unit='TFLOP/s', frac=a / peak)
-        # conv1..conv8: a few hundred MFMAs per workgroup -- bound by moving their activations (4 bytes per value in the
-        # split layout as in fp32): input + output (+ the fp32 copy conv2 / conv4 keep for the skips, + the skip read)
+        # conv1..conv8: a few hundred MFMAs per workgroup -- priced against moving their activations (4 bytes per value in
+        # the split layout as in fp32): input + output (+ the skip read of the transposed convolutions)
         if layer in (7, 8):
             nbytes = 4.0 * n_ref * (ci * work_vox + 2 * co * 8 * work_vox)
         else:
             vox_in = work_vox * (8 if layer in (1, 3, 5) else 1)
-            nbytes = 4.0 * n_ref * (ci * vox_in + co * work_vox * (2 if layer in (2, 4) else 1))
+            nbytes = 4.0 * n_ref * (ci * vox_in + co * work_vox)
     elif name == 'costreg_prob':
         nbytes = 4.0 * n_ref * vox * (8 + 1)
     elif name == 'soft_argmin':
