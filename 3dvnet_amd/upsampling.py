@@ -89,10 +89,15 @@ class PropagationNet(nn.Module):
         assert depth.shape == (B, 1, H, W) and Cf + 1 == self.in_dim, (tuple(depth.shape), tuple(features.shape), self.in_dim)
         handle = self.packed_handle(dev)
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-        ws = self._ws.get('prop', lib.v3d_propagation_workspace_bytes(handle, B, H, W), dev)
-        rc = lib.v3d_propagation_f32(handle, features.data_ptr(), depth.data_ptr(), B, Cf, H, W, out.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
-        _lib.check(rc, 'v3d_propagation_f32')
+        # the conv kernels address a launch's image stack with 32-bit slot offsets (B * H * W < 2^24 slots, checked by the
+        # library): larger stacks go through in pieces -- images are independent, the result is the same bit for bit
+        step = max(1, ((1 << 24) - 1) // (H * W))
+        for s in range(0, B, step):
+            nb = min(step, B - s)
+            ws = self._ws.get('prop', lib.v3d_propagation_workspace_bytes(handle, nb, H, W), dev)
+            rc = lib.v3d_propagation_f32(handle, features[s:s + nb].data_ptr(), depth[s:s + nb].data_ptr(), nb, Cf, H, W,
+                                         out[s:s + nb].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(rc, 'v3d_propagation_f32')
         return out
 
 
