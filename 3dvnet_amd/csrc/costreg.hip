@@ -1956,6 +1956,9 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restric
 #define V3D_L0_CFG kConvS1Pair, 32, 8, 4, 8, 28, 4, 3
 #endif
 typedef ConvCfg<V3D_L0_CFG> L0;
+// CostRegNet(16, 8) (the reference's signature default feat_dim = 16, lightningmodel.py:18): the exact-fp32 conv0 with 16 input
+// channels; the split-bf16 / depth-march conv0 kernels run on the volume zero-extended to 32 channels with zero weights
+typedef ConvCfg<kConvS1Pair, 16, 8, 4, 8, 28, 4, 3> L0_16;
 #ifndef V3D_L1_CFG
 #define V3D_L1_CFG kConvS2, 8, 16, 2, 4, 28, 4
 #endif
@@ -2148,14 +2151,15 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
                                 v3d_costreg_weights** out_handle) {
   V3D_REQUIRE(conv_w && bn_w && bn_b && bn_m && bn_v && prob_w && prob_b && out_handle,
               V3D_ERR_BAD_ARG, "v3d_costreg_pack: null argument");
-  V3D_REQUIRE(in_channels == 32 && base == 8, V3D_ERR_UNSUPPORTED,
-              "v3d_costreg_pack: only CostRegNet(32, 8) is built (got %d, %d)", in_channels, base);
+  V3D_REQUIRE((in_channels == 32 || in_channels == 16) && base == 8, V3D_ERR_UNSUPPORTED,
+              "v3d_costreg_pack: CostRegNet(32, 8) and CostRegNet(16, 8) are built (got %d, %d)", in_channels, base);
   v3d_costreg_weights* h = new v3d_costreg_weights();
   h->in_channels = in_channels; h->base = base;
   std::vector<float> host;
   auto reserve = [&](size_t nfloat) { size_t o = host.size(); host.resize(o + (nfloat + 63) / 64 * 64, 0.f); return o; };
   for (int l = 0; l < 10; ++l) {
-    const LayerDesc& L = kLayers[l];
+    LayerDesc L = kLayers[l];
+    if (l == 0) L.cin = in_channels;
     const bool pair = L.mode == kConvS1Pair;
     const int MB = pair ? 1 : (L.cout + 15) / 16, C4 = L.ck / 4, nchunk = L.cin / L.ck;
     const int KXN = pair ? 4 : 3, NT = 9 * KXN;
@@ -2206,9 +2210,9 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
           for (int e = 0; e < 8; ++e) {
             const int ci = chunk * 8 + e;
             float v = 0.f;
-            if (kx >= 0 && kx <= 2) {
+            if (kx >= 0 && kx <= 2 && ci < in_channels) {        // (16 input channels: chunks 2, 3 carry zero weights)
               const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
-              v = conv_w[l][((size_t)co * 32 + ci) * 27 + kzy * 3 + kx] * sc;
+              v = conv_w[l][((size_t)co * in_channels + ci) * 27 + kzy * 3 + kx] * sc;
             }
             hi[e] = rne(v);
             lo[e] = rne(v - up(hi[e]));
@@ -2232,9 +2236,9 @@ extern "C" int v3d_costreg_pack(const float* const* conv_w, const float* const* 
           for (int lane = 0; lane < 64; ++lane) {
             const int row = lane & 15, kxp = lane >> 4, sx = row >> 3, co = row & 7, kx = kxp - sx, ci = chunk * 8 + e;
             float v = 0.f;
-            if (kx >= 0 && kx <= 2) {
+            if (kx >= 0 && kx <= 2 && ci < in_channels) {
               const float sc = bn_w[l][co] / sqrtf(bn_v[l][co] + eps);
-              v = conv_w[l][((size_t)co * 32 + ci) * 27 + kzy * 3 + kx] * sc;
+              v = conv_w[l][((size_t)co * in_channels + ci) * 27 + kzy * 3 + kx] * sc;
             }
             wf[(((size_t)chunk * 9 + kzy) * 8 + e) * 64 + lane] = v;
           }
@@ -2379,6 +2383,12 @@ static int run_layer(const v3d_costreg_weights* h, int layer, const float* in, c
   const float* bias = h->dev + h->bias_ofs[layer];
   switch (layer) {
     case 0: {
+      if (h->in_channels == 16) {
+        V3D_REQUIRE(precision == V3D_PRECISION_FP32, V3D_ERR_UNSUPPORTED,
+                    "costreg: the per-layer conv0 of CostRegNet(16, 8) is built for V3D_PRECISION_FP32 only (the chain entry points "
+                    "cover both precisions)");
+        return launch_conv<L0_16>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
+      }
       if (precision == V3D_PRECISION_FP32) return launch_conv<L0>("costreg_conv0", in, wp, bias, skip, out, n, Di, Hi, Wi, s);
       return launch_conv0_bf16(false, false, in, h->dev + h->c0bf_ofs, bias, skip, out, n, Di, Hi, Wi, s);
     }
@@ -2658,6 +2668,8 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
   const bool generic = precision == V3D_PRECISION_FP32;
   const bool split_in = in_layout == 1, cl8_in = in_layout == 2;
   V3D_REQUIRE(!generic || !split_in, V3D_ERR_UNSUPPORTED, "V3D_PRECISION_FP32 needs an fp32 variance volume");
+  V3D_REQUIRE(h->in_channels == 32 || in_layout == 0, V3D_ERR_UNSUPPORTED,
+              "CostRegNet(16, 8) takes the variance volume in the reference layout (the hand-off formats are defined for 32 channels)");
   V3D_REQUIRE(generic || !cl8_in, V3D_ERR_UNSUPPORTED, "the fp32 channel-last volume is the input of V3D_PRECISION_FP32");
   if (generic) {
     if (cl8_in) {      // conv0 as a depth march on exact-fp32 matrix instructions (conv0z.hip)
@@ -2675,9 +2687,12 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     if (split_in) {
       if ((rc = v3d::launch_conv0z(false, var, h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0), n, D, H, W, s)) != V3D_OK) return rc;
     } else {
-      const size_t V0 = (size_t)D * H * W, total = 4 * V0;
+      // (CostRegNet(16, 8): channel groups 2, 3 of the encoded view are zeros, once -- their conv0 weights are zero as well)
+      const int cin = h->in_channels, ngrp = cin / 8;
+      const size_t V0 = (size_t)D * H * W, total = (size_t)ngrp * V0;
+      if (ngrp < 4) V3D_CHECK_HIP(hipMemsetAsync((char*)F(ws.enc) + (size_t)ngrp * 2 * V0 * 16, 0, (size_t)(4 - ngrp) * 2 * V0 * 16, s));
       for (int i = 0; i < n; ++i) {
-        encode_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(var + (size_t)i * 32 * V0, (u32x4*)F(ws.enc), 32, V0, total);
+        encode_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(var + (size_t)i * cin * V0, (u32x4*)F(ws.enc), cin, V0, total);
         V3D_CHECK_LAUNCH("encode_split_kernel");
         if ((rc = v3d::launch_conv0z(false, F(ws.enc), h->dev + h->c0bf_ofs, h->dev + h->bias_ofs[0], F(ws.c0) + (size_t)i * 8 * V0, 1, D, H,
                                      W, s)) != V3D_OK) return rc;

@@ -55,6 +55,7 @@ struct GemmParams {
   const float* wp;               // packed [seg][KP/32][8][MB][64]
   const float* bias;             // [N] or null
   const float* gn_w; const float* gn_b; float gn_eps;   // row GroupNorm over 16-channel groups (null = off)
+  int gn8;                                              // ... over 8-channel groups instead (use_gn == 8)
   const float* residual; int ld_res;
   int relu_out;
   float* pool; const int* pool_idx; int ld_pool;        // scatter-max target (null = off)
@@ -90,15 +91,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[nb][mw][r] + ((p.bias && co0 + r < p.N) ? p.bias[co0 + r] : 0.f);
       if (p.gn_w) {
-        // GroupNorm over the 16 channels of this block for row m: 4 registers x 4 lane quarters
+        // GroupNorm over the 16 channels of this block for row m: 4 registers x 4 lane quarters (8-channel groups --
+        // SparseUNet(dims[0] = 32, 4 groups), the reference's feat_dim = 16 -- are the lane quarter pairs (0, 1) and (2, 3))
+        const float ginv = p.gn8 ? 1.f / 8.f : 1.f / 16.f;
         float sum = v[0] + v[1] + v[2] + v[3];
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.f / 16.f);
+        sum += __shfl_xor(sum, 16);
+        if (!p.gn8) sum += __shfl_xor(sum, 32);
+        const float mean = sum * ginv;
         float sq = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sq += (v[r] - mean) * (v[r] - mean);
-        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-        const float rstd = 1.f / sqrtf(sq * (1.f / 16.f) + p.gn_eps);      // biased variance (torch GN)
+        sq += __shfl_xor(sq, 16);
+        if (!p.gn8) sq += __shfl_xor(sq, 32);
+        const float rstd = 1.f / sqrtf(sq * ginv + p.gn_eps);      // biased variance (torch GN)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (co0 + r < p.N) v[r] = (v[r] - mean) * rstd * p.gn_w[co0 + r] + p.gn_b[co0 + r];
@@ -736,6 +741,8 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
               "v3d_gemm_gather_f32: unknown precision %d", precision);
   V3D_REQUIRE(M >= 0, V3D_ERR_BAD_SHAPE, "v3d_gemm_gather_f32: M < 0");
+  V3D_REQUIRE(use_gn == 0 || use_gn == 1 || use_gn == 8 || use_gn == 16, V3D_ERR_BAD_ARG,
+              "v3d_gemm_gather_f32: use_gn = %d (0 off, 1 or 16: 16-channel groups, 8: 8-channel groups)", use_gn);
   V3D_REQUIRE(!use_gn || (h->has_gn && h->N % 16 == 0), V3D_ERR_BAD_ARG,
               "v3d_gemm_gather_f32: GroupNorm requested but weights carry no affine / N %% 16 != 0");
   V3D_REQUIRE(!pool || pool_idx, V3D_ERR_BAD_ARG, "v3d_gemm_gather_f32: pool without pool_idx");
@@ -752,7 +759,7 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   p.group_len = group_len; p.relu_in = relu_in;
   p.wp = h->dev; p.bias = h->has_bias ? h->dev + h->bias_ofs : nullptr;
   p.gn_w = use_gn ? h->dev + h->gnw_ofs : nullptr; p.gn_b = use_gn ? h->dev + h->gnb_ofs : nullptr;
-  p.gn_eps = gn_eps;
+  p.gn_eps = gn_eps; p.gn8 = use_gn == 8;
   p.residual = residual; p.ld_res = ld_res; p.relu_out = relu_out;
   p.pool = pool; p.pool_idx = pool_idx; p.ld_pool = ld_pool;
   p.out = out; p.ld_out = ld_out;

@@ -52,18 +52,17 @@ class PL3DVNet(nn.Module):
                  feat_shrinker=None, precision='split_bf16', backbone=False):
         """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20), except the DEFAULT of ``feat_dim``: the
         reference's signature says 16, but its config (mv3d/config.py:42) and the hparams of every released checkpoint say
-        32, the only width the HIP kernels are specialised for -- so ``PL3DVNet(depth_train, depth_test, edge_len)`` builds
-        the network the reference actually ships, and an explicit ``feat_dim=16`` raises.  Extra keywords:
+        32, the width the fast kernels are specialised for -- so ``PL3DVNet(depth_train, depth_test, edge_len)`` builds
+        the network the reference actually ships.  ``feat_dim=16`` runs too (round 4): the cost volume through the
+        reference-layout entry points (conv0 on the volume zero-extended to 32 channels), GroupNorm over 8-channel groups on
+        the first U-Net level, the unfused hypothesis decoder.  Extra keywords:
         ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
         ('split_bf16' | 'fp32') selects the MFMA operand precision of every matrix-core kernel (include/v3d.h)."""
         super().__init__()
-        if feat_dim != 32:
-            # the reference's signature default is 16, but its config (mv3d/config.py:42) and every released checkpoint use
-            # 32; the HIP kernels are specialised for that: the sparse U-Net's fused GroupNorm epilogue needs 16-channel
-            # groups (2*feat_dim / 4 groups), the split variance hand-off and the plane-reuse warp kernel need C = 32
-            raise ValueError('PL3DVNet: feat_dim=%d is not supported by the HIP path (only feat_dim=32, the value of '
-                             'mv3d/config.py:42)' % feat_dim)
+        if feat_dim not in (16, 32):
+            raise ValueError('PL3DVNet: feat_dim=%d is not supported by the HIP path (16 -- the reference\'s signature default -- '
+                             'and 32, the value of mv3d/config.py:42 and of the released checkpoints)' % feat_dim)
         if backbone and feat_extractor is None:
             from .backbone import build_backbone
             feat_extractor, feat_shrinker = build_backbone(feat_dim)

@@ -27,8 +27,10 @@ class PackedGemm:
     """Device-resident packed weights of one gather-GEMM layer (v3d_gemm_pack)."""
 
     def __init__(self, w, stride_seg, stride_co, stride_k, n_seg, N, K, scale=None, bias=None,
-                 gn_w=None, gn_b=None, device=None):
+                 gn_w=None, gn_b=None, device=None, gn_group=16):
         lib = _lib.load()
+        assert gn_group in (8, 16), 'the GroupNorm epilogue handles 8- and 16-channel groups'
+        self.gn_group = gn_group
         keep = [_host_f32(w)] + [None if x is None else _host_f32(x) for x in (scale, bias, gn_w, gn_b)]
         ptrs = [None if a is None else a.ctypes.data_as(_lib.c_float_p) for a in keep]
         self.handle = ctypes.c_void_p()
@@ -77,7 +79,7 @@ class PackedGemm:
         elif out is not None and out is not False:
             y = out
         rc = lib.v3d_gemm_gather_f32(
-            self.handle, M, src_arr, idx_arr, ld_arr, group_len, int(relu_in), int(use_gn), gn_eps,
+            self.handle, M, src_arr, idx_arr, ld_arr, group_len, int(relu_in), self.gn_group if use_gn else 0, gn_eps,
             _lib.ptr(residual), residual.shape[-1] if residual is not None else 0, int(relu_out),
             _lib.ptr(pool), _lib.ptr(pool_idx), pool.shape[-1] if pool is not None else 0,
             _lib.ptr(y), y.stride(0) if y is not None else 0, _lib.precision_code(precision), _lib.stream_ptr(dev))
@@ -237,8 +239,8 @@ class SparseUNet(nn.Module):
         super().__init__()
         _lib.precision_code(precision)
         self.precision = precision
-        assert all(d // g == 16 for d, g in zip(dims, n_groups)), \
-            'the fused GroupNorm epilogue handles 16-channel groups (reference: 64/4, 128/8)'
+        assert all(d % g == 0 and d // g in (8, 16) for d, g in zip(dims, n_groups)), \
+            'the fused GroupNorm epilogue handles 8- and 16-channel groups (reference: 64/4, 128/8; 32/4 at feat_dim 16)'
         self.dims, self.n_groups, self.n_res = tuple(dims), tuple(n_groups), tuple(n_res)
         self.res_down = nn.ModuleList([nn.Sequential(*[SparseResidual3d(dims[i], "gn", n_groups[i])
                                                        for _ in range(n)]) for i, n in enumerate(n_res)])
@@ -259,7 +261,7 @@ class SparseUNet(nn.Module):
     def _pack3(self, conv, norm):
         _, ci, co = conv.kernel.shape
         return PackedGemm(conv.kernel, ci * co, 1, co, 27, co, ci, gn_w=norm.gn.weight, gn_b=norm.gn.bias,
-                          device=self._dev)
+                          device=self._dev, gn_group=norm.gn.num_channels // norm.gn.num_groups)
 
     def _build(self):
         g = {}
@@ -274,7 +276,8 @@ class SparseUNet(nn.Module):
         for i, seq in enumerate(self.feat_adj):
             c2, co = seq[0].kernel.shape
             g[('feat_adj', i)] = PackedGemm(seq[0].kernel, (c2 // 2) * co, 1, co, 2, co, c2 // 2,
-                                            gn_w=seq[1].gn.weight, gn_b=seq[1].gn.bias, device=self._dev)
+                                            gn_w=seq[1].gn.weight, gn_b=seq[1].gn.bias, device=self._dev,
+                                            gn_group=seq[1].gn.num_channels // seq[1].gn.num_groups)
         return g
 
     # -- execution ----------------------------------------------------------------------------------

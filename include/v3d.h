@@ -223,8 +223,8 @@ int v3d_backproject_variance_f32(const float* depth, const float* feat, const fl
  * v3d_gemm_gather_f32: seg_src/seg_idx/seg_ld are HOST arrays of n_seg device pointers / strides;
  *   seg_idx[s] NULL = identity row map, entry -1 = zero row; group_len > 0 selects the conv1d row map
  *   (segment s reads row m + s - n_seg/2 inside each group of group_len rows; seg_idx ignored);
- *   relu_in: ReLU applied to gathered inputs; use_gn: per-row GroupNorm over 16-channel groups
- *   (eps gn_eps) before the optional residual add and ReLU; pool/pool_idx: scatter-max of the result
+ *   relu_in: ReLU applied to gathered inputs; use_gn: per-row GroupNorm (1 or 16: over 16-channel groups, 8: over 8-channel
+ *   groups; eps gn_eps) before the optional residual add and ReLU; pool/pool_idx: scatter-max of the result
  *   into pool[pool_idx[m], :] (pre-filled with -inf); out may be NULL.
  * ------------------------------------------------------------------------------------------ */
 typedef struct v3d_gemm_weights v3d_gemm_weights;

@@ -230,6 +230,36 @@ def test_hip_driver_matches_oracle_driver(cuda):
     assert float(m['abs_rel']) < 2e-5 and float(m['d_125']) == pytest.approx(1.0) and float(m['rmse']) < 1e-4
 
 
+@pytest.mark.gpu
+def test_hip_driver_feat_dim_16_matches_oracle_driver(cuda):
+    """The reference's signature default feat_dim = 16 (lightningmodel.py:18): CostRegNet(16, 8) -- conv0 on the volume
+    zero-extended to 32 channels (split-bf16) / the 16-channel exact-fp32 conv0 --, PointNet(64, 32, 19), SparseUNet((32, 128,
+    128)) with GroupNorm over 8-channel groups on its first level, the unfused HypothesisDecoder(304): the whole scene driver
+    against the oracle-backed driver, both operand precisions."""
+    lm, drv, syn = v3d('lightningmodel'), v3d('eval_3dvnet'), v3d('synthetic')
+    Batch = v3d('batch').Batch
+    cr = syn.costregnet_weights(in_channels=16, seed=0, sharpen=200.0)
+    pn = syn.pointnet_weights(hidden=64, out_dim=32, in_dim=19, seed=1)
+    un = syn.sparse_unet_weights(dims=(32, 128, 128), seed=2)
+    dec = syn.decoder_weights(in_dim=304, seed=3, sharpen=50.0)
+
+    def scene():
+        edges, n_img = syn.make_edges(5, 1, 1)
+        rot, tv, K = syn.make_cameras(n_img, IMG, seed=43)
+        b = Batch(None, rot, tv, K, None, edges)
+        b.features_quarter = syn.make_features(n_img, 16, *FEAT, seed=43)
+        return b
+    ref = drv.process_scene(scene(), OracleNet(cr, pn, un, dec, IMG, 0.16), 1, torch.device('cpu'), CFG, OFFSETS, 18, 16)
+    for precision, rtol in (('split_bf16', 1e-4), ('fp32', 2e-5)):
+        net = lm.PL3DVNet(None, CFG, 0.16, feat_dim=16, img_size=IMG, precision=precision).eval()
+        net.mvsnet.cnn_3d.load_state_dict(cr, strict=False)
+        net.pointnet.load_state_dict(pn)
+        net.sparse_conv.load_state_dict(un)
+        net.decoder.load_state_dict(dec, strict=False)
+        out = drv.process_scene(scene(), net.to(cuda), 1, cuda, CFG, OFFSETS, 2, 3)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=0)
+
+
 def test_driver_rejects_an_edge_list_that_breaks_the_dataset_layout():
     """The driver addresses reference views as images k .. k + n - 1 (eval-3dvnet.py:42-52) and builds its device-side edge
     tables from a chunk's reference count: an edge list in which a reference view has no edges would be processed with the

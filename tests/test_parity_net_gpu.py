@@ -214,6 +214,15 @@ def test_hip_propagation_net_matches_reference_golden_and_oracle_chain(cuda):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=0)
     assert out.shape == (5, 60, 76)
     assert float((ref - F.interpolate(depth.unsqueeze(1), (60, 76), mode='nearest')[:, 0]).abs().max()) > 1e-3    # it did something
+    # feat_dim = 16 (the reference's signature default): 17 guide + depth channels
+    sd17 = syn.propagation_weights(17, 32, 8)
+    n17 = up.PropagationNet(17, 32).eval()
+    n17.load_state_dict(sd17, strict=False)
+    g17, d17 = torch.rand((3, 16, 30, 38), generator=gen), 1 + torch.rand((3, 1, 30, 38), generator=gen)
+    with torch.no_grad():
+        o17 = n17.to(cuda)(g17.to(cuda), d17.to(cuda))
+        r17 = osc.propagation_net(g17, d17, sd17)
+    np.testing.assert_allclose(o17.cpu().numpy(), r17.numpy(), rtol=2e-5, atol=0)
 
 
 # ---- cached packed weights -----------------------------------------------------------------------------------------------
