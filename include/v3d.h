@@ -144,7 +144,10 @@ int v3d_psv_variance_cl8(const float* feat, const float* K, const float* R, cons
  * [Ci,Co,3,3,3], *.bn.{weight,bias,running_mean,running_var}, prob.weight [1,base,3,3,3],
  * prob.bias [1]), folds eval-mode BatchNorm (eps) into the convolutions, re-orders the weights
  * into MFMA fragment order and uploads them.  Order of the 10 conv/deconv layers in the arrays:
- * conv0..conv9.
+ * conv0..conv9.  Built: (in_channels, base_channels) = (32, 8) -- mv3d/config.py:42 -- and (16, 8), the
+ * reference's signature default feat_dim (lightningmodel.py:18); a 16-channel net takes its variance
+ * volume through v3d_costreg_depth_f32 only (the split / channel-last hand-off formats are defined
+ * for 32 channels).
  * ------------------------------------------------------------------------------------------ */
 typedef struct v3d_costreg_weights v3d_costreg_weights;
 
