@@ -167,9 +167,11 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             all_depth = init_depth_override[r0:r1].to(device=device, dtype=torch.float32).clone()
 
         # ---- stage 2: volumetric refinement (:65-99) ------------------------------------------------
-        rot = batch.rotmats[r0:r1 + halo].to(device)
-        tv = batch.tvecs[r0:r1 + halo].to(device)
-        K = batch.K[r0:r1 + halo].to(device)
+        # (contiguous once: the per-sweep calls below take leading-dimension slices, which then need no copy -- a rotation
+        # stack that arrives as a transposed view was re-packed by every one of the 24 point-flow calls of a scene)
+        rot = batch.rotmats[r0:r1 + halo].to(device).contiguous()
+        tv = batch.tvecs[r0:r1 + halo].to(device).contiguous()
+        K = batch.K[r0:r1 + halo].to(device).contiguous()
         edges_local_host = utils.slice_edges(scene_edges, r0 + k, r1 + k, 0) - r0
         edges_local = edges_local_host.to(device)
         depth_batch = torch.zeros(n_local, dtype=torch.long, device=device)
@@ -197,10 +199,11 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
             for offset in offsets:
                 for b0, b1, e, csr in chunks:
                     kw = {} if csr is None else {'csr': csr}
-                    all_depth[b0:b1] += net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
-                                                          feats_local[b0:b1 + halo], rot[b0:b1 + halo],
-                                                          tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3,
-                                                          **kw)
+                    # (`all_depth[b0:b1] += ...` is add_ on the view followed by a copy of the view onto itself)
+                    all_depth[b0:b1].add_(net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
+                                                            feats_local[b0:b1 + halo], rot[b0:b1 + halo],
+                                                            tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3,
+                                                            **kw))
         if hints:
             unet.flush_checks()             # hash-table range checks of both scene models: one wait here, not two in between
         if upsample:

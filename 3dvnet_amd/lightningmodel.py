@@ -84,6 +84,7 @@ class PL3DVNet(nn.Module):
         self.refine_full = PropagationNet(in_dim=3 + 1, h_dim=32)
         self._ws = _Workspace()
         self._offset_vals = {}
+        self._pts_batch = {}
 
     def make_initial_depth_predictions(self, batch, depth_config):
         """lightningmodel.py:124-130."""
@@ -144,7 +145,17 @@ class PL3DVNet(nn.Module):
         pts_hyp, pts_feat = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
                                                  self.hparams.img_size, offset=offset, n=n,
                                                  workspace=self._ws, csr=csr)
-        pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
+        # one batch index per point (lightningmodel.py:193-194); the scene driver sweeps the same chunks again and again: the
+        # expanded tensor of the last few (storage, version) pairs is kept instead of being rebuilt per call
+        pkey = (depth_batch.data_ptr(), depth_batch._version, n_imgs, n_pts, str(depth_batch.device))
+        pts_batch = self._pts_batch.get(pkey)
+        if pts_batch is None:
+            if len(self._pts_batch) >= 16:
+                self._pts_batch.clear()
+            pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
+            self._pts_batch[pkey] = (pts_batch, depth_batch)       # (the source is kept alive: its address is the key)
+        else:
+            pts_batch = pts_batch[0]
         key = (float(offset), int(n), str(depth_pred.device))
         if key not in self._offset_vals:      # torch.linspace on the CPU then moved, like lightningmodel.py:238-240
             self._offset_vals[key] = torch.linspace(-n * offset, n * offset, 2 * n + 1).to(depth_pred.device)

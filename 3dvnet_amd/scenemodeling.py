@@ -368,6 +368,13 @@ class SparseUNet(nn.Module):
             first = torch.full((n_batches,), batch.shape[0], dtype=rows.dtype, device=batch.device) \
                 .scatter_reduce_(0, batch.to(rows.dtype), rows, 'amin')
         pts_min = pts[first] - idx[first] * res                                        # [n_batches, 3]
+        # One batch element: x_pts is monotone in x_idx per axis (fl(fl(i * res) + pts_min), res > 0), so the minimum of a level's
+        # x_pts is that formula at the level's minimum index, and a level of stride s holds floor(c / s) * s of the finest
+        # coordinates c: ONE integer reduction over the finest level instead of a float reduction per level
+        idx_min = None
+        if n_batches == 1:
+            fine = min((lv for lv, _ in out), key=lambda l: l.stride)
+            idx_min = fine.coords[:, 1:].amin(dim=0, keepdim=True)                      # [1, 3] int32
         for lv, xf in out:
             x_idx = lv.coords[:, 1:].type_as(batch)
             x_batch = lv.coords[:, 0].type_as(batch)
@@ -376,7 +383,8 @@ class SparseUNet(nn.Module):
             # scatter(x.pts, x.batch, reduce='min') of the interpolation (refinement.py:33), here where the number of batch
             # elements is known: the decoder would have to read it back from the device in front of its first launch
             if n_batches == 1:
-                min_pts = x_pts.amin(dim=0, keepdim=True)
+                lv_min = torch.div(idx_min, lv.stride, rounding_mode='floor') * lv.stride if lv.stride != fine.stride else idx_min
+                min_pts = lv_min.type_as(batch) * res + pts_min[0:1]
             else:
                 sel = x_batch[None, :, None] == torch.arange(n_batches, device=x_batch.device)[:, None, None]
                 min_pts = torch.where(sel, x_pts[None], x_pts.new_full((), float('inf'))).amin(dim=1)
