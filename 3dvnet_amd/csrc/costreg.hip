@@ -2716,11 +2716,18 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     auto W_ = [&](int l) { return h->dev + h->cgbf_ofs[l]; };
     auto B_ = [&](int l) { return h->dev + h->bias_ofs[l]; };
     V3D_STOP(0);
+    // conv1 + conv2: the fused depth march of conv12z.hip (conv1's output never leaves LDS: 0.27 ms per 64 cfg2 views against 0.176 +
+    // 0.146 for the two tile kernels, which remain behind V3D_C12_MARCH=0 -- developer A/B -- and the per-layer entry points)
+    static const bool c12_march = V3D_SKIP_SPLIT && !(getenv("V3D_C12_MARCH") && atoi(getenv("V3D_C12_MARCH")) == 0);
+    if (c12_march) {
+      if ((rc = v3d::launch_conv12z(F(ws.c0), W_(1), W_(2), B_(1), B_(2), c2s, n, D, H, W, s)) != V3D_OK) return rc;
+    } else {
     if ((rc = launch_convg<CG<8, 16, 2, 14, kOutSplit>>("costreg_conv1", F(ws.c0), W_(1), B_(1), nullptr, F(ws.c1), n, D, H, W,
                                                         s)) != V3D_OK) return rc;
     V3D_STOP(1);
     if ((rc = launch_convg<CG<16, 16, 1, 14, V3D_SKIP_OUT>>("costreg_conv2", F(ws.c1), W_(2), B_(2), F(ws.c2), c2s, n,
                                                             D / 2, H / 2, W / 2, s)) != V3D_OK) return rc;
+    }
     V3D_STOP(2);
     if ((rc = launch_convg<CG<16, 32, 2, 14, kOutSplit>>("costreg_conv3", c2s, W_(3), B_(3), nullptr, F(ws.c3), n, D / 2, H / 2,
                                                          W / 2, s)) != V3D_OK) return rc;

@@ -215,6 +215,11 @@ int launch_conv0z(bool f32, const void* in, const float* wimg, const float* bias
 int launch_conv9z(const void* u8_split, const void* c0_split, const float* wbf, const float* bias9, const float* wprob,
                   const float* bprob, float* out, int n, int D, int H, int W, hipStream_t s);
 
+// conv1 + conv2 of CostRegNet as one depth march (conv12z.hip, experiment): conv0 output [n][hi, lo][D][H][W] (split layout)
+// -> conv2 output [n][2 groups][hi, lo][D2][H2][W2]; `w1` / `w2` = the split-bf16 images of conv1 / conv2 (costreg.hip, cgbf)
+int launch_conv12z(const void* c0_split, const float* w1, const float* w2, const float* b1, const float* b2, void* out_split,
+                   int n, int D, int H, int W, hipStream_t s);
+
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);
 

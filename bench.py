@@ -66,6 +66,9 @@ def kernel_roofline(name, avg_ms, shape):
     if name in ('costreg_conv9_prob', 'costreg_conv9_prob_f32'):
         # fused deconv9 + skip + prob: reads u8 (16 ch at half resolution) and the conv0 skip (8 ch), writes 1 ch
         nbytes = 4.0 * n_ref * (16 * (vox // 8) + 8 * vox + vox)
+    elif name == 'costreg_conv12':
+        # conv1 + conv2 fused (conv12z.hip): reads conv0's 8 channels at full resolution, writes conv2's 16 at half resolution
+        nbytes = 4.0 * n_ref * (8 * vox + 16 * (vox // 8))
     elif name.startswith('costreg_conv'):
         layer = int(name[len('costreg_conv'):])
         ci, co, div = COSTREG_LAYERS[layer]

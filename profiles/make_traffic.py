@@ -20,7 +20,7 @@ import sys
 NAMES = [('psv_variance_window_kernel<true, false>', 'psv_variance'), ('psv_variance_window_kernel<true, true>', 'psv_variance_cl8'),
          ('psv_variance_window_kernel<true>', 'psv_variance'), ('psv_variance_reuse_kernel<true>', 'psv_variance'),
          ('psv_variance_window_kernel', 'psv_variance_f32_out'), ('psv_variance_reuse_kernel', 'psv_variance_f32_out'), ('psv_variance_kernel', 'psv_variance'),
-         ('conv0z_kernel<false>', 'costreg_conv0'), ('conv0z_kernel<true>', 'costreg_conv0_f32'), ('conv0_bf16x2_kernel', 'costreg_conv0'), ('conv9_prob_kernel<true>', 'costreg_conv9_prob_f32'), ('conv9_prob_kernel', 'costreg_conv9_prob'),
+         ('conv0z_kernel<false>', 'costreg_conv0'), ('conv0z_kernel<true>', 'costreg_conv0_f32'), ('conv0_bf16x2_kernel', 'costreg_conv0'), ('conv12z_kernel', 'costreg_conv12'), ('conv9_prob_kernel<true>', 'costreg_conv9_prob_f32'), ('conv9_prob_kernel', 'costreg_conv9_prob'),
          ('convg_bf16x2_kernel<CG<8, 16', 'costreg_conv1'), ('convg_bf16x2_kernel<CG<16, 16', 'costreg_conv2'),
          ('convg_bf16x2_kernel<CG<16, 32', 'costreg_conv3'), ('convg_bf16x2_kernel<CG<32, 32', 'costreg_conv4'),
          ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin'),

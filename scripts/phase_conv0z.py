@@ -17,7 +17,7 @@ NAMES = ['M: wait at B', "M: MFMA phase (B', stores inside)", "H: wait at B'", '
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--refs', type=int, default=64)
-    ap.add_argument('--kernel', default='conv0z', choices=('conv0z', 'conv9z'))
+    ap.add_argument('--kernel', default='conv0z', choices=('conv0z', 'conv9z', 'conv12z'))
     args = ap.parse_args()
     libm = importlib.import_module('3dvnet_amd._lib')
     if os.environ.get('V3D_LIB_OVERRIDE'):
@@ -45,7 +45,8 @@ def main():
     fn(buf, 1024)
     tot = sum(buf)
     print(args.kernel + ' phases (cycles of wave 0, %d workgroups): total %.3e' % (256, tot))
-    names = NAMES if args.kernel == 'conv0z' else ['P: wait vmcnt', 'P: wait at B', 'P: issue DMA', 'P: MFMA', 'P: emit u9', 'C: prob conv + stores', 'C: wait at B', 'C: task tail']
+    names12 = ['1: wait at B (+ loop tail)', '1: odd plane MFMAs', '1: park + even plane', "1: wait at B'", "2: B .. arrival at B' (MFMAs)", "2: wait at B' (red stores, B wait in the next)", "H: B .. arrival at B' (stores, DMA issue, take)", "H: wait at B', vmcnt, B"]
+    names = NAMES if args.kernel == 'conv0z' else names12 if args.kernel == 'conv12z' else ['P: wait vmcnt', 'P: wait at B', 'P: issue DMA', 'P: MFMA', 'P: emit u9', 'C: prob conv + stores', 'C: wait at B', 'C: task tail']
     for n, v in zip(names, buf):
         print('  %-34s %6.1f %%  %.3e' % (n, 100.0 * v / max(tot, 1), v))
 
