@@ -272,6 +272,31 @@ def test_conv9_prob_depth_march_experiment_agrees_with_tile_kernel(cuda):
     assert str(res[0]['kernel']) == 'conv9_prob_kernel' and str(res[1]['kernel']) == 'conv9z_kernel'
 
 
+def test_conv1_conv2_depth_march_agrees_with_tile_kernels(cuda):
+    """csrc/conv12z.hip (the default: conv1 + conv2 as one depth march, conv1's output never leaves LDS) against the two tile
+    kernels it replaces (V3D_C12_MARCH=0): the same products, conv2's two input-channel chunks summed in another order --
+    regularised volume within 5e-6 of its range (measured 2.1e-6), depth within 1e-5, on a cfg1 batch and on a volume with partial tiles and
+    ragged edges.  The switch is read once per process: each variant runs in its own interpreter (scripts/c9_dump.py)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for extra in ({}, {'V3D_C12_MARCH': '0'}):
+            f = os.path.join(td, 'c12_%d.npz' % len(res))
+            r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'c9_dump.py'), f], env=dict(os.environ, **extra),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(f)))
+    for k in ('a', 'b'):
+        scale = float(np.abs(res[1]['reg_' + k]).max())
+        np.testing.assert_allclose(res[0]['reg_' + k], res[1]['reg_' + k], rtol=0, atol=5e-6 * scale)
+        np.testing.assert_allclose(res[0]['depth_' + k], res[1]['depth_' + k], rtol=1e-5, atol=0)
+        assert not np.array_equal(res[0]['reg_' + k], res[1]['reg_' + k])          # another kernel really ran
+
+
 def test_fp32_chain_agrees_with_split_bf16_chain(cuda):
     """precision='fp32' runs the regulariser on the exact-fp32 kernels (per-layer kernels for conv0..conv8 behind
     return_intermediates, conv9 + skip + prob fused on fp32 matrix instructions);
