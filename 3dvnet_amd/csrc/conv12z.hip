@@ -22,7 +22,8 @@
 // in lockstep pay the maximum at every barrier.  What did not move it: the park inside the conv1 waves (as a phase 0.270,
 // scheduled between the even plane's MFMAs 0.264 with spills), the park as a helper phase between B' and B (0.275), two conv1 waves
 // per SIMD with two helper waves (0.350: the helpers' 26 DMA issues per step become the longest role), de-interleaved tile
-// columns (the stride-2 reads were not the limiter), prefetch distance 1 / 3, wave priorities, more z segments.
+// columns (the stride-2 reads were not the limiter), prefetch distance 1 / 3, wave priorities, more z segments, an LDS counter
+// in place of the second barrier (V3D_C12_FLAGS: 0.293).
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -51,7 +52,7 @@ struct C12 {
   static constexpr int BUF1 = 4 * HL1;                         // [chunk 2][hi, lo]
   static constexpr int RED = 2 * NB2 * 1024;                   // [chunk][block][lane] f32x4
   static constexpr int RAW = NB1 * 1024;                       // a finished conv1 plane's accumulators on their way to the park
-  static constexpr int LDS_BYTES = R0 * PLANE0 + 2 * BUF1 + RED + RAW;
+  static constexpr int LDS_BYTES = R0 * PLANE0 + 2 * BUF1 + RED + RAW + 16;     // + the "taken" counter
   static_assert(TH * TW % 16 == 0 && NB1 == 12 && NSLOT0 <= NPIECE * 64 && 2 * NPIECE == 26 && LDS_BYTES <= 160 * 1024, "geometry");
 };
 
@@ -99,6 +100,17 @@ __device__ unsigned long long g_c12_phase[8 * 1024];
 #ifndef V3D_C12_ABLATE
 #define V3D_C12_ABLATE 0     // developer ablations: 1 no conv2 MFMAs, 2 no conv1 MFMAs, 3 no DMA, 4 no conv2 epilogue, 5 no conv1 park
 #endif
+#ifndef V3D_C12_FLAGS
+#define V3D_C12_FLAGS 0      // developer A/B, 1: the second barrier of a step (B': "the helpers have read `raw` and `red`") as an LDS
+#endif                       // counter the writers poll instead of a workgroup barrier -- correct, and SLOWER: 0.293 against 0.270 ms
+// The counter counts helper waves that have finished the reads of their round (4 per round, monotonic over the kernel).  A poll
+// that does not see its target within 2^16 tries gives up (wrong results, which the tests catch, instead of a hung GPU).
+__device__ __forceinline__ void c12_wait_taken(const volatile unsigned* cnt, unsigned target) {
+  for (int i = 0; i < (1 << 16); ++i) {
+    if (*cnt >= target) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 #ifndef V3D_C12_PRE
 #define V3D_C12_PRE 2        // B fragments this many items ahead of their MFMAs (as conv0z.hip)
 #endif
@@ -112,6 +124,8 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
   unsigned char* const buf1 = smem + C12::R0 * C12::PLANE0;             // [2][chunk][hi, lo][H1][P1] slots
   f32x4* const red = reinterpret_cast<f32x4*>(buf1 + 2 * C12::BUF1);    // [chunk][block][lane]
   f32x4* const raw = red + C12::RED / 16;                               // [block][lane]
+  unsigned* const taken = reinterpret_cast<unsigned*>(raw + C12::RAW / 16);
+  if (tid == 0) *taken = 0u;
   const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
 
   // the pad columns of the conv1 buffers (x = 30, 31: read by the idle fourth x tap) are never written: finite from the start
@@ -171,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
       boff[b] = (unsigned)(((2 * y1) * C12::W0 + ((kq & 1) ? C12::W1 + 1 : 0) + x1 + (kq >> 1)) * 16);
     }
     f32x4 acc_prev[6], acc_cur[6];
+    unsigned gbase = 0;                                                // helper rounds of the tasks before this one
 #pragma unroll 1
     for (int t = walk.t; t < walk.end; t += walk.step) {
       const Task q = decode(t);
@@ -239,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
           c12_static_for<0, NI1>(item);
         }
         C12_PHASE_MARK(2);
-        asm volatile("s_barrier" ::: "memory");                        // B'(s): `raw` has been read
+        if (V3D_C12_FLAGS) c12_wait_taken(taken, 4u * (gbase + (unsigned)s + 1u));
+        else asm volatile("s_barrier" ::: "memory");                   // B'(s): `raw` has been read
         C12_PHASE_MARK(3);
         // ---- conv1 plane P - 1 is complete since the odd plane: its accumulators go to the helper waves, which park it during
         // the next step (bias, ReLU, zero padding, split: ~30 VALU instructions per block -- in this wave, which issues in order,
@@ -252,7 +268,8 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
         for (int b = 0; b < 6; ++b) { acc_prev[b] = acc_cur[b]; acc_cur[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       }
       __syncthreads();                                                 // B(nsteps)
-      asm volatile("s_barrier" ::: "memory");                          // B'(nsteps)
+      if (!V3D_C12_FLAGS) asm volatile("s_barrier" ::: "memory");      // B'(nsteps)
+      gbase += (unsigned)q.nsteps + 1u;
     }
     if (wave8 == 0) C12_PHASE_FLUSH(0, 3);
   } else if (wave8 < 4) {
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int b = 0; b < C12::NB2; ++b) acc[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned gbase = 0;
 #pragma unroll 1
     for (int t = walk.t; t < walk.end; t += walk.step) {
       const Task q = decode(t);
@@ -324,7 +342,8 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
           for (int b = 0; b < C12::NB2; ++b) acc[A0][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         C12_PHASE_MARK(4);
-        asm volatile("s_barrier" ::: "memory");                        // B'(s): the helpers have read `red`
+        if (V3D_C12_FLAGS) c12_wait_taken(taken, 4u * (gbase + (unsigned)s + 1u));
+        else asm volatile("s_barrier" ::: "memory");                   // B'(s): the helpers have read `red`
         C12_PHASE_MARK(5);
         // conv2 plane Q - 1 has its three taps (from conv1 planes Q - 2, Q - 1, Q; the absent ones are zero planes)
 #pragma unroll
@@ -337,7 +356,8 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
         if (s + 2 < q.nsteps) step(s + 2, std::integral_constant<int, 2>{});
       }
       __syncthreads();                                                 // B(nsteps)
-      asm volatile("s_barrier" ::: "memory");                          // B'(nsteps)
+      if (!V3D_C12_FLAGS) asm volatile("s_barrier" ::: "memory");      // B'(nsteps)
+      gbase += (unsigned)q.nsteps + 1u;
       // (the accumulator rotation restarts at U = 0 with the next task: every slot is re-initialised by its first use --
       // A0 starts from zero at ky == 0 or is cleared; A1, A2 of the first two steps only ever hold cleared values)
 #pragma unroll
@@ -524,7 +544,13 @@ __global__ __launch_bounds__(512, 2) void conv12z_kernel(C12Params p, const floa
         if (fin) take();
         fin_prev = fin; zo_prev = zo;
         C12_PHASE_MARK(6);
-        asm volatile("s_barrier" ::: "memory");                        // B'(s)
+        if (V3D_C12_FLAGS) {
+          // the reads of `raw` and `red` have returned (park: values consumed above; take: explicit wait): one count per wave
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          asm volatile("s_barrier" ::: "memory");                      // B'(s)
+        }
       }
       if (fin_prev) finish(zo_prev);
     }
