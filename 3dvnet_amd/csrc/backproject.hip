@@ -22,6 +22,10 @@ struct BpParams {
   float* var;            // [n_ref*P, n_hyp, C]
   int n_ref, Hf, Wf, H, W, h, w, n_hyp, n_half;
   double x_step, y_step, offset;
+  // launch constants from the host (round 4: per lane they were two IEEE f64 divisions and two run-time integer divisions
+  // through the float reciprocal, all quarter- / half-rate instructions)
+  float rWm1, rHm1;                 // (float)(1.0 / (double)(W - 1)), (float)(1.0 / (double)(H - 1))
+  unsigned m_hyp, m_w;              // v3d::magic_u32() of n_hyp and w (0: divide)
 };
 
 template <int C>
@@ -50,14 +54,15 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
   const int sample = (blockIdx.x * 256 + tid) / LP;       // (pixel, hypothesis) of this lane group
   const int cg = tid % LP;
   const bool active = sample < P * p.n_hyp;
-  const int pix = active ? sample / p.n_hyp : 0, hyp = active ? sample % p.n_hyp : 0;
-  const int gy = pix / p.w, gx = pix % p.w;
+  const unsigned spix = active ? v3d::udiv_magic((unsigned)sample, (unsigned)p.n_hyp, p.m_hyp) : 0u;
+  const int pix = (int)spix, hyp = active ? sample - (int)spix * p.n_hyp : 0;
+  const int gy = (int)v3d::udiv_magic(spix, (unsigned)p.w, p.m_w), gx = pix - gy * p.w;
   const float xf = (p.w > 1 && gx == p.w - 1) ? (float)(p.W - 1) : (float)((double)gx * p.x_step);
   const float yf = (p.h > 1 && gy == p.h - 1) ? (float)(p.H - 1) : (float)((double)gy * p.y_step);
   // hypothesis depth: depth + i * offset with i * offset evaluated in double then rounded (python float)
   const float dep = v3d::add_rn(p.depth[(size_t)r * P + pix], (float)((double)(hyp - p.n_half) * p.offset));
   const float Wm1 = (float)(p.W - 1), Hm1 = (float)(p.H - 1), Wfm1 = (float)(p.Wf - 1), Hfm1 = (float)(p.Hf - 1);
-  const float rWm1 = (float)(1.0 / (double)(p.W - 1)), rHm1 = (float)(1.0 / (double)(p.H - 1));
+  const float rWm1 = p.rWm1, rHm1 = p.rHm1;
   float X = 0.f, Y = 0.f, Z = 0.f;
   float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_q = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -141,11 +146,16 @@ __global__ __launch_bounds__(256) void backproject_variance_kernel(BpParams p) {
   const size_t row = ((size_t)r * P + pix) * p.n_hyp + hyp;
   if (cg == 0) { p.pts[row * 3] = X; p.pts[row * 3 + 1] = Y; p.pts[row * 3 + 2] = Z; }
   const float cnt = (float)max(ne, 1);
+  // x / cnt is an IEEE division (~10 instructions, eight of them per lane); for a power-of-two count x * (1 / cnt) is the same
+  // number exactly (block-uniform choice, as in the warp kernels)
+  const bool cnt_pow2 = (max(ne, 1) & (max(ne, 1) - 1)) == 0;
+  const float cnt_inv = 1.f / cnt;
+  auto mean = [&](float x) __attribute__((always_inline)) { return cnt_pow2 ? x * cnt_inv : x / cnt; };
   float4 o;
-  { float a = acc_s.x / cnt, q = acc_q.x / cnt; o.x = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
-  { float a = acc_s.y / cnt, q = acc_q.y / cnt; o.y = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
-  { float a = acc_s.z / cnt, q = acc_q.z / cnt; o.z = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
-  { float a = acc_s.w / cnt, q = acc_q.w / cnt; o.w = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = mean(acc_s.x), q = mean(acc_q.x); o.x = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = mean(acc_s.y), q = mean(acc_q.y); o.y = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = mean(acc_s.z), q = mean(acc_q.z); o.z = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
+  { float a = mean(acc_s.w), q = mean(acc_q.w); o.w = v3d::sub_rn(q, v3d::mul_rn(a, a)); }
   *reinterpret_cast<float4*>(p.var + row * C + cg * 4) = o;
 }
 
@@ -182,6 +192,10 @@ extern "C" int v3d_backproject_variance_f32(const float* depth, const float* fea
   p.n_hyp = 2 * n_half + 1; p.n_half = n_half; p.offset = offset;
   p.x_step = w > 1 ? (double)(W - 1) / (double)(w - 1) : 0.0;
   p.y_step = h > 1 ? (double)(H - 1) / (double)(h - 1) : 0.0;
+  p.rWm1 = (float)(1.0 / (double)(W - 1));
+  p.rHm1 = (float)(1.0 / (double)(H - 1));
+  p.m_hyp = v3d::magic_u32((unsigned long long)h * w * p.n_hyp + 256, (unsigned)p.n_hyp);
+  p.m_w = v3d::magic_u32((unsigned long long)h * w + 256, (unsigned)w);
   const long long lanes = (long long)h * w * p.n_hyp * (C / 4);
   dim3 grid((unsigned)((lanes + 255) / 256), n_ref);
   {
