@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRECISION = {'split_bf16': 0, 'fp32': 1}      # V3D_PRECISION_* of include/v3d.h
 
 
@@ -103,7 +103,9 @@ SIGNATURES = {
     'v3d_decoder_fused_f32': (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
                                       ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_void_p,
-                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    'v3d_decoder_fused_workspace_bytes': (c_size_t, [c_int, c_int]),
     'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
 }

@@ -36,7 +36,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, strict=False):
     """Compile every csrc/*.hip to an object (in parallel) and link the shared library."""
     headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))
     tag = _flags_tag()
@@ -60,15 +60,13 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s' % src)
         if verbose and out:
             print(out.decode())
-    # Static guard for the fused decoder's LDS hazard (scripts/check_lds_hazard.py): the default build must carry the LDS
-    # read signature that passed the determinism test on hardware; developer flag sets are not checked.
+    # ISA guard of the fused decoder (3dvnet_amd/isa_check.py: no scratch; LDS read signature pinned per compiler version) on the
+    # default build; developer flag sets are not checked.  `strict` (the entry-point build): the guard must be able to run.
     if not os.environ.get('V3D_EXTRA_FLAGS', '').strip() and not os.environ.get('V3D_SKIP_LDS_CHECK'):
-        sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+        sys.path.insert(0, HERE)
         try:
-            import check_lds_hazard
-            check_lds_hazard.check(os.path.join(objdir, 'decoder.o'))
-        except FileNotFoundError as e:      # no llvm-objcopy / clang-offload-bundler / llvm-objdump next to this hipcc
-            sys.stderr.write('build.py: LDS-hazard guard NOT run (%s)\n' % e)
+            import isa_check
+            isa_check.check(os.path.join(objdir, 'decoder.o'), strict=strict)
         finally:
             sys.path.pop(0)
     if force or procs or linked != tag or _stale(LIB, objs):

@@ -2,6 +2,7 @@
 // along the hypothesis axis, softmax over the hypotheses (refinement.py:24,43) and, optionally, the
 // expected depth offset sum_i p_i * vals_i (lightningmodel.py:238-241).  One wave per point.
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gemm_weights.h"
@@ -61,121 +62,139 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fused hypothesis decoder (rows C2a + C2b + C3 in ONE kernel): sparse trilinear interpolation of
-// the three U-Net levels (refinement.py:28-41) -> Conv1d+BN+ReLU x3 along the hypothesis axis (:16-23) -> Conv1d(128 -> 1)
-// + softmax (:24,43) -> expected offset (lightningmodel.py:237-241).  The [Nq, 352, 7] feature tensor (30.9 MB per
-// reference view and sweep) and the three [Nq*7, 128] activations never reach HBM.
+// Fused hypothesis decoder (rows C2a + C2b + C3): sparse trilinear interpolation of the three U-Net
+// levels (refinement.py:28-41) -> Conv1d+BN+ReLU x3 along the hypothesis axis (:16-23) -> Conv1d(128 -> 1) + softmax (:24,43)
+// -> expected offset (lightningmodel.py:237-241).  The [Nq, 352, 7] feature tensor (30.9 MB per reference view and sweep) and
+// the three [Nq*7, 128] activations never reach HBM.
 //
-// One workgroup (4 waves) = kFPts = 8 query points = kFPts * n_hyp (<= 64) GEMM columns; whole hypothesis groups, so no conv
-// tap crosses the tile.  Layer 1 consumes its 352 input channels in 32-wide chunks that are PRODUCED on the fly: every
-// thread blends the 8 corner rows (hash-probed once per tile into an LDS corner table) of its (row, 4 channels) and commits
-// the split-bf16 values to the staging tile the MFMAs read; the next chunk's gathers are in flight during the MFMAs of the
-// current one.  Layer outputs (bias + ReLU) are split and kept in LDS in B-fragment order for the next layer; the last
-// layer's output stays in LDS as fp32 for the 128 -> 1 head, softmax and expectation.  Matrix arithmetic as everywhere on
-// this path: split-bf16 operands (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16), fp32 accumulation; weights are the
-// split images of v3d_gemm_pack (A fragments go from L2 straight to registers, one tap ahead).
-// LDS: two activation buffers of 33 KB (the second doubles as staging tile + corner table during layer 1).
-// STATUS (round 3): the default decoder whenever the configuration allows (HypothesisDecoder.can_fuse): two workgroups per CU,
-// 3.1 ms per 64-view sweep against 3.7 ms for v3d_sparse_interp_f32 + v3d_gemm_gather_f32 x 3 + v3d_decoder_head_f32 (see
-// kFLdsBytes below for the occupancy bug of round 2).
+// Round 5 decomposition (the round-3/4 kernel kept activations in LDS, every wave fetched its own weight fragments through the
+// CU's vector-memory path -- 0.93 of the 1.6 MB a 64-column tile moved through it -- and spilled 47 registers):
+//
+//   * COLUMN-OWNER WAVES.  A wave owns 32 MFMA columns = 4 query points x 8 hypothesis slots (n_hyp <= 8; slot h >= n_hyp is
+//     padding) and ALL 128 output channels: four v_mfma_f32_32x32x16_bf16 row blocks, 64 accumulator registers.  The C/D layout
+//     of that instruction gives lane (g = lane >> 5, n = lane & 31) the channels 32 mb + 8 j + 4 g + r of column n -- exactly
+//     the 8 k-values per 16-wide K step a B fragment wants once the NEXT layer's weights are packed in that channel order
+//     (v3d_gemm_pack, dec_ofs).  So bias + ReLU + hi/lo split turn a layer's accumulators into the next layer's B fragments
+//     in registers: no activation ever touches LDS, no barrier belongs to the data path.
+//   * The conv taps h - 1 / h + 1 are lane shifts of the B fragment inside a 16-lane row (DPP row_shr / row_shl, zero fill),
+//     masked where a tap leaves the hypothesis group.
+//   * WEIGHTS THROUGH AN LDS RING.  The 8 waves of the workgroup (one per CU, 256 columns = 32 points per tile) walk the
+//     (layer, 16-channel K step) sequence together; the step's 24 KB slab ([3 taps][hi, lo][4 row blocks] A fragments) is
+//     brought into a 3-slot LDS ring by LDS-DMA two steps ahead (3 x 1 KB per wave), one s_barrier per step: the vector-memory
+//     path carries each weight byte once per 256 columns instead of once per 64, and A fragments are ds_read_b128 (LDS has
+//     four times the bandwidth of that path).
+//   * Layer 1's B fragments are PRODUCED by the lane that consumes them: lane (g, n) gathers the 8 corner rows of column n
+//     for its 8 channels of the step (2 x 16 B per corner; the two g halves of a column read 32 contiguous bytes), blends,
+//     splits.  The gathers of step s + 1 are in flight during the matrix instructions of step s.
+//   * The hash probes moved into a pre-kernel (decoder_corner_kernel: one thread per (query row, corner), three levels) that
+//     leaves (row, weight) pairs in a caller-provided table; a data-dependent probe loop inside barrier-coupled matrix waves
+//     stalled all of them.  The tile's entries are parked in a wave-private LDS table during layer 2 of the previous tile.
+//
+// Matrix arithmetic as everywhere on this path: split-bf16 operands (hi*hi + hi*lo + lo*hi), fp32 accumulation.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef V3D_FUSED_PTS
-#define V3D_FUSED_PTS 8
-#endif
-constexpr int kFPts = V3D_FUSED_PTS;          // query points per workgroup: 8 (4 waves, two workgroups per CU; 3.0 ms per 64-view
-                                              // sweep) or 16 (8 waves, one per CU: 3.6 ms -- the barriers span twice the waves)
-constexpr int kFRows = kFPts * 8;             // MFMA columns per workgroup (kFPts * n_hyp <= kFRows)
-#ifndef V3D_FUSED_NB
-#define V3D_FUSED_NB 4
-#endif
-constexpr int kFNB = V3D_FUSED_NB;            // column blocks (16 columns) per wave: 4, or 2 (twice the waves at half the accumulators)
-constexpr int kFWaves = 4 * (kFRows / 16 / kFNB);   // waves per workgroup: wave = (row quarter, column group): 32 channels x 16 kFNB columns
-constexpr int kFThreads = 64 * kFWaves;
-constexpr int kFStageRows = kFRows * 8 / kFThreads;     // staging rows per thread (8 threads x 4 channels per row and chunk)
-constexpr int kFNBT = kFRows / 16;            // column blocks of the workgroup
-constexpr int kFZero = kFRows;           // index of the all-zero activation row (conv padding)
-constexpr int kFRT = kFZero + 1;         // rows per LDS activation array
-constexpr int kFH = 128;            // hidden width of the decoder
-constexpr int kFMBW = 2, kFMB = 4 * kFMBW;      // per wave: kFNB column blocks x 2 row blocks
-constexpr int kFWslab = 4 * kFMBW * 16 * 32;          // packed floats per (tap, K chunk) of a layer's weight image
-constexpr size_t kFActBytes = (size_t)2 * kFRT * 16 * 16;                // [hi, lo][65 rows][16 slots of 8 bf16]
-constexpr size_t kFStageBytes = (size_t)2 * kFRT * 4 * 16;               // [hi, lo][65 rows][4 slots]: one 32-channel chunk
-constexpr size_t kFConstBytes = (3 * 128 + 128 * 3 + 4 + 8) * 4;            // biases of the three layers, head weights, head bias, offset values
-constexpr size_t kFUsedLdsBytes = 2 * kFActBytes + kFConstBytes;
-// Requested LDS: 80 KB = two workgroups per CU (two waves per SIMD: the kernel's 186 VGPRs + 50 AGPRs allow exactly that).
-//
-// The round-2 nondeterminism at two workgroups per CU, diagnosed in round 3 (scripts/micro/fused_decoder_stress.py dumps the
-// layer-1 input rows a workgroup commits and compares them with v3d_sparse_interp_f32):
-//   * it is not a race in this source: wrong rows appear in ~10 % of the workgroups on EVERY launch, always rows 6, 7 (mod 8)
-//     of a wave's staging rows -- lanes 48..63 -- in single channels, as partial corner sums; workgroups at LDS base 0 and at
-//     base 80 KB are hit alike; drains (vmcnt(0) + s_sleep), extra barriers and padded register allocations change nothing;
-//   * it needs matrix instructions in flight on the SIMD (a build that reads the B fragments but issues no MFMA is clean) and
-//     two waves per SIMD (any build whose register count admits one wave per SIMD is clean);
-//   * it follows ONE code-generation choice: at -O2 / -O3 hipcc merges the eight consecutive corner weights a thread reads
-//     from the LDS corner table into two ds_read_b128 (register tuples v[66:69], v[134:137]: even, not 4-aligned); -O1 emits
-//     ds_read2_b32 and is clean, and so is -O3 with those reads kept scalar -- 300 launches beside a GEMM on a second stream.
-// So the corner table is laid out corner-major ([corner][level][row]): the eight values a thread needs are 768 bytes apart,
-// every read is a ds_read_b32 / ds_read2st64_b32 with an immediate offset and nothing can be merged into a 16-byte read
-// (keeping the row-major table and reading it through volatile pointers also works, but every volatile access carries a full
-// s_waitcnt, which serialises the gathers: 3.7 instead of 3.1 ms per sweep).  The GPU suite runs the repeated-launch
-// determinism check at this occupancy.
-constexpr size_t kFLdsBytes = kFPts == 8 ? 80 * 1024 : kFUsedLdsBytes;      // 8 points: two workgroups per CU; 16: one (132 KB)
-__device__ __forceinline__ int fused_corner_index(int r, int l, int corner) { return (corner * 3 + l) * kFRows + r; }
-static_assert(2 * kFStageBytes + 2 * kFRows * 3 * 8 * 4 <= kFActBytes, "two staging tiles + corner table alias the second buffer");
-static_assert((size_t)kFRows * kFH * 4 <= kFActBytes, "fp32 output of the last layer aliases the first buffer");
+constexpr int kDWaves = 8, kDThreads = 64 * kDWaves;
+constexpr int kDPtsWave = 4, kDPtsTile = kDPtsWave * kDWaves;     // query points per wave / per tile (8 column slots each)
+constexpr int kDH = 128;                                           // hidden width of the decoder
+constexpr int kDSlabFrags = 24;                                    // [3 taps][hi, lo][4 row blocks] fragments of 1 KB
+constexpr int kDSlab = kDSlabFrags * 1024;                         // bytes per 16-channel K step
+constexpr int kDRing = 3;
+constexpr int kDCtabWave = 4 * 8 * 32 * 8;                         // bytes: [3 levels + point features][corner][column] (row, weight)
+constexpr int kDStageWave = 2 * 64 * 16;                           // bytes: [hi, lo][g][column] one B fragment slot each
+constexpr int kDLdsRing = kDRing * kDSlab;
+constexpr int kDLdsCtab = kDWaves * kDCtabWave;
+constexpr int kDLdsStage = kDWaves * kDStageWave;
+constexpr int kDLdsConst = (3 * kDH + 3 * kDH + 16) * 4;           // permuted biases, permuted head weights, head bias, offset values
+constexpr int kDLdsBytes = kDLdsRing + kDLdsCtab + kDLdsStage + kDLdsConst;     // 158 784 B: one workgroup per CU
+static_assert(kDLdsBytes <= 160 * 1024, "LDS of one CU");
+static_assert(kDSlabFrags % kDWaves == 0, "every wave issues the same number of LDS-DMA pieces per step");
+constexpr int kDPieces = kDSlabFrags / kDWaves;                    // 3
 
-struct FusedLevel {
-  v3dhash::HashTable table;
-  const float* feats;     // [N, C]
-  const float* min_pts;   // [n_batch, 3]
-  float res;              // x.res of the level (= tensor_stride * voxel size)
-  int C, ts;
+struct CornerParams {
+  v3dhash::HashTable table[3];
+  const float* min_pts[3];     // [n_batch, 3]
+  float res[3];                // x.res of the level (= tensor_stride * voxel size)
+  int ts[3];
+  const float* pts;            // [n_q, 3]
+  const long long* pts_batch;  // [n_pts]
+  int n_hyp;
+  int n_q;
+  u32x2* out;                  // [n_q][3 levels][8 corners] (feature row, weight bits); absent corner = (0, 0.f)
 };
 
+// Rows C2a's index half: the 8 lattice corners of every hypothesis point on the three levels (refinement.py:33-39 feeding
+// MinkowskiInterpolation): query coordinate ((p - min) / x.res) * x.stride in base-voxel units, corner floor(q / ts) ts + {0, ts}^3,
+// weight prod (1 - |q - c| / ts), absent corners contribute nothing (no renormalisation).  One thread per (row, corner).
+__global__ __launch_bounds__(256) void decoder_corner_kernel(CornerParams cp) {
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;      // (host: 8 n_q < 2^31)
+  const unsigned q = gid >> 3;
+  const int corner = (int)(gid & 7u);
+  if (q >= (unsigned)cp.n_q) return;
+  const int b = (int)cp.pts_batch[q / (unsigned)cp.n_hyp];
+  const float px = cp.pts[(size_t)q * 3 + 0], py = cp.pts[(size_t)q * 3 + 1], pz = cp.pts[(size_t)q * 3 + 2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float ts = (float)cp.ts[l], res = cp.res[l];
+    const float* mn = cp.min_pts[l] + b * 3;
+    const float qx = ((px - mn[0]) / res) * ts, qy = ((py - mn[1]) / res) * ts, qz = ((pz - mn[2]) / res) * ts;
+    const float c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
+    const float c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
+    const float c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
+    float w = 1.f;
+    w *= 1.f - fabsf(qx - c0) / ts;
+    w *= 1.f - fabsf(qy - c1) / ts;
+    w *= 1.f - fabsf(qz - c2) / ts;
+    int row = -1;
+    // (a coordinate outside the key range cannot be present and is never looked up)
+    if (c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard && c0 <= 60000.f && c1 <= 60000.f && c2 <= 60000.f)
+      row = v3dhash::hash_find(cp.table[l], v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2));
+    // an absent corner reads feature row 0 with weight 0: the gathers of the fused kernel are unconditional
+    cp.out[((size_t)q * 3 + l) * 8 + corner] = (u32x2){row < 0 ? 0u : (unsigned)row, row < 0 ? 0u : __float_as_uint(w)};
+  }
+}
+
 struct FusedParams {
-  FusedLevel lv[3];       // in feature-row order: channels [0, C0) = lv[0] (finest), then lv[1], lv[2], then pts_feat
-  const float* pts;       // [n_pts, n_hyp, 3]
-  const long long* pts_batch;
-  const float* pts_feat;  // [n_pts, n_hyp, c_feat] or null
-  int c_feat, n_pts, n_hyp, nkc1;
-  const float* w[3];      // split-bf16 weight images of the three Conv1d layers
-  const float* bias[3];   // folded BatchNorm biases [128]
-  const float* head_w;    // [1, 128, 3]
+  const float* feats[3];      // level features [N_l, C_l], in feature-row order: channels [0, C0) = finest level, then the coarser two
+  int C[3];
+  const u32x2* ctab;          // decoder_corner_kernel's table
+  const float* pts_feat;      // [n_pts, n_hyp, c_feat] or null
+  int c_feat, n_pts, n_hyp;
+  const void* w[3];           // slab images (v3d_gemm_weights::dec_ofs) of the three Conv1d layers
+  int nstep1;                 // 16-channel K steps of layer 1 (the 128 -> 128 layers have 8)
+  const float* bias[3];       // folded BatchNorm biases [128]
+  const float* head_w;        // [1, 128, 3]
   const float* head_b;
-  const float* vals;      // [n_hyp] offset values or null
-  float* preds;           // [n_pts, n_hyp]
-  float* expect;          // [n_pts] or null
-#ifdef V3D_FUSED_DEBUG
-  float* dbg_x;           // developer build: [n_pts * n_hyp, K1] the interpolated layer-1 input as committed to the staging tile
-  unsigned* dbg_wg;       // developer build: per workgroup [4]: HW_REG_LDS_ALLOC, HW_REG_HW_ID, XCC id, 0
-#endif
+  const float* vals;          // [n_hyp] offset values or null
+  float* preds;               // [n_pts, n_hyp]
+  float* expect;              // [n_pts] or null
 };
 
 __device__ __forceinline__ unsigned fused_pack_bf16x2(float a, float b) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
 }
-// x = hi + lo (hi = RNE_bf16(x), lo = RNE_bf16(x - hi)) for 4 values -> two words of hi, two of lo
-__device__ __forceinline__ void fused_split4(const float (&v)[4], u32x2& hi, u32x2& lo) {
-  const unsigned h01 = fused_pack_bf16x2(v[0], v[1]), h23 = fused_pack_bf16x2(v[2], v[3]);
-  hi = (u32x2){h01, h23};
-  lo = (u32x2){fused_pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
-               fused_pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+// x = hi + lo (hi = RNE_bf16(x), lo = RNE_bf16(x - hi)) for 8 values -> four words of hi, four of lo (one B fragment each)
+__device__ __forceinline__ void fused_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned h = fused_pack_bf16x2(v[2 * q], v[2 * q + 1]);
+    hi[q] = h;
+    lo[q] = fused_pack_bf16x2(v[2 * q] - __uint_as_float(h << 16), v[2 * q + 1] - __uint_as_float(h & 0xffff0000u));
+  }
 }
+// lane n of a 16-lane row receives lane n - 1 (shr) / n + 1 (shl); lanes without a source receive 0
+__device__ __forceinline__ unsigned fused_row_shr1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned fused_row_shl1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true); }
 
-#ifndef V3D_FUSED_LB
-#define V3D_FUSED_LB 2      // two waves per SIMD = two workgroups per CU: the register allocator must stay within 256
-#endif
 #ifdef V3D_PHASE_TIMING
-// developer build only (as in costreg.hip): wave 0 of every workgroup adds up the cycles between marks and writes them to
-// its own slot; phases: 0 corner table, 1 layer-1 commits (two barriers + blend + split), 2 layer-1 matrix phase, 3 activation
-// stores, 4 layer 2, 5 layer 3, 6 head
-constexpr int kFPhaseSlots = 1 << 15;
+// developer build only: wave 0 of every workgroup adds up the cycles between marks: 0 tile prologue, 1 layer-1 steps, 2 head,
+// 3 layer transitions, 4 layer 2, 5 layer 3, 6 first half of a step incl. the wait for the slab, 7 waits at the step barrier
+constexpr int kFPhaseSlots = 1 << 12;
 __device__ unsigned long long g_fused_phase[8 * kFPhaseSlots];
 #define FPHASE_DECL long long ph_t = __builtin_readcyclecounter(); long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define FPHASE_MARK(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
@@ -185,573 +204,456 @@ __device__ unsigned long long g_fused_phase[8 * kFPhaseSlots];
 #define FPHASE_MARK(i)
 #define FPHASE_FLUSH
 #endif
-// -DV3D_PHASE_TIMING=2: the coarse marks collapse into slot 0 and the layer-1 chunk loop is resolved instead: 1 gather issue,
-// 2 / 3 / 4 the three taps, 5 commit (wait for the gathers, blend, split, LDS writes), 6 barrier
-#if defined(V3D_PHASE_TIMING) && V3D_PHASE_TIMING == 2
-#undef FPHASE_MARK
-#define FPHASE_MARK(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[0] += t_ - ph_t; ph_t = t_; } while (0)
-#define FPHASE_FINE(i) do { long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
-#else
-#define FPHASE_FINE(i)
+#ifndef V3D_FUSED_FETCH64
+#define V3D_FUSED_FETCH64 0       // developer experiment: 1 = the staged B fragment is fetched with two 16-byte reads (the hazard)
+#endif
+#ifndef V3D_FUSED_SAFE_WAIT
+#define V3D_FUSED_SAFE_WAIT 0     // developer experiment: every rendezvous drains the wave's vector-memory queue
 #endif
 #ifndef V3D_FUSED_ABLATE
-#define V3D_FUSED_ABLATE 0   // developer ablations (scripts/micro/fused_decoder_ablate.sh): 1 no matrix instructions, 2 no feature gathers
-                             // (corner rows read as row 0 ... of a 4 KB window), 3 weight fragments from a 2 KB window, 4 no hash probes,
-                             // 5 layer 1 only, 7 tiles interleaved over the XCDs, 8 a chunk's gathers in one burst
+#define V3D_FUSED_ABLATE 0   // developer ablations: 1 no matrix instructions, 2 gathers from rows 0..7 only, 3 no weight DMA, 6 no gathers, 8 neither
 #endif
-__global__ __launch_bounds__(kFThreads, V3D_FUSED_LB) void decoder_fused_kernel(FusedParams p) {
+
+__global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* const actA = reinterpret_cast<u32x4*>(smem);                               // [2][kFRT][16]
-  u32x4* const actB = reinterpret_cast<u32x4*>(smem + kFActBytes);                  // [2][kFRT][16]
-  u32x4* const xq = actB;                                                           // layer 1: two staging tiles [2][kFRT][4]
-  int* const crow = reinterpret_cast<int*>(smem + kFActBytes + 2 * kFStageBytes);   // layer 1: [8 corners][3 levels][rows]
-  float* const cw = reinterpret_cast<float*>(crow + kFRows * 24);
-  constexpr int kFStageSlots = 2 * kFRT * 4;                                        // 16-byte slots of one staging tile
-  float* const cbias = reinterpret_cast<float*>(smem + 2 * kFActBytes);             // [3][128] folded BatchNorm biases
-  float* const chead = cbias + 3 * kFH;                                             // [128][3] head weights, then the head bias
+  float* const cbias = reinterpret_cast<float*>(smem + kDLdsRing + kDLdsCtab + kDLdsStage);   // [3 layers][4 mb][2 g][16 regs]
+  float* const chead = cbias + 3 * kDH;                                               // [3 taps][4 mb][2 g][16 regs]
+  float* const cmisc = chead + 3 * kDH;                                               // head bias, -, -, -, offset values [8]
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
 
-  // Per-lane indices.  They are re-derived from an opaque copy of threadIdx.x at the top of every tile (refresh_lane_ids): with
-  // plain loop invariants the compiler hoists every per-lane LDS / global address of every phase out of the tile loop and
-  // keeps them all alive across it (256 VGPRs + 144 AGPRs + scratch instead of ~220 registers).
-  int tid = threadIdx.x, lane = tid & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = wave_id & 3;            // row quarter: output channels 32 wave .. 32 wave + 31
-  const int cb0 = (wave_id >> 2) * kFNB;   // first of this wave's 4 column blocks
-  int kq = lane >> 4, jn = lane & 15;
-  // query points per tile: as many whole hypothesis groups as the kFRows columns hold (7 hypotheses: 9 points = 63 of 64
-  // columns; with a fixed 8 points per tile an eighth of every MFMA's columns was padding)
-  const int n_hyp = p.n_hyp, npt = kFRows / n_hyp, rows = npt * n_hyp;
-  const long long n_q = (long long)p.n_pts * n_hyp;
-  const int n_tiles = (p.n_pts + npt - 1) / npt;
-  // The workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host launches as many workgroups as the chip holds at
-  // once): everything that does not depend on the tile -- biases, head weights, the weight-fragment ring -- is set up once, and
-  // the corner table of the NEXT tile is looked up while the matrix pipe works on layers 2 and 3 of the current one.
-  int pt0 = 0;
-  long long q0 = 0;                        // first global (point, hypothesis) row of the current tile
-
-#ifdef V3D_FUSED_DEBUG
-  if (p.dbg_wg && tid == 0) {
-    p.dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);     // HW_REG_LDS_ALLOC
-    p.dbg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
-    p.dbg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
-  }
-#endif
+  int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x2* const ctab = reinterpret_cast<u32x2*>(smem + kDLdsRing + wave * kDCtabWave);   // wave-private [4][8][32]
+  unsigned char* const stage = smem + kDLdsRing + kDLdsCtab + wave * kDStageWave;       // wave-private [hi, lo][g][column] 16 B
+  const int n_hyp = p.n_hyp;
+  const int sb1 = p.C[0] >> 4, sb2 = sb1 + (p.C[1] >> 4), sb3 = sb2 + (p.C[2] >> 4), n1 = p.nstep1;   // step ranges of layer 1
   FPHASE_DECL;
 
-  // ---- corner table: 8 hash probes per (row, level), as interp_corners_kernel (sparse.hip) -------------------------------------
-  // (the level index is kept wave-uniform everywhere: a per-lane index into the kernel-argument array p.lv[] makes the
-  // compiler build a per-lane scratch copy of it)
-  // A thread owns one corner of kFProbeRows rows on all three levels.  The lookups are four stages of independent loads --
-  // (point, batch) of the rows; the levels' minimum corners; the first slot of every probe sequence, key and value together;
-  // resolve (+ the rare longer probe sequence) -- instead of six hash_find() calls in a row, each a chain of four dependent global
-  // loads.  Measured per workgroup (wave 0, -DV3D_PHASE_TIMING): 36 k of 128 k cycles when the table was built in front of every
-  // tile, whatever the load order -- the chain is latency under a loaded memory system, so the stages of the next tile are spread
-  // over the matrix phases of layers 2 and 3, where the gather registers are free.
-  constexpr int kFProbeRows = kFRows * 8 / kFThreads;
-  int corner = tid & 7;
-  // what survives from one tile to the next: feature row (-1 = absent) and weight of this thread's corner of its rows
-  int ct_row[3][kFProbeRows];
-  float ct_w[3][kFProbeRows];
-  // the lookups in flight: declared per tile (below) so that nothing but ct_row / ct_w is carried around the tile loop
-  struct Probe {
-    bool live[kFProbeRows], ok[3][kFProbeRows];
-    float px[kFProbeRows], py[kFProbeRows], pz[kFProbeRows], mn[3][kFProbeRows][3];
-    int bb[kFProbeRows], found[3][kFProbeRows];
-    unsigned long long key[3][kFProbeRows];
-    unsigned slot[3][kFProbeRows];
-  };
-  auto ct_points = [&](Probe& c, int tile) __attribute__((always_inline)) {
-    const int tp0 = tile * npt;
-    const long long tq0 = (long long)tp0 * n_hyp;
-#pragma unroll
-    for (int i = 0; i < kFProbeRows; ++i) {
-      const int r = (tid >> 3) + i * (kFThreads / 8);
-      c.live[i] = r < rows && tq0 + r < n_q;
-      const long long q = c.live[i] ? tq0 + r : tq0;
-      c.px[i] = p.pts[(size_t)q * 3 + 0]; c.py[i] = p.pts[(size_t)q * 3 + 1]; c.pz[i] = p.pts[(size_t)q * 3 + 2];
-      c.bb[i] = (int)p.pts_batch[tp0 + (c.live[i] ? (int)((unsigned)r / (unsigned)n_hyp) : 0)];      // = q / n_hyp
-    }
-  };
-  auto ct_mins = [&](Probe& c) __attribute__((always_inline)) {
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int i = 0; i < kFProbeRows; ++i)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) c.mn[l][i][a] = p.lv[l].min_pts[c.bb[i] * 3 + a];
-  };
-  auto ct_keys = [&](Probe& c) __attribute__((always_inline)) {
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      const float ts = (float)p.lv[l].ts, res = p.lv[l].res;
-#pragma unroll
-      for (int i = 0; i < kFProbeRows; ++i) {
-        // query coordinate in base-voxel units: ((p - min) / x.res) * x.stride   (refinement.py:34-35)
-        const float qx = ((c.px[i] - c.mn[l][i][0]) / res) * ts;
-        const float qy = ((c.py[i] - c.mn[l][i][1]) / res) * ts;
-        const float qz = ((c.pz[i] - c.mn[l][i][2]) / res) * ts;
-        const float c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
-        const float c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
-        const float c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
-        float w = 1.f;
-        w *= 1.f - fabsf(qx - c0) / ts;
-        w *= 1.f - fabsf(qy - c1) / ts;
-        w *= 1.f - fabsf(qz - c2) / ts;
-        ct_w[l][i] = w;
-        c.ok[l][i] = c.live[i] && c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard &&
-                     c0 <= 60000.f && c1 <= 60000.f && c2 <= 60000.f;
-        // (a coordinate outside the key range is never looked up; clamping keeps the int conversions defined)
-        const float lo = -(float)v3dhash::kGuard, hi = 60000.f;
-        c.key[l][i] = v3dhash::pack_key(c.bb[i], (int)fminf(fmaxf(c0, lo), hi), (int)fminf(fmaxf(c1, lo), hi),
-                                        (int)fminf(fmaxf(c2, lo), hi));
-        c.slot[l][i] = V3D_FUSED_ABLATE == 4 ? (unsigned)i : v3dhash::hash_u64(c.key[l][i]) & p.lv[l].table.mask;
-        c.found[l][i] = -1;
-      }
-    }
-  };
-  // All probe sequences of the thread advance in lock step, two slots per round: a round is ONE memory round trip for the six
-  // lookups (in turn they cost the sum of their chain lengths: unsuccessful searches -- absent corners are the common case off the
-  // surface -- run to the first empty slot, and a wave waits for its longest chain: 39 k cycles per tile, measured).
-  auto ct_probe = [&](Probe& c) __attribute__((always_inline)) {
-    unsigned pending = 0;
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int i = 0; i < kFProbeRows; ++i) pending |= (c.ok[l][i] && V3D_FUSED_ABLATE != 4 ? 1u : 0u) << (l * kFProbeRows + i);
-    for (unsigned round = 0; __any(pending != 0) && round <= 0x40000000u; ++round) {
-      unsigned long long ka[3][kFProbeRows], kb[3][kFProbeRows];
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int i = 0; i < kFProbeRows; ++i) {
-          // (a finished lookup re-reads its last slots: unconditional loads keep the six of them in one batch)
-          ka[l][i] = p.lv[l].table.keys[c.slot[l][i]];
-          kb[l][i] = p.lv[l].table.keys[(c.slot[l][i] + 1) & p.lv[l].table.mask];
-        }
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int i = 0; i < kFProbeRows; ++i) {
-          const unsigned bit = 1u << (l * kFProbeRows + i);
-          if (pending & bit) {
-            const unsigned s0 = c.slot[l][i], s1 = (s0 + 1) & p.lv[l].table.mask;
-            if (ka[l][i] == c.key[l][i]) { c.found[l][i] = (int)s0; pending &= ~bit; }
-            else if (ka[l][i] == v3dhash::kEmpty) pending &= ~bit;
-            else if (kb[l][i] == c.key[l][i]) { c.found[l][i] = (int)s1; pending &= ~bit; }
-            else if (kb[l][i] == v3dhash::kEmpty) pending &= ~bit;
-            else c.slot[l][i] = (s1 + 1) & p.lv[l].table.mask;
-          }
-        }
-    }
-  };
-  auto ct_values = [&](Probe& c) __attribute__((always_inline)) {
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int i = 0; i < kFProbeRows; ++i) {
-        if (V3D_FUSED_ABLATE == 4) ct_row[l][i] = c.ok[l][i] ? (int)(c.key[l][i] >> 32) & 1023 : -1;
-        else ct_row[l][i] = c.found[l][i] >= 0 ? p.lv[l].table.vals[c.found[l][i]] : -1;
-      }
-  };
-  // an absent corner (or a padding row) reads feature row 0 with weight 0: the gathers below are unconditional
-  auto ct_store = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int i = 0; i < kFProbeRows; ++i) {
-        const int r = (tid >> 3) + i * (kFThreads / 8);
-        crow[fused_corner_index(r, l, corner)] = ct_row[l][i] < 0 ? 0 : ct_row[l][i];
-        cw[fused_corner_index(r, l, corner)] = ct_row[l][i] < 0 ? 0.f : ct_w[l][i];
-      }
-  };
-
-  // ---- layer 1: K = 3 taps x (C0 + C1 + C2 + c_feat) channels, produced chunk by chunk ----------------------------------
-  int srow = tid >> 3, sc4 = (tid & 7) * 4;
-  const int cb1 = p.lv[0].C, cb2 = cb1 + p.lv[1].C, cb3 = cb2 + p.lv[2].C;
-  // Gather registers: the level chunks (8 corner rows per staging row) and the per-point feature chunks (one row) have their
-  // own registers and their own loops below -- with one conditional producer the compiler routed the gathers through
-  // temporaries and waited for ALL of them before the chunk's first MFMA (no overlap).
-  f32x4 xr[kFStageRows][8], xf[kFStageRows];
-  const int nkc_lv = cb3 / 32;             // chunks produced by interpolation; chunks nkc_lv .. nkc1 - 1 copy pts_feat
-  // level of a 32-channel chunk: wave-uniform (chunk boundaries are multiples of 32)
-  auto level_of = [&](int kc) __attribute__((always_inline)) {
-    const int c = kc * 32;
-    return c < cb1 ? 0 : c < cb2 ? 1 : 2;
-  };
-  // part = -1: all gathers of the chunk; 0 / 1 / 2: a third of them (issued between the taps of the previous chunk: one burst of
-  // 16 x 1 KB per wave from all eight waves of the CU backs up the CU's single vector-memory path and the wave cannot issue its
-  // matrix instructions behind it -- measured 1.6 k cycles for the burst)
-  auto issue_lv = [&](int kc, int part) __attribute__((always_inline)) {
-    const int l = level_of(kc);
-    const float* const feats = l == 0 ? p.lv[0].feats : l == 1 ? p.lv[1].feats : p.lv[2].feats;
-    const int C = l == 0 ? p.lv[0].C : l == 1 ? p.lv[1].C : p.lv[2].C;
-    const int lc = kc * 32 - (l == 0 ? 0 : l == 1 ? cb1 : cb2) + sc4;
-#pragma unroll
-    for (int ps = 0; ps < kFStageRows; ++ps) {
-      const int r = srow + (kFThreads / 8) * ps;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (part >= 0 && ((ps * 8 + k) * 3) / (kFStageRows * 8) != part) continue;
-        const int cr = V3D_FUSED_ABLATE == 2 ? (crow[fused_corner_index(r, l, k)] & 7) : crow[fused_corner_index(r, l, k)];
-        xr[ps][k] = *reinterpret_cast<const f32x4*>(feats + (size_t)cr * C + lc);
-      }
-    }
-  };
-  auto issue_feat = [&](int kc) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ps = 0; ps < kFStageRows; ++ps) {
-      const int r = srow + (kFThreads / 8) * ps;
-      xf[ps] = (r < rows && q0 + r < n_q)
-                   ? *reinterpret_cast<const f32x4*>(p.pts_feat + (size_t)(q0 + r) * p.c_feat + (kc * 32 - cb3 + sc4))
-                   : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  // split one staging row's 4 channels and commit them to the staging tile of chunk kc (tile kc & 1)
-  auto commit_row = [&](int kc, int r, const float (&v)[4]) __attribute__((always_inline)) {
-#ifdef V3D_FUSED_DEBUG
-    if (p.dbg_x && r < rows && q0 + r < n_q)
-      *reinterpret_cast<f32x4*>(p.dbg_x + (size_t)(q0 + r) * (p.nkc1 * 32) + kc * 32 + sc4) = (f32x4){v[0], v[1], v[2], v[3]};
-#endif
-    u32x2 hi, lo;
-    fused_split4(v, hi, lo);
-    const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
-    const int slot = kg ^ (((r >> 3) & 1) * 3);
-    u32x2* x2 = reinterpret_cast<u32x2*>(xq + (kc & 1) * kFStageSlots);
-    x2[(r * 4 + slot) * 2 + half] = hi;
-    x2[((kFRT + r) * 4 + slot) * 2 + half] = lo;
-  };
-  auto commit_lv = [&](int kc) __attribute__((always_inline)) {
-    const int l = level_of(kc);
-#pragma unroll
-    for (int ps = 0; ps < kFStageRows; ++ps) {
-      const int r = srow + (kFThreads / 8) * ps;
-      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {      // corner order x fastest; absent corners add nothing (no renormalisation)
-        const float w = cw[fused_corner_index(r, l, k)];
-        a = __builtin_elementwise_fma(xr[ps][k], (f32x4){w, w, w, w}, a);
-      }
-      const float v[4] = {a.x, a.y, a.z, a.w};
-      commit_row(kc, r, v);
-    }
-  };
-  auto commit_feat = [&](int kc) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ps = 0; ps < kFStageRows; ++ps) {
-      const float v[4] = {xf[ps].x, xf[ps].y, xf[ps].z, xf[ps].w};
-      commit_row(kc, srow + (kFThreads / 8) * ps, v);
-    }
-  };
-
-  // per column block: does tap 0 / tap 2 of this lane's output row stay inside its hypothesis group?
-  unsigned tapmask = 0;
-#pragma unroll
-  for (int nb = 0; nb < kFNB; ++nb) {
-    const int hh = ((cb0 + nb) * 16 + jn) % n_hyp;
-    tapmask |= (hh >= 1 ? 1u : 0u) << (2 * nb);
-    tapmask |= (hh + 1 < n_hyp ? 1u : 0u) << (2 * nb + 1);
+  // tile-invariant constants, parked in LDS in the register order of the accumulator tile: entry [mb][g][r] belongs to channel
+  // 32 mb + 8 (r >> 2) + 4 g + (r & 3)
+  for (int i = tid; i < 3 * kDH; i += kDThreads) {
+    const int L = i >> 7, j = i & 127, mb = j >> 5, gg = (j >> 4) & 1, r = j & 15;
+    const int ch = 32 * mb + 8 * (r >> 2) + 4 * gg + (r & 3);
+    cbias[i] = (L == 0 ? p.bias[0] : L == 1 ? p.bias[1] : p.bias[2])[ch];
+    chead[i] = p.head_w[ch * 3 + L];                          // weight [1, C, 3]: L = tap
   }
-  // Weight fragments: a ring of three tap steps.  The (layer, chunk, tap) steps form one cyclic sequence through all the tiles of
-  // the workgroup; the fragments of step g + 2 are requested when step g starts, so an L2 round trip has two steps' worth of
-  // matrix instructions (2 x 24 x 16 cycles of this wave alone) to hide behind.  Three taps per chunk = three ring slots: the
-  // slot of a tap is a compile-time constant.
-  u32x4 a_ring[3][2 * kFMBW];
-  auto load_a = [&](u32x4 (&a)[2 * kFMBW], const float* wp, int nkc, int t, int kc) __attribute__((always_inline)) {
-    const u32x4* w = reinterpret_cast<const u32x4*>(wp + (V3D_FUSED_ABLATE == 3 ? (size_t)0 : (size_t)(t * nkc + kc) * kFWslab)) + lane;
-#pragma unroll
-    for (int m = 0; m < kFMBW; ++m) {
-      a[m] = w[(wave * kFMBW + m) * 64];
-      a[kFMBW + m] = w[(kFMB + wave * kFMBW + m) * 64];
-    }
-  };
-  f32x4 acc[kFNB][kFMBW];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int nb = 0; nb < kFNB; ++nb)
-#pragma unroll
-      for (int m = 0; m < kFMBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  bool has_next = false;                   // another tile follows the current one (wave-uniform)
-  // the fragments of the step two after (layer, kc, t); layer 0 = the first Conv1d (nkc1 chunks), 1 and 2 = the 128 -> 128 ones;
-  // behind the last layer the sequence starts over for the next tile
-  auto prefetch_a = [&](u32x4 (&a)[2 * kFMBW], int layer, int kc, int t) __attribute__((always_inline)) {
-    int t2 = t + 2, kc2 = kc, l2 = layer;
-    if (t2 >= 3) { t2 -= 3; ++kc2; }
-    if (kc2 >= (layer == 0 ? p.nkc1 : 4)) { kc2 = 0; ++l2; }
-    if (l2 == 3) {
-      if (!has_next) return;
-      l2 = 0;
-    }
-    load_a(a, l2 == 0 ? p.w[0] : l2 == 1 ? p.w[1] : p.w[2], l2 == 0 ? p.nkc1 : 4, t2, kc2);
-  };
-  auto mfma_block = [&](const u32x4 (&a_cur)[2 * kFMBW], const bf16x8 b_hi, const bf16x8 b_lo, int nb) __attribute__((always_inline)) {
-#if defined(V3D_FUSED_NOMFMA) || V3D_FUSED_ABLATE == 1      // developer experiment: B fragments are read, no matrix instruction is issued
-    asm volatile("" : : "v"(b_hi), "v"(b_lo));
-    return;
-#endif
-#pragma unroll
-    for (int m = 0; m < kFMBW; ++m) {
-      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a_cur[m]), a_lo = __builtin_bit_cast(bf16x8, a_cur[kFMBW + m]);
-      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[nb][m], 0, 0, 0);
-      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[nb][m], 0, 0, 0);
-      acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
-    }
-  };
-  // folded BatchNorm biases and head weights: tile-invariant, parked in LDS once (a global load in front of every activation
-  // store / head is an exposed L2 round trip per layer and tile; registers are what this kernel does not have)
-  for (int i = tid; i < 3 * kFH; i += kFThreads) cbias[i] = (i < kFH ? p.bias[0] : i < 2 * kFH ? p.bias[1] : p.bias[2])[i % kFH];
-  for (int i = tid; i < 3 * kFH; i += kFThreads) chead[i] = p.head_w[i];
-  if (tid == 0) chead[3 * kFH] = p.head_b[0];
-  if (tid < 8) chead[3 * kFH + 4 + tid] = (p.vals && tid < p.n_hyp) ? p.vals[tid] : 0.f;      // offset values of the expectation
-  // bias + ReLU of this wave's 32 channels x 64 rows -> split -> LDS activation buffer (B-fragment order, 16-byte slots of 8
-  // channels, slot index XOR-ed with the row so that the 16 row-lanes of a ds_read_b128 hit 16 different slots)
-  auto store_act = [&](u32x4* dst, const float* bias) __attribute__((always_inline)) {
-    u32x2* d2 = reinterpret_cast<u32x2*>(dst);
-#pragma unroll
-    for (int nb = 0; nb < kFNB; ++nb) {
-      const int r = (cb0 + nb) * 16 + jn;
-#pragma unroll
-      for (int mw = 0; mw < kFMBW; ++mw) {
-        const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + co0);
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bq[k], 0.f);
-        u32x2 hi, lo;
-        fused_split4(v, hi, lo);
-        const int slot = (co0 >> 3) ^ (r & 15), half = (co0 >> 2) & 1;
-        d2[(r * 16 + slot) * 2 + half] = hi;
-        d2[((kFRT + r) * 16 + slot) * 2 + half] = lo;
-      }
-    }
-  };
-
-  // the three taps of chunk kc: MFMAs on its staging tile, A fragments two taps ahead
-  auto mfma_chunk = [&](int kc, auto tap_hook) __attribute__((always_inline)) {
-    const u32x4* const xs = xq + (kc & 1) * kFStageSlots;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      prefetch_a(a_ring[(t + 2) % 3], 0, kc, t);
-      tap_hook(t);
-#pragma unroll
-      for (int nb = 0; nb < kFNB; ++nb) {
-        const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
-        const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
-        const int slot = R * 4 + (kq ^ (((R >> 3) & 1) * 3));
-        mfma_block(a_ring[t], __builtin_bit_cast(bf16x8, xs[slot]), __builtin_bit_cast(bf16x8, xs[kFRT * 4 + slot]), nb);
-      }
-      FPHASE_FINE(2 + t);
-    }
-  };
-  // a 128 -> 128 layer on the activations in `src`; `hook(kc)` runs in front of every chunk (the next tile's corner-table stages)
-  auto dense_layer = [&](int layer, const u32x4* src, auto hook) __attribute__((always_inline)) {
-#pragma unroll 1
-    for (int kc = 0; kc < 4; ++kc) {
-      hook(kc);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        prefetch_a(a_ring[(t + 2) % 3], layer, kc, t);
-#pragma unroll
-        for (int nb = 0; nb < kFNB; ++nb) {
-          const bool inside = t == 1 || ((tapmask >> (2 * nb + (t >> 1))) & 1u);
-          const int R = inside ? (cb0 + nb) * 16 + jn + t - 1 : kFZero;
-          const int slot = R * 16 + ((kc * 4 + kq) ^ (R & 15));
-          mfma_block(a_ring[t], __builtin_bit_cast(bf16x8, src[slot]), __builtin_bit_cast(bf16x8, src[kFRT * 16 + slot]), nb);
-        }
-      }
-    }
-  };
-
-  int hpt = tid >> 5, hl32 = tid & 31, hc0 = hl32 * 4;       // head: 32 lanes per point, 4 channels per lane
-  auto refresh_lane_ids = [&]() __attribute__((always_inline)) {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    tid = t; lane = t & 63; kq = lane >> 4; jn = lane & 15; corner = t & 7; srow = t >> 3; sc4 = (t & 7) * 4;
-    hpt = t >> 5; hl32 = t & 31; hc0 = hl32 * 4;
-  };
+  if (tid == 0) cmisc[0] = p.head_b[0];
+  if (tid < 8) cmisc[4 + tid] = (p.vals && tid < n_hyp) ? p.vals[tid] : 0.f;
 
   // Tile walk: workgroups are dealt round-robin to the 8 XCDs, so XCD x = blockIdx.x % 8 takes the x-th contiguous eighth of the
   // tiles (consecutive tiles are neighbouring pixels of one view): the corner rows its workgroups gather then come from the part
   // of the scene a few views see and stay in that XCD's 4 MB L2, instead of every XCD streaming all three feature tables.
-  const int n_xcd = V3D_FUSED_ABLATE != 7 && gridDim.x % 8 == 0 ? 8 : 1;
+  const int n_tiles = (p.n_pts + kDPtsTile - 1) / kDPtsTile;
+  const int n_xcd = gridDim.x % 8 == 0 ? 8 : 1;
   const int tiles_per_xcd = (n_tiles + n_xcd - 1) / n_xcd, tile_step = gridDim.x / n_xcd;
   const int tile_end = min(n_tiles, ((int)blockIdx.x % n_xcd + 1) * tiles_per_xcd);
   int tile = ((int)blockIdx.x % n_xcd) * tiles_per_xcd + (int)blockIdx.x / n_xcd;
   if (tile >= tile_end) return;
-#ifdef V3D_FUSED_SKEW
-  // developer experiment: the second half of the grid starts V3D_FUSED_SKEW x 8 k cycles late, so that the two workgroups of a CU
-  // do not walk through the same phases at the same time
-  if (blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < V3D_FUSED_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+
+  // ---- weight ring ------------------------------------------------------------------------------------------------------------
+  // this wave's three 1 KB pieces of the slab at `base` -> ring slot `slot` (hand-written LDS-DMA: M0 carries the LDS address, the
+  // global address is an SGPR base + lane * 16)
+  auto dma_issue = [&](const char* base, int slot) __attribute__((always_inline)) {
+    if (V3D_FUSED_ABLATE == 3 || V3D_FUSED_ABLATE == 9) return;
+    base += wave * (kDPieces * 1024);
+    const unsigned dst = ring_lds + (unsigned)slot * kDSlab + (unsigned)wave * (kDPieces * 1024);
+    const unsigned voff = (unsigned)(threadIdx.x & 63) * 16u;
+    const char* const b1 = base + 1024;
+    const char* const b2 = base + 2048;
+    unsigned m0v;
+    asm volatile(
+        "s_mov_b32 %[m0v], m0\n\t"
+        "s_mov_b32 m0, %[dst]\n\t"
+        "global_load_lds_dwordx4 %[v], %[b0]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %[v], %[b1]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %[v], %[b2]\n\t"
+        "s_mov_b32 m0, %[m0v]"
+        : [m0v] "=&s"(m0v)
+        : [dst] "s"(dst), [b0] "s"(base), [b1] "s"(b1), [b2] "s"(b2), [v] "v"(voff)
+        : "memory", "scc");
+  };
+  const char* const w0 = reinterpret_cast<const char*>(p.w[0]);
+  const char* const w1 = reinterpret_cast<const char*>(p.w[1]);
+  const char* const w2 = reinterpret_cast<const char*>(p.w[2]);
+  // slab of layer-1 step `st`; st = n1, n1 + 1 are the first two steps of the second layer
+  auto slab1 = [&](int st) __attribute__((always_inline)) { return (st < n1 ? w0 : w1) + (size_t)(st < n1 ? st : st - n1) * kDSlab; };
+  int slot = 0;            // ring slot of the current step
+  // The one rendezvous of a step sits in its MIDDLE (between matrix-instruction groups 2 and 3), so that no wave ever starts a step
+  // with empty hands: the slab of step s + 1 was requested in the middle of step s - 1; in the middle of step s this wave's pieces of
+  // it must have landed (WAIT = the number of vector-memory operations the wave has issued since that request: the counter retires
+  // in order), the barrier publishes it -- from group 5 on the wave prefetches the first A fragments of step s + 1 -- and says that
+  // every wave has left step s - 1, whose slot takes the slab of step s + 2 (`next2`; behind the last tile the sequence simply wraps
+  // around: the surplus slabs are never read).
+  auto mid_sync = [&](const char* next2, auto wait) __attribute__((always_inline)) {
+    constexpr int W = decltype(wait)::value;
+    if constexpr (W == 0 || V3D_FUSED_SAFE_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (W == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (W == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(W == 0, "mid_sync: unsupported wait");
+    FPHASE_MARK(6);
+    __syncthreads();
+    FPHASE_MARK(7);
+    dma_issue(next2, slot == 0 ? 2 : slot - 1);
+  };
+  auto step_done = [&]() __attribute__((always_inline)) { slot = slot == 2 ? 0 : slot + 1; };
+  using W0 = std::integral_constant<int, 0>;
+  using W12 = std::integral_constant<int, 12>;
+  using W16 = std::integral_constant<int, 16>;
+
+  // ---- per-lane geometry: re-derived from an opaque copy of threadIdx.x in every tile so that nothing per-lane is hoisted out of
+  // (and kept alive across) the tile loop
+  int lane, g, n, h;                         // consumer view: MFMA column n = lane & 31, k half g = lane >> 5
+  int pcol, ppc;                             // producer view: quad lane >> 2 owns columns pcol and pcol + 16, lane & 3 = 16-byte piece
+  unsigned m_t0, m_t2;                       // tap 0 (h - 1) / tap 2 (h + 1) stays inside the hypothesis group
+  auto refresh_lane_ids = [&]() __attribute__((always_inline)) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    tid = t; lane = t & 63; g = lane >> 5; n = lane & 31; h = n & 7;
+    pcol = lane >> 2; ppc = lane & 3;
+    m_t0 = h >= 1 ? 0xffffffffu : 0u;
+    m_t2 = h + 1 < n_hyp ? 0xffffffffu : 0u;
+  };
+  refresh_lane_ids();
+
+  // The tile's corner table, wave-private in LDS: [level 0..2 | point features][corner][column] (row, weight).  Lane (g, n)
+  // fetches corners 4 g .. 4 g + 3 of the three levels for column n from decoder_corner_kernel's table; the pseudo-level 3 makes the
+  // per-point feature channels of the first layer one more "interpolation": corner 0 = (row of the hypothesis point, 1.0),
+  // corners 1..7 = (0, 0.0).  Invalid columns (hypothesis slot >= n_hyp, point >= n_pts) read row 0 with weight 0 everywhere.
+  auto ctab_load = [&](u32x4 (&ce)[3][2], int tl) __attribute__((always_inline)) {
+    const int pt = tl * kDPtsTile + wave * kDPtsWave + (n >> 3);
+    const bool ok = pt < p.n_pts && h < n_hyp;
+    // (unconditional loads from a clamped address, masked afterwards: a select makes the compiler branch around each load and
+    // wait for it)
+    const unsigned okm = ok ? 0xffffffffu : 0u;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.ctab + ((size_t)(ok ? pt : 0) * n_hyp + (ok ? h : 0)) * 24 + 4 * g);
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ce[l][j] = src[l * 4 + j] & (u32x4){okm, okm, okm, okm};
+  };
+  auto ctab_store = [&](const u32x4 (&ce)[3][2], int tl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ctab[(l * 8 + 4 * g + 2 * j) * 32 + n] = (u32x2){ce[l][j][0], ce[l][j][1]};
+        ctab[(l * 8 + 4 * g + 2 * j + 1) * 32 + n] = (u32x2){ce[l][j][2], ce[l][j][3]};
+      }
+    const int pt = tl * kDPtsTile + wave * kDPtsWave + (n >> 3);
+    const bool ok = pt < p.n_pts && h < n_hyp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * g + j;
+      ctab[(24 + k) * 32 + n] = (k == 0 && ok) ? (u32x2){(unsigned)(pt * n_hyp + h), __float_as_uint(1.f)} : (u32x2){0u, 0u};
+    }
+  };
+
+  // ---- layer-1 producer ----------------------------------------------------------------------------------------------------------
+  // A quad (4 lanes x 16 bytes = 64 contiguous bytes of one feature row: the 16 channels of a K step) per column and load
+  // instruction -- a quad that reads four different rows costs the CU's one vector-memory path four times as much -- two columns
+  // per quad (pcol, pcol + 16), 8 corner rows each: 16 gathers per step and lane, blended in the lane that loaded them, split,
+  // and handed to the consumer's lane layout through a 2 KB wave-private LDS tile.  The gathers form a rotating pipeline one step
+  // deep: in step s, between the matrix instructions, corner k of step s + 1's rows (requested during step s - 1) is consumed and
+  // the same registers immediately request corner k of step s + 2 -- every load has a whole step to land, the loads of a wave
+  // are spread over the step, and 64 registers hold them.
+  struct StepSrc { const char* base; unsigned rowb, cofs; int ct; };            // wave-uniform description of a layer-1 step
+  auto src_of = [&](int u) __attribute__((always_inline)) {
+    StepSrc q;
+    const int l = u < sb1 ? 0 : u < sb2 ? 1 : u < sb3 ? 2 : 3;
+    q.base = reinterpret_cast<const char*>(l == 0 ? p.feats[0] : l == 1 ? p.feats[1] : l == 2 ? p.feats[2] : p.pts_feat);
+    q.rowb = (unsigned)(l == 0 ? p.C[0] : l == 1 ? p.C[1] : l == 2 ? p.C[2] : p.c_feat) * 4u;
+    q.cofs = (unsigned)(u - (l == 0 ? 0 : l == 1 ? sb1 : l == 2 ? sb2 : sb3)) * 64u;
+    q.ct = l * 256;
+    return q;
+  };
+  f32x4 gx[8][2];          // [corner][column half]
+  f32x4 pa0, pa1;          // the two columns' blends in progress
+  auto prod_issue = [&](int k, const StepSrc& q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned row = ctab[q.ct + k * 32 + pcol + 16 * c][0];
+      // (rows and row pitches fit 24 bits -- checked on the host -- so the product is a full-rate v_mad_u32_u24)
+      const unsigned off = __umul24(V3D_FUSED_ABLATE == 2 ? (row & 7u) : row, q.rowb) + q.cofs + (unsigned)ppc * 16u;
+#if V3D_FUSED_ABLATE == 6 || V3D_FUSED_ABLATE == 8 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 10   // timing experiment: no gathers
+      gx[k][c] = (f32x4){__uint_as_float(off), 0.f, 0.f, 0.f};
+#else
+      gx[k][c] = *reinterpret_cast<const f32x4*>(q.base + (size_t)off);
 #endif
+    }
+  };
+  auto prod_consume = [&](int k, const StepSrc& q) __attribute__((always_inline)) {
+    // corner order x fastest; absent corners add nothing (no renormalisation)
+    const float wa = __uint_as_float(ctab[q.ct + k * 32 + pcol][1]), wb = __uint_as_float(ctab[q.ct + k * 32 + pcol + 16][1]);
+    pa0 = __builtin_elementwise_fma(gx[k][0], (f32x4){wa, wa, wa, wa}, pa0);
+    pa1 = __builtin_elementwise_fma(gx[k][1], (f32x4){wb, wb, wb, wb}, pa1);
+  };
+  // the finished blends -> split -> the consumer layout: piece ppc = 2 j + g' holds the channels 8 j + 4 g' .. + 3 of the step, i.e.
+  // half j of the B fragment of lane (g', column)
+  auto prod_finalize = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4 a = c == 0 ? pa0 : pa1;
+      const unsigned h01 = fused_pack_bf16x2(a.x, a.y), h23 = fused_pack_bf16x2(a.z, a.w);
+      const unsigned l01 = fused_pack_bf16x2(a.x - __uint_as_float(h01 << 16), a.y - __uint_as_float(h01 & 0xffff0000u));
+      const unsigned l23 = fused_pack_bf16x2(a.z - __uint_as_float(h23 << 16), a.w - __uint_as_float(h23 & 0xffff0000u));
+      unsigned char* const d = stage + (((ppc & 1) * 32 + pcol + 16 * c) * 16 + (ppc >> 1) * 8);
+      *reinterpret_cast<u32x2*>(d) = (u32x2){h01, h23};
+      *reinterpret_cast<u32x2*>(d + 1024) = (u32x2){l01, l23};
+    }
+    pa0 = pa1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto prod_fetch = [&](u32x4& xh, u32x4& xl) __attribute__((always_inline)) {
+#if V3D_FUSED_FETCH64 == 0
+    // 8-byte reads, waited for in place: a 16-byte LDS read whose result feeds VECTOR instructions (here the DPP shifts of the next
+    // step) has returned the registers' previous contents in some lanes when matrix instructions were in flight on the SIMD (the
+    // round-3 hazard of the corner table; reproduced in round 5 with this very read: a few points per launch kept
+    // the previous step's B fragment); the A fragments -- 16-byte reads consumed by matrix instructions -- are not affected.
+    const unsigned sa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)stage + (unsigned)lane * 16u;
+    u32x2 h0, h1, l0, l1;
+    asm volatile(
+        "ds_read_b64 %0, %4\n\t"
+        "ds_read_b64 %1, %4 offset:8\n\t"
+        "ds_read_b64 %2, %4 offset:1024\n\t"
+        "ds_read_b64 %3, %4 offset:1032\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+        : "v"(sa)
+        : "memory");
+    xh = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+    xl = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+#else
+    xh = *reinterpret_cast<const u32x4*>(stage + lane * 16);
+    xl = *reinterpret_cast<const u32x4*>(stage + 1024 + lane * 16);
+#endif
+  };
+
+  // ---- one K step: 3 taps x 4 row blocks x (hi*hi, hi*lo, lo*hi) on the slab in ring slot `slot`, as six groups of six matrix
+  // instructions; hook(i) runs behind group i (the producer's share of the step)
+  f32x16 acc[4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  };
+  // A fragments of group (t, mp): row blocks 2 mp, 2 mp + 1, hi and lo.  The next group's are requested before this group's matrix
+  // instructions (an LDS round trip per group in front of them otherwise); group 5 requests group 0 of the NEXT step's slab,
+  // published by this step's rendezvous.
+  u32x4 af[2][4];
+  auto load_a = [&](u32x4 (&a)[4], int sl, int t, int mp, const u32x4 xh, const u32x4 xl) __attribute__((always_inline)) {
+    const u32x4* const slab = reinterpret_cast<const u32x4*>(smem + sl * kDSlab) + lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#if V3D_FUSED_ABLATE == 10        // timing experiment: no A-fragment reads either
+      a[j] = xh; a[2 + j] = xl;
+#else
+      a[j] = slab[((t * 2 + 0) * 4 + 2 * mp + j) * 64];
+      a[2 + j] = slab[((t * 2 + 1) * 4 + 2 * mp + j) * 64];
+#endif
+    }
+  };
+  auto mma_step = [&](const u32x4 xh, const u32x4 xl, auto hook, auto mid) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      u32x4 th = xh, tl = xl;
+      if (t != 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          th[q] = (t == 0 ? fused_row_shr1(xh[q]) : fused_row_shl1(xh[q])) & (t == 0 ? m_t0 : m_t2);
+          tl[q] = (t == 0 ? fused_row_shr1(xl[q]) : fused_row_shl1(xl[q])) & (t == 0 ? m_t0 : m_t2);
+        }
+      }
+      const bf16x8 b_hi = __builtin_bit_cast(bf16x8, th), b_lo = __builtin_bit_cast(bf16x8, tl);
+#pragma unroll
+      for (int mp = 0; mp < 2; ++mp) {
+        const int grp = t * 2 + mp;
+        if (grp < 5) load_a(af[(grp + 1) & 1], slot, (grp + 1) >> 1, (grp + 1) & 1, xh, xl);
+        else load_a(af[0], slot == 2 ? 0 : slot + 1, 0, 0, xh, xl);
+        __builtin_amdgcn_sched_barrier(0);     // (the requests stay in front of the matrix instructions)
+        const u32x4 (&a)[4] = af[grp & 1];
+#if V3D_FUSED_ABLATE == 1 || V3D_FUSED_ABLATE == 8 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 10
+        asm volatile("" : : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b_hi), "v"(b_lo));
+#else
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[2 * mp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), b_hi, acc[2 * mp + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[2 * mp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), b_lo, acc[2 * mp + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[2 * mp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[2 + j]), b_hi, acc[2 * mp + j], 0, 0, 0);
+#endif
+        hook(std::integral_constant<int, 0>{}, grp);
+        if (grp == 2) mid();
+        __builtin_amdgcn_sched_barrier(0);     // the producer's loads stay where they are written: spread over the step
+      }
+    }
+  };
+  auto no_hook = [](auto, int) __attribute__((always_inline)) {};
+  // the producer's share of a step: groups 0..3 turn over two corners each (consume step `cu`'s rows, request step `iu`'s),
+  // group 4 stages the finished B fragment, group 5 fetches it in the consumer layout
+  u32x4 bh, bl;            // B fragment (hi, lo) of the layer-1 step about to run
+  u32x4 bhn, bln;
+  auto prod_hook = [&](const StepSrc& cs, const StepSrc& is, bool consume) __attribute__((always_inline)) {
+    return [&, consume](auto, int grp) __attribute__((always_inline)) {
+      if (grp < 4) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = 2 * grp + kk;
+          if (consume) prod_consume(k, cs);
+          prod_issue(k, is);
+        }
+      } else if (grp == 4) {
+        if (consume) prod_finalize();
+      } else {
+        if (consume) prod_fetch(bhn, bln);
+      }
+    };
+  };
+  // bias + ReLU of the accumulator tile -> the 8 B fragments (hi, lo) of the next 128 -> 128 layer
+  u32x4 ah[8], al[8];
+  auto next_layer_operands = [&](int layer) __attribute__((always_inline)) {
+    const float* const bs = cbias + layer * kDH + g * 16;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float bq[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bs + mb * 32 + q * 4);
+        bq[4 * q] = b4.x; bq[4 * q + 1] = b4.y; bq[4 * q + 2] = b4.z; bq[4 * q + 3] = b4.w;
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[mb][8 * pp + e] + bq[8 * pp + e], 0.f);
+        fused_split8(v, ah[2 * mb + pp], al[2 * mb + pp]);
+      }
+    }
+  };
+
+  // ---- prologue: the first two slabs, the first tile's corner table, the producer pipeline primed for steps 0 and 1 --------------
+  dma_issue(slab1(0), 0);
+  dma_issue(slab1(1), 1);
   {
-    Probe c;
-    ct_points(c, tile);
-    load_a(a_ring[0], p.w[0], p.nkc1, 0, 0);
-    load_a(a_ring[1], p.w[0], p.nkc1, 1, 0);
-    ct_mins(c);
-    ct_keys(c);
-    ct_probe(c);
-    ct_values(c);
+    u32x4 ce[3][2];
+    ctab_load(ce, tile);
+    ctab_store(ce, tile);
   }
+  pa0 = pa1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const StepSrc s0 = src_of(0), s1 = src_of(min(1, n1 - 1));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) prod_issue(k, s0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { prod_consume(k, s0); prod_issue(k, s1); }
+    prod_finalize();
+    prod_fetch(bh, bl);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // both slabs (and the rows of step 1) have landed
+  __syncthreads();                                      // ... in every wave; cbias / chead / cmisc visible
+  load_a(af[0], 0, 0, 0, bh, bl);
+
 #pragma unroll 1
   for (; tile < tile_end; tile += tile_step) {
     refresh_lane_ids();
-    pt0 = tile * npt;
-    q0 = (long long)pt0 * n_hyp;
-    has_next = tile + tile_step < tile_end;
-    // every wave is past the barrier behind layer 3 of the previous tile: the second buffer (staging tiles, corner table) is free
-    if (tid < 2 * 2 * 4) xq[(tid >> 3) * kFStageSlots + (((tid >> 2) & 1) * kFRT + kFZero) * 4 + (tid & 3)] = (u32x4){0u, 0u, 0u, 0u};
-    ct_store();
+    const bool has_next = tile + tile_step < tile_end;
     zero_acc();
-    __syncthreads();                         // corner table ready
     FPHASE_MARK(0);
-    issue_lv(0, -1);
-    commit_lv(0);
-    __syncthreads();
-    FPHASE_MARK(1);
-    // chunk kc: its staging tile is complete; the next chunk's gathers fly during this chunk's MFMAs and are committed to the
-    // OTHER staging tile behind them (last read by chunk kc - 1, which every wave finished before the barrier in front of chunk
-    // kc): one barrier per chunk
-#pragma unroll 1
-    for (int kc = 0; kc < nkc_lv; ++kc) {
-#if V3D_FUSED_ABLATE == 8
-      if (kc + 1 < nkc_lv) issue_lv(kc + 1, -1);
-      else if (nkc_lv < p.nkc1) issue_feat(nkc_lv);
-      FPHASE_FINE(1);
-      mfma_chunk(kc, [&](int) __attribute__((always_inline)) {});
-#else
-      if (kc + 1 >= nkc_lv && nkc_lv < p.nkc1) issue_feat(nkc_lv);
-      FPHASE_FINE(1);
-      mfma_chunk(kc, [&](int t) __attribute__((always_inline)) {
-        if (kc + 1 < nkc_lv) issue_lv(kc + 1, t);
-      });
-#endif
-      FPHASE_MARK(2);
-      if (kc + 1 < nkc_lv) commit_lv(kc + 1);
-      else if (nkc_lv < p.nkc1) commit_feat(nkc_lv);
-      FPHASE_FINE(5);
-      __syncthreads();
-      FPHASE_FINE(6);
-      FPHASE_MARK(1);
-    }
-#pragma unroll 1
-    for (int kc = nkc_lv; kc < p.nkc1; ++kc) {
-      if (kc + 1 < p.nkc1) issue_feat(kc + 1);
-      FPHASE_FINE(1);
-      mfma_chunk(kc, [&](int) __attribute__((always_inline)) {});
-      FPHASE_MARK(2);
-      if (kc + 1 < p.nkc1) commit_feat(kc + 1);
-      FPHASE_FINE(5);
-      __syncthreads();
-      FPHASE_FINE(6);
-      FPHASE_MARK(1);
-    }
-    // (the fp32 output of the previous tile's last layer covered the zero row of the first buffer)
-    if (tid < 2 * 16) actA[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
-    store_act(actA, cbias);
-    if (tid < 2 * 16) actB[((tid >> 4) * kFRT + kFZero) * 16 + (tid & 15)] = (u32x4){0u, 0u, 0u, 0u};
-    __syncthreads();        // act1 complete; staging tiles / corner table (aliasing the second buffer) no longer needed
-    FPHASE_MARK(3);
 
-    // ---- layers 2 and 3: K = 3 taps x 128 channels read from LDS; the next tile's corner table is looked up on the side ------------
-    const int next_tile = tile + tile_step;
-    Probe c;
+    // ---- layer 1: every step consumes the rows of the next step and requests those of the step after next (clamped to the last
+    // step at the end: the surplus B fragments are never used) -- 16 gathers per step, hence the 16 of the rendezvous ------------
+#pragma unroll 1
+    for (int s = 0; s < n1; ++s) {
+      const StepSrc cs = src_of(min(s + 1, n1 - 1)), is = src_of(min(s + 2, n1 - 1));
+      const char* const nx = slab1(s + 2);
+      mma_step(bh, bl, prod_hook(cs, is, true), [&]() __attribute__((always_inline)) { mid_sync(nx, W16{}); });
+      bh = bhn; bl = bln;
+      step_done();
+      FPHASE_MARK(1);
+    }
+
+    // ---- layers 2 and 3: B fragments straight from the accumulators; the next tile's corner table is fetched on the side (late in
+    // layer 2, when half of its B fragments are dead) -----------------------------------------------------------------------------
+    next_layer_operands(0);
     zero_acc();
-    dense_layer(1, actA, [&](int kc) __attribute__((always_inline)) {
-      if (has_next && kc == 0) ct_points(c, next_tile);
-      if (has_next && kc == 2) ct_mins(c);
-    });
-    FPHASE_MARK(4);
-    if (V3D_FUSED_ABLATE != 5) {
-      store_act(actB, cbias + kFH);
-      __syncthreads();
-      FPHASE_MARK(3);
-      zero_acc();
-      dense_layer(2, actB, [&](int kc) __attribute__((always_inline)) {
-        if (has_next && kc == 0) ct_keys(c);
-        if (has_next && kc == 1) ct_probe(c);
-        if (has_next && kc == 3) ct_values(c);
-      });
-      FPHASE_MARK(5);
-    }
-    {
-      // last layer: fp32 [64 rows][128] into the first buffer (act1 is dead: every wave passed the barrier after layer 2)
-      float* const of = reinterpret_cast<float*>(actA);
-#pragma unroll
-      for (int nb = 0; nb < kFNB; ++nb)
-#pragma unroll
-        for (int mw = 0; mw < kFMBW; ++mw) {
-          const int co0 = (wave * kFMBW + mw) * 16 + kq * 4;
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(cbias + 2 * kFH + co0);
-          f32x4 v;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[nb][mw][k] + bq[k], 0.f);
-          *reinterpret_cast<f32x4*>(of + ((cb0 + nb) * 16 + jn) * kFH + co0) = v;
-        }
-    }
-    __syncthreads();
     FPHASE_MARK(3);
-
-    // ---- head: Conv1d(128 -> 1, k3, pad 1, bias) over the hypotheses, softmax, expectation (32 lanes per point) ----------------
     {
-      const float* const of = reinterpret_cast<const float*>(actA);
-      float score[8], hw0[4], hw1[4], hw2[4];
+      u32x4 ce[3][2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { hw0[k] = chead[(hc0 + k) * 3]; hw1[k] = chead[(hc0 + k) * 3 + 1]; hw2[k] = chead[(hc0 + k) * 3 + 2]; }
-      const float head_b = chead[3 * kFH];
-      // (32 lanes per point, kFThreads / 32 points per pass: a tile of 9 points takes a second pass for its last one)
-#pragma unroll 1
-      for (int hp = hpt; hp < npt; hp += kFThreads / 32) {
+      for (int s = 0; s < 8; ++s) {
+        const char* const nx = s + 2 < 8 ? w1 + (size_t)(s + 2) * kDSlab : w2 + (size_t)(s + 2 - 8) * kDSlab;
+        if (s == 4 && has_next) ctab_load(ce, tile + tile_step);
+        mma_step(ah[s], al[s], no_hook, [&]() __attribute__((always_inline)) { mid_sync(nx, W0{}); });
+        if (s == 5 && has_next) ctab_store(ce, tile + tile_step);       // (fetched during step 4: landed, by the vmcnt(0) of step 5)
+        step_done();
+        FPHASE_MARK(4);
+      }
+    }
+    next_layer_operands(1);
+    zero_acc();
+    FPHASE_MARK(3);
+    {
+      // steps 6 and 7 prime the producer for the next tile: step 6 requests the rows of its step 0, step 7 consumes them, requests
+      // those of its step 1 and leaves the B fragment of its step 0 in (bh, bl)
+      const StepSrc s0 = src_of(0), s1 = src_of(min(1, n1 - 1));
 #pragma unroll
-      for (int h = 0; h < 8; ++h) score[h] = 0.f;
+      for (int s = 0; s < 8; ++s) {
+        const char* const nx = s + 2 < 8 ? w2 + (size_t)(s + 2) * kDSlab : w0 + (size_t)(s + 2 - 8) * kDSlab;
+        if (s == 6) mma_step(ah[s], al[s], prod_hook(s0, s0, false), [&]() __attribute__((always_inline)) { mid_sync(nx, W12{}); });
+        else if (s == 7) mma_step(ah[s], al[s], prod_hook(s0, s1, true), [&]() __attribute__((always_inline)) { mid_sync(nx, W16{}); });
+        else mma_step(ah[s], al[s], no_hook, [&]() __attribute__((always_inline)) { mid_sync(nx, W0{}); });
+        step_done();
+        FPHASE_MARK(5);
+      }
+      bh = bhn; bl = bln;
+    }
+
+    // ---- head: Conv1d(128 -> 1, k3, pad 1, bias) over the hypotheses, softmax, expectation ------------------------------------
+    {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      const float* const bs = cbias + 2 * kDH + g * 16;
+      const float* const hw = chead + g * 16;
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        if (h < n_hyp) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(of + (hp * n_hyp + h) * kFH + hc0);
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bs + mb * 32 + q * 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(hw + mb * 32 + q * 4);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(hw + kDH + mb * 32 + q * 4);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(hw + 2 * kDH + mb * 32 + q * 4);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            // out[h'] = sum_t in[h' + t - 1] w[t]  =>  in[h] feeds out[h+1] (t=0), out[h] (t=1), out[h-1] (t=2)
-            if (h + 1 < 8) score[h + 1] += x[k] * hw0[k];
-            score[h] += x[k] * hw1[k];
-            if (h > 0) score[h - 1] += x[k] * hw2[k];
+            const float y = fmaxf(acc[mb][4 * q + k] + b4[k], 0.f);
+            s0 = fmaf(y, w0[k], s0); s1 = fmaf(y, w1[k], s1); s2 = fmaf(y, w2[k], s2);
           }
         }
-      }
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      // out[h] = in[h - 1] w[0] + in[h] w[1] + in[h + 1] w[2]
+      float sc = s1 + __uint_as_float(fused_row_shr1(__float_as_uint(s0)) & m_t0) +
+                 __uint_as_float(fused_row_shl1(__float_as_uint(s2)) & m_t2) + cmisc[0];
+      const bool hyp_ok = h < n_hyp;
+      if (!hyp_ok) sc = -INFINITY;
+      float m = sc;
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        float v = score[h];
+      for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+      const float ex = hyp_ok ? expf(sc - m) : 0.f;
+      float sum = ex;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        score[h] = v + head_b;
-      }
-      if (hl32 == 0 && pt0 + hp < p.n_pts) {
-        float m = -INFINITY;
+      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+      const float pr = ex / sum;
+      float e = cmisc[4 + h] * pr;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) if (h < n_hyp) m = fmaxf(m, score[h]);
-        float ex[8], sum = 0.f;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {                 // every exponential once; same values, same summation order as before
-          ex[h] = h < n_hyp ? expf(score[h] - m) : 0.f;
-          if (h < n_hyp) sum += ex[h];
-        }
-        float e = 0.f;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          if (h < n_hyp) {
-            const float pr = ex[h] / sum;
-            p.preds[(size_t)(pt0 + hp) * n_hyp + h] = pr;
-            e += chead[3 * kFH + 4 + h] * pr;         // (offset values parked in LDS: a global load per hypothesis sat in this chain)
-          }
-        }
-        if (p.expect) p.expect[pt0 + hp] = e;
-      }
+      for (int o = 1; o < 8; o <<= 1) e += __shfl_xor(e, o);
+      const int pt = tile * kDPtsTile + wave * kDPtsWave + (n >> 3);
+      if (g == 0 && pt < p.n_pts) {
+        if (hyp_ok) p.preds[(size_t)pt * n_hyp + h] = pr;
+        if (h == 0 && p.expect) p.expect[pt] = e;
       }
     }
-    FPHASE_MARK(6);
-    // the next tile's first writes into the second buffer are safe (every wave passed the barrier behind layer 3); its writes into
-    // the first buffer (activation stores of layer 1) come several barriers after this tile's head reads
+    FPHASE_MARK(2);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may be in flight when the workgroup's LDS is released
   FPHASE_FLUSH;
 }
 }  // namespace
@@ -783,12 +685,10 @@ extern "C" int v3d_debug_fused_phase_read(unsigned long long* out8_host, int n_b
 }
 #endif
 
-#ifdef V3D_FUSED_DEBUG
-static float* g_fused_dbg_x = nullptr;
-static unsigned* g_fused_dbg_wg = nullptr;
-extern "C" void v3d_debug_fused_dump(float* x) { g_fused_dbg_x = x; }
-extern "C" void v3d_debug_fused_dump_wg(unsigned* x) { g_fused_dbg_wg = x; }
-#endif
+extern "C" size_t v3d_decoder_fused_workspace_bytes(int n_pts, int n_hyp) {
+  if (n_pts <= 0 || n_hyp <= 0) return 256;
+  return (size_t)n_pts * (size_t)n_hyp * 24 * sizeof(u32x2) + 256;
+}
 
 extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const float* head_weight,
                                      const float* head_bias, const void* const* level_table_host,
@@ -797,70 +697,81 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
                                      const float* const* level_min_pts_host, const float* level_res_host,
                                      const float* pts, const int64_t* pts_batch, const float* pts_feat, int c_feat,
                                      int n_pts, int n_hyp, const float* offset_vals, float* preds, float* expect,
-                                     void* stream) {
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(layers_host && head_weight && head_bias && level_table_host && level_n_host && level_feats_host &&
                   level_C_host && level_stride_host && level_min_pts_host && level_res_host && pts && pts_batch && preds,
               V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: null argument");
   V3D_REQUIRE(n_pts >= 0 && n_hyp >= 1 && n_hyp <= 8, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: n_hyp=%d (1..8)", n_hyp);
-  V3D_REQUIRE(c_feat >= 0 && c_feat % 32 == 0 && (c_feat == 0 || pts_feat), V3D_ERR_UNSUPPORTED,
-              "v3d_decoder_fused_f32: c_feat=%d must be a multiple of 32 (with pts_feat given)", c_feat);
+  // (24-bit row indices in the kernel's gather addresses)
+  V3D_REQUIRE((long long)n_pts * n_hyp < (1ll << 24), V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: n_pts=%d too large for one call", n_pts);
+  V3D_REQUIRE(c_feat >= 0 && c_feat % 16 == 0 && (c_feat == 0 || pts_feat), V3D_ERR_UNSUPPORTED,
+              "v3d_decoder_fused_f32: c_feat=%d must be a multiple of 16 (with pts_feat given)", c_feat);
   V3D_REQUIRE(!expect || offset_vals, V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: expect without offset_vals");
+  V3D_REQUIRE(workspace && workspace_bytes >= v3d_decoder_fused_workspace_bytes(n_pts, n_hyp), V3D_ERR_WORKSPACE_TOO_SMALL,
+              "v3d_decoder_fused_f32: workspace of %zu bytes, need %zu", workspace_bytes,
+              v3d_decoder_fused_workspace_bytes(n_pts, n_hyp));
+  V3D_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0 && (!pts_feat || (reinterpret_cast<size_t>(pts_feat) & 15) == 0),
+              V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: workspace / pts_feat must be 16-byte aligned");
   FusedParams p;
+  CornerParams cp;
   memset(&p, 0, sizeof(p));
+  memset(&cp, 0, sizeof(cp));
   int k1 = c_feat;
   for (int l = 0; l < 3; ++l) {
     V3D_REQUIRE(level_table_host[l] && level_feats_host[l] && level_min_pts_host[l] && level_n_host[l] > 0 &&
-                    level_C_host[l] > 0 && level_C_host[l] % 32 == 0 && level_stride_host[l] > 0 && level_res_host[l] > 0.f,
-                V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: level %d (channels must be a multiple of 32)", l);
-    p.lv[l].table = v3dhash::table_view(const_cast<void*>(level_table_host[l]), level_n_host[l]);
-    p.lv[l].feats = level_feats_host[l]; p.lv[l].min_pts = level_min_pts_host[l]; p.lv[l].res = level_res_host[l];
-    p.lv[l].C = level_C_host[l]; p.lv[l].ts = level_stride_host[l];
+                    level_C_host[l] > 0 && level_C_host[l] % 16 == 0 && level_stride_host[l] > 0 && level_res_host[l] > 0.f,
+                V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: level %d (channels must be a multiple of 16)", l);
+    V3D_REQUIRE((reinterpret_cast<size_t>(level_feats_host[l]) & 15) == 0, V3D_ERR_BAD_ARG,
+                "v3d_decoder_fused_f32: level %d features must be 16-byte aligned", l);
+    // (the kernel addresses a level's rows with 32-bit byte offsets)
+    V3D_REQUIRE((long long)level_n_host[l] * level_C_host[l] * 4 < (1ll << 31) && level_n_host[l] < (1 << 24), V3D_ERR_UNSUPPORTED,
+                "v3d_decoder_fused_f32: level %d holds %d x %d floats (2 GB limit)", l, level_n_host[l], level_C_host[l]);
+    cp.table[l] = v3dhash::table_view(const_cast<void*>(level_table_host[l]), level_n_host[l]);
+    cp.min_pts[l] = level_min_pts_host[l]; cp.res[l] = level_res_host[l]; cp.ts[l] = level_stride_host[l];
+    p.feats[l] = level_feats_host[l]; p.C[l] = level_C_host[l];
     k1 += level_C_host[l];
   }
   for (int l = 0; l < 3; ++l) {
     const v3d_gemm_weights* h = layers_host[l];
-    V3D_REQUIRE(h && h->n_seg == 3 && h->N == kFH && h->MBW == kFMBW && h->has_bias && h->K == (l == 0 ? k1 : kFH) &&
-                    h->KP == h->K,
+    V3D_REQUIRE(h && h->n_seg == 3 && h->N == kDH && h->has_bias && h->K == (l == 0 ? k1 : kDH) && h->dec_ofs != 0,
                 V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: layer %d must be a packed Conv1d(k3) %d -> 128 with bias", l,
-                l == 0 ? k1 : kFH);
-    p.w[l] = h->dev + h->bf_ofs;
+                l == 0 ? k1 : kDH);
+    p.w[l] = h->dev + h->dec_ofs;
     p.bias[l] = h->dev + h->bias_ofs;
   }
-  p.nkc1 = k1 / 32;
-  p.pts = pts; p.pts_batch = (const long long*)pts_batch; p.pts_feat = pts_feat; p.c_feat = c_feat;
-  p.n_pts = n_pts; p.n_hyp = n_hyp;
+  p.nstep1 = k1 / 16;
+  V3D_REQUIRE(p.nstep1 >= 2, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: the first layer needs at least 32 input channels");
+  p.ctab = reinterpret_cast<const u32x2*>(workspace);
+  p.pts_feat = pts_feat; p.c_feat = c_feat; p.n_pts = n_pts; p.n_hyp = n_hyp;
   p.head_w = head_weight; p.head_b = head_bias; p.vals = offset_vals; p.preds = preds; p.expect = expect;
-#ifdef V3D_FUSED_DEBUG
-  p.dbg_x = g_fused_dbg_x;
-  p.dbg_wg = g_fused_dbg_wg;
-#endif
+  cp.pts = pts; cp.pts_batch = (const long long*)pts_batch; cp.n_hyp = n_hyp; cp.n_q = n_pts * n_hyp;
+  cp.out = reinterpret_cast<u32x2*>(workspace);
   if (n_pts == 0) return V3D_OK;
   hipStream_t s = (hipStream_t)stream;
-  // developer switch (scripts/micro/fused_decoder_stress.py): dynamic LDS request in KB
-  static const size_t lds_bytes = getenv("V3D_FUSED_LDS_KB") ? (size_t)atoi(getenv("V3D_FUSED_LDS_KB")) * 1024 : kFLdsBytes;
-  V3D_REQUIRE(lds_bytes >= kFUsedLdsBytes && lds_bytes <= 160 * 1024, V3D_ERR_BAD_ARG, "V3D_FUSED_LDS_KB out of range");
-  // per device: the dynamic-LDS opt-in and the number of workgroups the device holds at once (160 KB / lds_bytes per CU)
+  // per device: the dynamic-LDS opt-in and the number of CUs (one workgroup each)
   static int resident_of[64] = {0};
   int dev = 0;
   V3D_CHECK_HIP(hipGetDevice(&dev));
   V3D_REQUIRE(dev >= 0 && dev < 64, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: device ordinal %d", dev);
   if (!resident_of[dev]) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds_bytes));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)decoder_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDLdsBytes));
     int n_cu = 0;
     V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int per_cu = getenv("V3D_FUSED_WG_PER_CU") ? atoi(getenv("V3D_FUSED_WG_PER_CU")) : (int)(160 * 1024 / lds_bytes);
-    resident_of[dev] = (n_cu > 0 ? n_cu : 256) * (per_cu > 0 ? per_cu : 1);
+    resident_of[dev] = n_cu > 0 ? n_cu : 256;
   }
-  const int resident = resident_of[dev];
   {
-    // persistent tile walk: workgroup b takes tiles b, b + grid, ... (equal work per tile, so a static split is balanced)
-    const int npt = kFRows / n_hyp;                    // as in the kernel
-    const int n_tiles = (n_pts + npt - 1) / npt;
+    v3d::TimedScope ts("decoder_corners", s);
+    const long long n_thr = (long long)cp.n_q * 8;
+    decoder_corner_kernel<<<(unsigned)((n_thr + 255) / 256), 256, 0, s>>>(cp);
+  }
+  V3D_CHECK_LAUNCH("decoder_corner_kernel");
+  {
+    // persistent tile walk: workgroup b takes tiles b, b + grid, ... of its XCD's share (equal work per tile)
+    const int n_tiles = (n_pts + kDPtsTile - 1) / kDPtsTile;
+    const int resident = resident_of[dev];
     v3d::TimedScope ts("decoder_fused", s);
-    decoder_fused_kernel<<<n_tiles < resident ? n_tiles : resident, kFThreads, lds_bytes, s>>>(p);
+    decoder_fused_kernel<<<n_tiles < resident ? n_tiles : resident, kDThreads, kDLdsBytes, s>>>(p);
   }
   V3D_CHECK_LAUNCH("decoder_fused_kernel");
   return V3D_OK;
 }
-

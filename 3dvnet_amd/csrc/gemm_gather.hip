@@ -711,6 +711,34 @@ extern "C" int v3d_gemm_pack(const float* w_host, long long stride_seg, long lon
             }
           }
   }
+  h->dec_ofs = 0;
+  if (n_seg == 3 && N == 128 && K % 16 == 0) {
+    const int nst = K / 16;
+    h->dec_ofs = host.size();
+    host.resize(h->dec_ofs + (size_t)nst * 24 * 256, 0.f);
+    unsigned* wb = reinterpret_cast<unsigned*>(host.data() + h->dec_ofs);
+    auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int st = 0; st < nst; ++st)
+      for (int t = 0; t < 3; ++t)
+        for (int mb = 0; mb < 4; ++mb)
+          for (int lane = 0; lane < 64; ++lane) {
+            unsigned hi[8], lo[8];
+            const int co = mb * 32 + (lane & 31), g = lane >> 5;
+            for (int e = 0; e < 8; ++e) {
+              const int k = 16 * st + 8 * (e >> 2) + 4 * g + (e & 3);
+              float v = w_host[t * stride_seg + co * stride_co + k * stride_k];
+              if (scale_host) v *= scale_host[co];
+              hi[e] = rne(v);
+              lo[e] = rne(v - up(hi[e]));
+            }
+            for (int part = 0; part < 2; ++part) {
+              const unsigned* src = part ? lo : hi;
+              unsigned* dst = wb + ((((size_t)st * 3 + t) * 2 + part) * 4 + mb) * 256 + (size_t)lane * 4;
+              for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+            }
+          }
+  }
   h->has_bias = bias_host != nullptr;
   h->has_gn = gn_w_host != nullptr && gn_b_host != nullptr;
   for (int i = 0; i < N; ++i) {

@@ -114,7 +114,7 @@ class HypothesisDecoder(nn.Module):
         channels, level / point-feature widths that are multiples of 32, at most 8 hypotheses, split-bf16 operands."""
         cf = 0 if pts_feat is None else pts_feat.shape[2]
         return (self.fused and self.precision == 'split_bf16' and self.h_dim == 128 and len(xs) == 3 and pts.shape[1] <= 8
-                and cf % 32 == 0 and all(x['feats'].shape[1] % 32 == 0 for x in xs)
+                and cf % 16 == 0 and all(x['feats'].shape[1] % 16 == 0 for x in xs)
                 and sum(x['feats'].shape[1] for x in xs) + cf == self.in_dim)
 
     def decode_fused(self, xs, pts, pts_feat, pts_batch, offset_vals=None):
@@ -154,10 +154,11 @@ class HypothesisDecoder(nn.Module):
         if offset_vals is not None:
             offset_vals = offset_vals.to(dev).float().contiguous()
             expect = torch.empty(n_pts, dtype=torch.float32, device=dev)
+        ws = self._ws.get('fused', lib.v3d_decoder_fused_workspace_bytes(n_pts, n_hyp), dev)
         rc = lib.v3d_decoder_fused_f32(layers, w_last.data_ptr(), b_last.data_ptr(), tables, n_in, feats, chans, strides,
                                        mins, res, pts.data_ptr(), pts_batch.data_ptr(), _lib.ptr(pts_feat), cf, n_pts,
                                        n_hyp, _lib.ptr(offset_vals), preds.data_ptr(), _lib.ptr(expect),
-                                       _lib.stream_ptr(dev))
+                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, 'v3d_decoder_fused_f32')
         return preds if expect is None else (preds, expect)
 

@@ -339,22 +339,26 @@ int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* feat
 
 /* Rows C2a + C2b + C3 fused: MinkowskiInterpolation of the three U-Net levels at the hypothesis
  * points (mv3d/subnetworks/refinement.py:28-41) -> the three Conv1d+BN+ReLU layers along the hypothesis axis (:16-23) ->
- * Conv1d(128 -> 1) + softmax (:24,43) -> expected offset (mv3d/lightningmodel.py:237-241) in ONE kernel: the
+ * Conv1d(128 -> 1) + softmax (:24,43) -> expected offset (mv3d/lightningmodel.py:237-241): one index kernel (the 8 lattice
+ * corners of every hypothesis point on the three levels -> (row, weight) pairs in `workspace`) and ONE matrix kernel; the
  * [n_pts, C, n_hyp] feature tensor and the intermediate activations never reach HBM.  Split-bf16 MFMA operands
  * (V3D_PRECISION_SPLIT_BF16; for exact fp32 use v3d_sparse_interp_f32 + v3d_gemm_gather_f32 + v3d_decoder_head_f32).
  *   layers_host   3 handles from v3d_gemm_pack: Conv1d weights [128, Cin, 3] (strides 1, 3*Cin, 3; n_seg 3) with the folded
  *                 BatchNorm scale / bias; Cin = sum of the level widths + c_feat for the first, 128 for the others
  *   level_*_host  HOST arrays of 3 entries in feature-row order (finest level first, refinement.py:41): hash table
- *                 (v3d_hash_build) and its row count, feats [N, C] (C a multiple of 32), tensor stride, per-batch minimum
- *                 point [n_batch, 3] (refinement.py:33), x.res
- *   pts [n_pts, n_hyp, 3], pts_batch [n_pts] int64, pts_feat [n_pts, n_hyp, c_feat] or NULL (c_feat 0), n_hyp <= 8
- *   head_weight [1, 128, 3], head_bias [1]; offset_vals [n_hyp] or NULL; preds [n_pts, n_hyp]; expect [n_pts] or NULL */
+ *                 (v3d_hash_build) and its row count, feats [N, C] (C a multiple of 16, 16-byte aligned, N*C*4 < 2 GB), tensor
+ *                 stride, per-batch minimum point [n_batch, 3] (refinement.py:33), x.res
+ *   pts [n_pts, n_hyp, 3], pts_batch [n_pts] int64, pts_feat [n_pts, n_hyp, c_feat] or NULL (c_feat 0 or a multiple of 16),
+ *   n_hyp <= 8; head_weight [1, 128, 3], head_bias [1]; offset_vals [n_hyp] or NULL; preds [n_pts, n_hyp]; expect [n_pts] or NULL
+ *   workspace     v3d_decoder_fused_workspace_bytes(n_pts, n_hyp) bytes, 16-byte aligned (ABI version 3) */
+size_t v3d_decoder_fused_workspace_bytes(int n_pts, int n_hyp);
 int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const float* head_weight, const float* head_bias,
                           const void* const* level_table_host, const int* level_n_host,
                           const float* const* level_feats_host, const int* level_C_host, const int* level_stride_host,
                           const float* const* level_min_pts_host, const float* level_res_host, const float* pts,
                           const int64_t* pts_batch, const float* pts_feat, int c_feat, int n_pts, int n_hyp,
-                          const float* offset_vals, float* preds, float* expect, void* stream);
+                          const float* offset_vals, float* preds, float* expect, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 #ifdef __cplusplus
 }

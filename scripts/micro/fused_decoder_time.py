@@ -19,11 +19,12 @@ with torch.no_grad():
     outs = {}
     for fused in ((True,) if os.environ.get('V3D_TIME_FUSED_ONLY') else (False, True)):
         net.decoder.fused = fused
+        CH = int(os.environ.get('V3D_TIME_CHUNK', '16'))      # reference views per run_pointflow call (eval-3dvnet.py: 16)
         def sweep():
             o = []
-            for b0 in range(0, 64, 16):
-                e = edges[:, (edges[0] >= b0 + k) & (edges[0] < b0 + 16 + k)] - b0
-                o.append(net.run_pointflow(xs, depth[b0:b0 + 16], db[b0:b0 + 16], feat[b0:b0 + 20], rot[b0:b0 + 20], tv[b0:b0 + 20], K[b0:b0 + 20], e, 0.05, 3))
+            for b0 in range(0, 64, CH):
+                e = edges[:, (edges[0] >= b0 + k) & (edges[0] < b0 + CH + k)] - b0
+                o.append(net.run_pointflow(xs, depth[b0:b0 + CH], db[b0:b0 + CH], feat[b0:b0 + CH + 2 * k], rot[b0:b0 + CH + 2 * k], tv[b0:b0 + CH + 2 * k], K[b0:b0 + CH + 2 * k], e, 0.05, 3))
             return torch.cat(o)
         for _ in range(2): outs[fused] = sweep()
         torch.cuda.synchronize(); libm.timing_enable(True)
@@ -35,6 +36,6 @@ with torch.no_grad():
     if os.environ.get('V3D_FUSED_PHASES'):      # library built with -DV3D_PHASE_TIMING (fused_decoder_ablate.sh build "-DV3D_PHASE_TIMING")
         import ctypes
         fn = libm.load().v3d_debug_fused_phase_read; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-        buf = (ctypes.c_ulonglong * 8)(); nb = 16 * 3136 // 8; fn(buf, nb); tot = sum(buf)
+        buf = (ctypes.c_ulonglong * 8)(); nb = 256; fn(buf, nb); tot = sum(buf)
         print('phases (cycles per workgroup of the last launch, wave 0): total %.0f:' % (tot / nb), ' '.join('%d:%.0f (%.1f%%)' % (i, v / nb, 100.0 * v / tot) for i, v in enumerate(buf)))
     if False in outs: print('max |offset fused - chain| = %.2e m' % float((outs[True] - outs[False]).abs().max()))

@@ -94,27 +94,33 @@ def test_pl3dvnet_default_construction_and_unsupported_feat_dim():
         lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=24)
 
 
-def test_lds_hazard_guard_pins_the_fused_decoder_signature():
-    """scripts/check_lds_hazard.py (run by 3dvnet_amd/build.py on the default build): the LDS read signature of
-    decoder_fused_kernel in the built object equals the pinned one, and a moved signature fails the check."""
-    import glob
+def test_isa_guard_of_the_fused_decoder():
+    """3dvnet_amd/isa_check.py (run by 3dvnet_amd/build.py on the default build): decoder_fused_kernel in the built object has no
+    scratch instruction, its LDS read signature equals the pinned one, and a moved signature fails the check with the pinned
+    compiler (and only warns with another one)."""
     import importlib
     import os
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tag = open(os.path.join(root, '3dvnet_amd', 'build', 'linked_flags')).read().strip()
     obj = os.path.join(root, '3dvnet_amd', 'build', tag, 'decoder.o')
     if not os.path.exists(obj) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
         pytest.skip('no decoder.o / llvm tools here')
-    sys.path.insert(0, os.path.join(root, 'scripts'))
+    chk = importlib.import_module('3dvnet_amd.isa_check')
+    sig, scratch = chk.signature(obj)
+    assert scratch == 0
+    assert sig['ds_read_b128'] > 0
+    assert chk.check(obj, strict=True) == sig
+    pinned, comp = chk.PINNED, chk.PINNED_COMPILER
     try:
-        chk = importlib.import_module('check_lds_hazard')
-        sig = chk.check(obj)
-        assert sig['ds_read_b128'] > 0 and sig['ds_read_b32'] > 0
-        pinned = dict(chk.PINNED)
-        chk.PINNED['ds_read_b64'] += 1
-        with pytest.raises(RuntimeError, match='signature'):
-            chk.check(obj)
-        chk.PINNED.update(pinned)
+        if pinned is not None:
+            chk.PINNED = dict(pinned, ds_read_b64=pinned.get('ds_read_b64', 0) + 1)
+            chk.PINNED_COMPILER = chk.compiler_id()
+            with pytest.raises(RuntimeError, match='signature'):
+                chk.check(obj)
+            chk.PINNED_COMPILER = 'some other compiler'
+            assert chk.check(obj) == sig                    # warns, does not fail
+        with pytest.raises(RuntimeError, match='could not run'):
+            chk.check(obj + '.missing', strict=True)
+        assert chk.check(obj + '.missing', strict=False) is None
     finally:
-        sys.path.pop(0)
+        chk.PINNED, chk.PINNED_COMPILER = pinned, comp

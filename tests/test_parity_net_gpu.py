@@ -324,12 +324,14 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         assert torch.equal(dec(xs, pts, pf, pts_batch), p_u)
 
 
-def test_fused_decoder_is_deterministic_at_two_workgroups_per_cu(cuda):
+def test_fused_decoder_is_deterministic_under_load(cuda):
     """Round 2 shipped the fused decoder behind a 96 KB LDS request because results changed from launch to launch with two
-    workgroups per CU.  Round 3 traced that to vectorised (ds_read_b128) reads of the LDS corner table under co-resident
-    matrix instructions and keeps those reads scalar (decoder.hip, kFLdsBytes); the kernel now requests 80 KB = two workgroups
-    per CU.  Here: a 6-view cfg3-shaped scene (18 816 query points = 2 352 workgroups, > 4 per CU), 60 launches while a GEMM
-    runs on a second stream: every launch bit-identical to the first and within 2e-6 of the unfused chain."""
+    waves per SIMD; round 3 traced that to vectorised (ds_read_b128) reads of a self-written LDS corner table under co-resident
+    matrix instructions.  The round-5 kernel (column-owner waves, 8 waves per workgroup = two per SIMD, wave-private corner
+    table read with 8-byte reads, LDS-DMA weight ring) must stay clean: a 6-view cfg3-shaped scene (18 816 query points = 588
+    tiles, more than two per CU), 60 launches while a GEMM runs on a second stream: every launch bit-identical to the first, and
+    within 2e-5 of the unfused chain (same products, another summation order: the chain sums k in 32-wide chunks on 16x16x32
+    matrix instructions, the fused kernel in 16-wide steps on 32x32x16 ones, and its softmax sums are shuffle trees)."""
     syn, lm = v3d('synthetic'), v3d('lightningmodel')
     cfg = syn.CONFIGS['cfg3']
     n_ref, k = 6, 2
@@ -363,7 +365,7 @@ def test_fused_decoder_is_deterministic_at_two_workgroups_per_cu(cuda):
             if first is None:
                 first = (p_f.clone(), e_f.clone())
             assert torch.equal(p_f, first[0]) and torch.equal(e_f, first[1]), 'launch %d differs from launch 0' % i
-        assert float((first[0] - p_u).abs().max()) < 2e-6 and float((first[1] - e_u).abs().max()) < 1e-6
+        assert float((first[0] - p_u).abs().max()) < 2e-5 and float((first[1] - e_u).abs().max()) < 5e-6
 
 
 @pytest.mark.parametrize('case', range(7))
