@@ -192,8 +192,8 @@ __device__ __forceinline__ unsigned fused_row_shr1(unsigned x) { return (unsigne
 __device__ __forceinline__ unsigned fused_row_shl1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true); }
 
 #ifdef V3D_PHASE_TIMING
-// developer build only: wave 0 of every workgroup adds up the cycles between marks: 0 tile prologue, 1 layer-1 steps, 2 head,
-// 3 layer transitions, 4 layer 2, 5 layer 3, 6 first half of a step incl. the wait for the slab, 7 waits at the step barrier
+// developer build only: wave 0 of every workgroup adds up the cycles between marks: 0 wait for the slab (vmcnt), 1 second half of the
+// layer-1 steps, 2 head, 3 layer transitions, 4 / 5 second half of the layer 2 / 3 steps, 6 first half of a step, 7 waits at the step barrier
 constexpr int kFPhaseSlots = 1 << 12;
 __device__ unsigned long long g_fused_phase[8 * kFPhaseSlots];
 #define FPHASE_DECL long long ph_t = __builtin_readcyclecounter(); long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
   int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x2* const ctab = reinterpret_cast<u32x2*>(smem + kDLdsRing + wave * kDCtabWave);   // wave-private [4][8][32]
+  const unsigned* const ctab32 = reinterpret_cast<const unsigned*>(ctab);
   unsigned char* const stage = smem + kDLdsRing + kDLdsCtab + wave * kDStageWave;       // wave-private [hi, lo][g][column] 16 B
   const int n_hyp = p.n_hyp;
   const int sb1 = p.C[0] >> 4, sb2 = sb1 + (p.C[1] >> 4), sb3 = sb2 + (p.C[2] >> 4), n1 = p.nstep1;   // step ranges of layer 1
@@ -288,11 +289,12 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
   // around: the surplus slabs are never read).
   auto mid_sync = [&](const char* next2, auto wait) __attribute__((always_inline)) {
     constexpr int W = decltype(wait)::value;
+    FPHASE_MARK(6);
     if constexpr (W == 0 || V3D_FUSED_SAFE_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (W == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (W == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(W == 0, "mid_sync: unsupported wait");
-    FPHASE_MARK(6);
+    FPHASE_MARK(0);
     __syncthreads();
     FPHASE_MARK(7);
     dma_issue(next2, slot == 0 ? 2 : slot - 1);
@@ -370,24 +372,26 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
   };
   f32x4 gx[8][2];          // [corner][column half]
   f32x4 pa0, pa1;          // the two columns' blends in progress
+  // (rows and row pitches fit 24 bits -- checked on the host -- so the product is a full-rate v_mad_u32_u24)
+  auto prod_issue_row = [&](int k, int c, unsigned row, const StepSrc& q) __attribute__((always_inline)) {
+    const unsigned off = __umul24(V3D_FUSED_ABLATE == 2 ? (row & 7u) : row, q.rowb) + q.cofs + (unsigned)ppc * 16u;
+#if V3D_FUSED_ABLATE == 6 || V3D_FUSED_ABLATE == 8 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 10   // timing experiment: no gathers
+    gx[k][c] = (f32x4){__uint_as_float(off), 0.f, 0.f, 0.f};
+#else
+    gx[k][c] = *reinterpret_cast<const f32x4*>(q.base + (size_t)off);
+#endif
+  };
   auto prod_issue = [&](int k, const StepSrc& q) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const unsigned row = ctab[q.ct + k * 32 + pcol + 16 * c][0];
-      // (rows and row pitches fit 24 bits -- checked on the host -- so the product is a full-rate v_mad_u32_u24)
-      const unsigned off = __umul24(V3D_FUSED_ABLATE == 2 ? (row & 7u) : row, q.rowb) + q.cofs + (unsigned)ppc * 16u;
-#if V3D_FUSED_ABLATE == 6 || V3D_FUSED_ABLATE == 8 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 10   // timing experiment: no gathers
-      gx[k][c] = (f32x4){__uint_as_float(off), 0.f, 0.f, 0.f};
-#else
-      gx[k][c] = *reinterpret_cast<const f32x4*>(q.base + (size_t)off);
-#endif
-    }
+    for (int c = 0; c < 2; ++c) prod_issue_row(k, c, ctab32[2 * (q.ct + k * 32 + pcol + 16 * c)], q);
   };
-  auto prod_consume = [&](int k, const StepSrc& q) __attribute__((always_inline)) {
-    // corner order x fastest; absent corners add nothing (no renormalisation)
-    const float wa = __uint_as_float(ctab[q.ct + k * 32 + pcol][1]), wb = __uint_as_float(ctab[q.ct + k * 32 + pcol + 16][1]);
+  // corner order x fastest; absent corners add nothing (no renormalisation)
+  auto prod_consume_w = [&](int k, float wa, float wb) __attribute__((always_inline)) {
     pa0 = __builtin_elementwise_fma(gx[k][0], (f32x4){wa, wa, wa, wa}, pa0);
     pa1 = __builtin_elementwise_fma(gx[k][1], (f32x4){wb, wb, wb, wb}, pa1);
+  };
+  auto prod_consume = [&](int k, const StepSrc& q) __attribute__((always_inline)) {
+    prod_consume_w(k, __uint_as_float(ctab32[2 * (q.ct + k * 32 + pcol) + 1]), __uint_as_float(ctab32[2 * (q.ct + k * 32 + pcol + 16) + 1]));
   };
   // the finished blends -> split -> the consumer layout: piece ppc = 2 j + g' holds the channels 8 j + 4 g' .. + 3 of the step, i.e.
   // half j of the B fragment of lane (g', column)
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
         const int grp = t * 2 + mp;
         if (grp < 5) load_a(af[(grp + 1) & 1], slot, (grp + 1) >> 1, (grp + 1) & 1, xh, xl);
         else load_a(af[0], slot == 2 ? 0 : slot + 1, 0, 0, xh, xl);
+        hook(std::integral_constant<int, 1>{}, grp);      // (the producer's table reads of this group, too)
         __builtin_amdgcn_sched_barrier(0);     // (the requests stay in front of the matrix instructions)
         const u32x4 (&a)[4] = af[grp & 1];
 #if V3D_FUSED_ABLATE == 1 || V3D_FUSED_ABLATE == 8 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 10
@@ -489,24 +494,43 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
       }
     }
   };
-  auto no_hook = [](auto, int) __attribute__((always_inline)) {};
-  // the producer's share of a step: groups 0..3 turn over two corners each (consume step `cu`'s rows, request step `iu`'s),
-  // group 4 stages the finished B fragment, group 5 fetches it in the consumer layout
+  auto no_hook = [](auto, int) __attribute__((always_inline)) {};      // hook(phase, group): phase 1 in front of the group's matrix instructions, 0 behind
+  // the producer's share of a step: groups 0..3 turn over two corners each (consume step `cu`'s rows, request step `iu`'s), group
+  // 3 also stages the finished B fragment, group 4 fetches it in the consumer layout
   u32x4 bh, bl;            // B fragment (hi, lo) of the layer-1 step about to run
   u32x4 bhn, bln;
+  // The table entries a group's share needs -- weights of the rows it consumes, row indices of those it requests -- are read in
+  // front of the group's matrix instructions: behind them they were two LDS round trips in a row per group, in the issue path of
+  // the wave's next matrix instructions.
+  unsigned pr[4];
+  float pw[4];
   auto prod_hook = [&](const StepSrc& cs, const StepSrc& is, bool consume) __attribute__((always_inline)) {
-    return [&, consume](auto, int grp) __attribute__((always_inline)) {
-      if (grp < 4) {
+    return [&, consume](auto phase, int grp) __attribute__((always_inline)) {
+      if constexpr (decltype(phase)::value == 1) {
+        if (grp < 4) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int k = 2 * grp + kk;
-          if (consume) prod_consume(k, cs);
-          prod_issue(k, is);
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int k = 2 * grp + kk;
+              // (4-byte reads on purpose: see prod_fetch -- LDS reads that return 16 bytes per lane must not feed vector instructions)
+              if (consume) pw[2 * kk + c] = __uint_as_float(ctab32[2 * (cs.ct + k * 32 + pcol + 16 * c) + 1]);
+              pr[2 * kk + c] = ctab32[2 * (is.ct + k * 32 + pcol + 16 * c)];
+            }
         }
-      } else if (grp == 4) {
-        if (consume) prod_finalize();
       } else {
-        if (consume) prod_fetch(bhn, bln);
+        if (grp < 4) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int k = 2 * grp + kk;
+            if (consume) prod_consume_w(k, pw[2 * kk], pw[2 * kk + 1]);
+            prod_issue_row(k, 0, pr[2 * kk], is);
+            prod_issue_row(k, 1, pr[2 * kk + 1], is);
+          }
+          if (grp == 3 && consume) prod_finalize();
+        } else if (grp == 4) {
+          if (consume) prod_fetch(bhn, bln);
+        }
       }
     };
   };
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
     refresh_lane_ids();
     const bool has_next = tile + tile_step < tile_end;
     zero_acc();
-    FPHASE_MARK(0);
+    FPHASE_MARK(3);
 
     // ---- layer 1: every step consumes the rows of the next step and requests those of the step after next (clamped to the last
     // step at the end: the surplus B fragments are never used) -- 16 gathers per step, hence the 16 of the rendezvous ------------

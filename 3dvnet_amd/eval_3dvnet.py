@@ -19,8 +19,12 @@ from .batch import Batch
 from . import utils
 from .mvsnet import edges_to_csr
 
-INIT_DEPTH_BATCH = 18      # eval-3dvnet.py:12-14
-OFFSET_BATCH = 16
+# Reference views per call (the reference: INIT_DEPTH_BATCH = 18, OFFSET_BATCH = 16, eval-3dvnet.py:12-14 -- sized for its GPU's
+# memory).  Results do not depend on the chunking (tests/test_driver.py), and on an MI355X both stages hold a whole 64-view scene
+# at once: 64 views per call is the batch the cost-volume kernels are tuned for (2.5 GB variance volume of 288 GB), and one
+# point-flow call per sweep fills the persistent decoder's tile walk evenly (24.5 tiles per CU instead of 4 x 6.1 -> 4 x 7).
+INIT_DEPTH_BATCH = 64
+OFFSET_BATCH = 64
 DEPTH_CONFIG = {'depth_start': 0.5, 'depth_interval': 0.05, 'n_intervals': 96, 'size': (56, 56)}
 OFFSETS_LIST = [[0.05, 0.05, 0.025], [0.05, 0.05, 0.025]]
 
