@@ -33,6 +33,8 @@ c_float_pp = ctypes.POINTER(c_float_p)
 SIGNATURES = {
     'v3d_version': (c_int, []),
     'v3d_last_error': (ctypes.c_char_p, []),
+    'v3d_set_option': (c_int, [ctypes.c_char_p, c_int]),
+    'v3d_get_option': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
     'v3d_timing_enable': (c_int, [c_int]),
     'v3d_timing_collect': (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_float),
                                    ctypes.POINTER(c_int)]),
@@ -143,6 +145,11 @@ def load():
         raise V3DLibraryError('ABI version mismatch: library %d, binding %d'
                               % (lib.v3d_version(), ABI_VERSION))
     _lib = lib
+    # developer convenience (scripts/): V3D_OPTIONS="name=value,name=value" -> v3d_set_option once at load time.  (The library
+    # itself reads no environment variable.)
+    for item in filter(None, os.environ.get('V3D_OPTIONS', '').split(',')):
+        name, _, val = item.partition('=')
+        check(lib.v3d_set_option(name.strip().encode(), int(val)), 'v3d_set_option(%s)' % item)
     return lib
 
 
@@ -151,6 +158,15 @@ def check(rc, what):
         msg = load().v3d_last_error()
         raise V3DLibraryError('%s failed: %s (%s)' % (what, _ERR_NAMES.get(rc, rc),
                                                       msg.decode() if msg else ''))
+
+
+def set_option(name, value):
+    """Developer options of the library (include/v3d.h: v3d_set_option); returns the previous value."""
+    lib = load()
+    old = c_int(0)
+    check(lib.v3d_get_option(name.encode(), ctypes.byref(old)), 'v3d_get_option')
+    check(lib.v3d_set_option(name.encode(), int(value)), 'v3d_set_option')
+    return old.value
 
 
 def ptr(t):

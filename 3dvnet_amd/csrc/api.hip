@@ -1,4 +1,6 @@
 // Library-level entry points of lib3dvnet_hip.so (see include/v3d.h).
+#include <atomic>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -35,6 +37,51 @@ void timing_end(hipStream_t s) {
   if (!g_spans.empty()) (void)hipEventRecord(g_spans.back().b, s);
 }
 }  // namespace v3d
+
+namespace {
+struct OptDef { const char* name; int def; };
+const OptDef kOptDefs[v3d::kOptCount] = {{"psv_kernel", 0}, {"psv_threads", 64}, {"c12_march", 1}, {"c12_nseg", 0}, {"c9_kernel", 0},
+                                         {"conv_vec", 1}, {"stop_after", 99}, {"gemm_rounds", 1}, {"gemm_round_rows", 0}};
+std::atomic<int> g_opt[v3d::kOptCount];
+std::atomic<bool> g_opt_init{false};
+void opt_init() {
+  if (!g_opt_init.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_opt_init.load()) {
+      for (int i = 0; i < v3d::kOptCount; ++i) g_opt[i].store(kOptDefs[i].def);
+      g_opt_init.store(true, std::memory_order_release);
+    }
+  }
+}
+}  // namespace
+
+int v3d::option(v3d::Option o) {
+  opt_init();
+  return g_opt[o].load(std::memory_order_relaxed);
+}
+
+extern "C" int v3d_set_option(const char* name, int value) {
+  V3D_REQUIRE(name, V3D_ERR_BAD_ARG, "v3d_set_option: null name");
+  opt_init();
+  for (int i = 0; i < v3d::kOptCount; ++i)
+    if (!strcmp(name, kOptDefs[i].name)) {
+#ifndef V3D_EXPERIMENTS
+      V3D_REQUIRE(!(i == v3d::kOptC9Kernel && value == 1), V3D_ERR_UNSUPPORTED,
+                  "v3d_set_option: c9_kernel = 1 (csrc/conv9z.hip) needs a library built with -DV3D_EXPERIMENTS");
+#endif
+      g_opt[i].store(value);
+      return V3D_OK;
+    }
+  return v3d::fail(V3D_ERR_BAD_ARG, "v3d_set_option: unknown option '%s'", name);
+}
+
+extern "C" int v3d_get_option(const char* name, int* value) {
+  V3D_REQUIRE(name && value, V3D_ERR_BAD_ARG, "v3d_get_option: null argument");
+  opt_init();
+  for (int i = 0; i < v3d::kOptCount; ++i)
+    if (!strcmp(name, kOptDefs[i].name)) { *value = g_opt[i].load(); return V3D_OK; }
+  return v3d::fail(V3D_ERR_BAD_ARG, "v3d_get_option: unknown option '%s'", name);
+}
 
 extern "C" int v3d_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -581,8 +581,7 @@ int v3d::launch_conv12z(const void* c0, const float* w1, const float* w2, const 
     const long long cost = rounds * (len + 5) + 2 * rounds;
     if (best < 0 || cost < best) { best = cost; p.nseg = nseg; p.seg_len = len; }
   }
-  if (const char* e = getenv("V3D_C12_NSEG")) {                 // developer A/B
-    const int nseg = atoi(e);
+  if (const int nseg = v3d::option(v3d::kOptC12Nseg)) {        // developer A/B (v3d_set_option "c12_nseg")
     if (nseg >= 1 && nseg <= p.D2) { p.nseg = nseg; p.seg_len = (p.D2 + nseg - 1) / nseg; p.nseg = (p.D2 + p.seg_len - 1) / p.seg_len; }
   }
   const long long tasks = tiles * p.nseg;

@@ -14,7 +14,8 @@
 //     turn them into the two new u9 planes of a ring of six, four CONSUMER waves run the prob conv one step behind on the
 //     planes that are complete -- one barrier per step, the two roles overlap, the (y, x) halo is the only recompute (1.34x).
 //
-// STATUS (round 4): an experiment behind V3D_C9_MARCH=1, NOT the default.  It is correct (tests/test_costvolume_gpu.py passes
+// STATUS (round 4): an experiment, NOT the default and since round 5 not even part of the default build (-DV3D_EXPERIMENTS, then
+// v3d_set_option("c9_kernel", 1)).  It is correct (tests/test_costvolume_gpu.py passes
 // with it: goldens, fuzz, batch invariance) but measures 0.51 ms per 64 cfg2 views against 0.46 for the tile kernel, after:
 // prob weights out of the step loop's vector loads (0.60 -> 0.49: after the consumers' stores the compiler could not prove them
 // invariant; __restrict__ + an LDS copy), all LDS reads of a step issued up front, the transposed conv's five accumulator
@@ -31,6 +32,16 @@
 #include <utility>
 
 #include "v3d_common.h"
+
+#ifndef V3D_EXPERIMENTS
+// The default build does not carry this experiment (v3d_set_option("c9_kernel", 1) is refused): build with
+// V3D_EXTRA_FLAGS=-DV3D_EXPERIMENTS to time it (scripts/phase_conv0z.py --kernel conv9z).
+int v3d::launch_conv9z(const void*, const void*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
+                       hipStream_t) {
+  return v3d::fail(V3D_ERR_UNSUPPORTED, "conv9z: experimental kernel, not in this build (-DV3D_EXPERIMENTS)");
+}
+#else
+
 
 namespace {
 
@@ -515,3 +526,4 @@ extern "C" int v3d_debug_conv9z_phase_read(unsigned long long* out8_host, int n_
   return V3D_OK;
 }
 #endif
+#endif  // V3D_EXPERIMENTS

@@ -2008,7 +2008,7 @@ int launch_conv(const char* name, const float* in, const float* wp, const float*
     v3d::TimedScope ts(name, s);
     // (conv0 only: on conv2 the 40 extra staging registers cost more than the loads save: 0.37 -> 0.41 ms)
     constexpr bool kVecOk = C::MODE == kConvS1Pair && C::PF && C::TW % 4 == 0 && C::IW <= 61;
-    const bool vec = kVecOk && Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && !getenv("V3D_CONV_NO_VEC");
+    const bool vec = kVecOk && Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && v3d::option(v3d::kOptConvVec) != 0;
     if constexpr (kVecOk) {
       if (vec) conv3d_mfma_kernel<C, true><<<(unsigned)blocks, 256, 0, s>>>(p);
       else conv3d_mfma_kernel<C, false><<<(unsigned)blocks, 256, 0, s>>>(p);
@@ -2038,8 +2038,11 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
   const long long blocks = (long long)n * p.ntz * p.nty * p.ntx;
   V3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: bad grid");
   V3D_REQUIRE((long long)8 * Di * Hi * Wi < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv0: input volume too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};      // per device: the dynamic-LDS opt-in is a per-device function attribute
+  int attr_dev = 0;
+  V3D_CHECK_HIP(hipGetDevice(&attr_dev));
+  V3D_REQUIRE(attr_dev >= 0 && attr_dev < 64, V3D_ERR_UNSUPPORTED, "device ordinal %d", attr_dev);
+  if (!attr_set[attr_dev]) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<true, false, 4>,
@@ -2048,7 +2051,7 @@ int launch_conv0_bf16(bool split_in, bool split_out, const float* in, const floa
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv0_bf16x2_kernel<false, true, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0::LDS_BYTES));
-    attr_set = true;
+    attr_set[attr_dev] = true;
   }
   {
     v3d::TimedScope ts("costreg_conv0", s);
@@ -2087,11 +2090,14 @@ int launch_convg(const char* name, const void* in, const float* wbf, const float
   // the output side indexes 4 planes from the item's base
   V3D_REQUIRE(Di < (1 << 12) && Hi < (1 << 12) && Wi < (1 << 12) && (long long)Di * Hi * Wi < (1ll << 24), V3D_ERR_BAD_SHAPE,
               "%s: volume %d x %d x %d too large for 32-bit slot offsets", name, Di, Hi, Wi);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};      // per device: the dynamic-LDS opt-in is a per-device function attribute
+  int attr_dev = 0;
+  V3D_CHECK_HIP(hipGetDevice(&attr_dev));
+  V3D_REQUIRE(attr_dev >= 0 && attr_dev < 64, V3D_ERR_UNSUPPORTED, "device ordinal %d", attr_dev);
+  if (!attr_set[attr_dev]) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)convg_bf16x2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)C::LDS_BYTES));
-    attr_set = true;
+    attr_set[attr_dev] = true;
   }
   {
     v3d::TimedScope ts(name, s);
@@ -2699,7 +2705,7 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
       }
     }
 #ifdef V3D_PHASE_TIMING
-    const int stop_after = getenv("V3D_STOP_AFTER") ? atoi(getenv("V3D_STOP_AFTER")) : 99;   // isolate one kernel's counters
+    const int stop_after = v3d::option(v3d::kOptStopAfter);   // isolate one kernel's counters
 #define V3D_STOP(l) if (stop_after == (l)) return V3D_OK
 #else
 #define V3D_STOP(l)
@@ -2717,8 +2723,8 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     auto B_ = [&](int l) { return h->dev + h->bias_ofs[l]; };
     V3D_STOP(0);
     // conv1 + conv2: the fused depth march of conv12z.hip (conv1's output never leaves LDS: 0.27 ms per 64 cfg2 views against 0.176 +
-    // 0.146 for the two tile kernels, which remain behind V3D_C12_MARCH=0 -- developer A/B -- and the per-layer entry points)
-    static const bool c12_march = V3D_SKIP_SPLIT && !(getenv("V3D_C12_MARCH") && atoi(getenv("V3D_C12_MARCH")) == 0);
+    // 0.146 for the two tile kernels, which remain behind the developer option c12_march = 0 and the per-layer entry points)
+    const bool c12_march = V3D_SKIP_SPLIT && v3d::option(v3d::kOptC12March) != 0;
     if (c12_march) {
       if ((rc = v3d::launch_conv12z(F(ws.c0), W_(1), W_(2), B_(1), B_(2), c2s, n, D, H, W, s)) != V3D_OK) return rc;
     } else {
@@ -2760,11 +2766,11 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
     RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
   }
-  // conv9 + skip + prob: the tile kernel (split-bf16 or exact fp32 operands).  Developer A/B: V3D_C9_MARCH=1 selects the depth-march
+  // conv9 + skip + prob: the tile kernel (split-bf16 or exact fp32 operands).  Developer A/B (v3d_set_option "c9_kernel"): 1 selects the depth-march
   // experiment of round 4 for the split path (conv9z.hip: correct -- the GPU suite passes on it -- but 0.51 against 0.46 ms per 64
-  // views, see its header); V3D_C9_F32_UNFUSED=1 the per-layer conv9 kernel + prob_conv_kernel for the exact-fp32 path (rounds 1-3).
-  static const bool tile_kernel = getenv("V3D_C9_MARCH") == nullptr;
-  static const bool f32_unfused = getenv("V3D_C9_F32_UNFUSED") != nullptr;
+  // views, see its header; -DV3D_EXPERIMENTS builds only); 2 the per-layer conv9 kernel + prob_conv_kernel for the exact-fp32 path (rounds 1-3).
+  const bool tile_kernel = v3d::option(v3d::kOptC9Kernel) != 1;
+  const bool f32_unfused = v3d::option(v3d::kOptC9Kernel) == 2;
   if (!generic && !tile_kernel) {
     if ((rc = v3d::launch_conv9z(F(ws.u8), F(ws.c0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9], h->dev + h->prob_w2_ofs,
                                  h->dev + h->prob_b_ofs, xreg, n, D, H, W, s)) != V3D_OK) return rc;

@@ -819,15 +819,15 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
     else gemm_gather_kernel<MBW_, NB_, true><<<blocks, 256, 0, s>>>(p);                    \
   } while (0)
     // small M, split-bf16, every segment 16-byte loadable: the rounds kernel (four steps per pair of barriers)
-    bool rounds = small && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && !getenv("V3D_GEMM_NO_ROUNDS");
+    bool rounds = small && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && v3d::option(v3d::kOptGemmRounds) != 0;
     for (int t = 0; rounds && t < h->n_seg; ++t)
       rounds = p.seg[t].ld % 4 == 0 && (reinterpret_cast<size_t>(p.seg[t].src) & 15) == 0;
     if (rounds) {
       // developer A/B: rows per tile (32 / 64 / 128) -- a tile re-reads the whole weight image, so L2 -> CU weight traffic is
       // M / rows x 27 x K x N x 4 bytes (0.8 GB per 64-channel conv on 60 k voxels with 32-row tiles, twice the gathers)
-      static const int rows_env = getenv("V3D_GEMM_ROUND_ROWS") ? atoi(getenv("V3D_GEMM_ROUND_ROWS")) : 0;
+      const int rows_env = v3d::option(v3d::kOptGemmRoundRows);
       V3D_REQUIRE(rows_env == 0 || rows_env == 32 || rows_env == 64 || rows_env == 128, V3D_ERR_BAD_ARG,
-                  "V3D_GEMM_ROUND_ROWS must be 32, 64 or 128 (got %d)", rows_env);
+                  "option gemm_round_rows must be 0, 32, 64 or 128 (got %d)", rows_env);
       const int rows = rows_env ? rows_env : 32;
       const unsigned rb = (unsigned)((M + rows - 1) / rows);
       if (h->MBW == 2) {

@@ -1103,9 +1103,9 @@ static int psv_variance_impl(int mode, const float* feat, const float* K, const 
   p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.var = var; p.camp = camp;
   p.n_img = n_img; p.n_ref = n_ref; p.Hf = Hf; p.Wf = Wf; p.H = H; p.W = W; p.D = D;
   p.h = h; p.w = w;
-  // workgroup size: single-wave workgroups (16 pixels) unless V3D_PSV_THREADS=256 asks for the 64-pixel variant
-  static const int threads = getenv("V3D_PSV_THREADS") ? atoi(getenv("V3D_PSV_THREADS")) : 64;
-  V3D_REQUIRE(threads == 64 || threads == 256, V3D_ERR_BAD_ARG, "V3D_PSV_THREADS must be 64 or 256");
+  // workgroup size: single-wave workgroups (16 pixels) unless the developer option psv_threads = 256 asks for the 64-pixel variant
+  const int threads = v3d::option(v3d::kOptPsvThreads);
+  V3D_REQUIRE(threads == 64 || threads == 256, V3D_ERR_BAD_ARG, "option psv_threads must be 64 or 256");
   const int pix = threads / 4;
   p.n_ptile = (h * w + pix - 1) / pix;
   p.x_step = w > 1 ? (double)(W - 1) / (double)(w - 1) : 0.0;
@@ -1125,12 +1125,13 @@ static int psv_variance_impl(int mode, const float* feat, const float* K, const 
     if (threads == 64) psv_variance_kernel<C_, SPLIT_, 64><<<grid, 64, 0, s>>>(p); \
     else psv_variance_kernel<C_, SPLIT_, 256><<<grid, 256, 0, s>>>(p);             \
   } while (0)
-    static const bool plain_gather = getenv("V3D_PSV_GATHER") != nullptr;   // developer A/B switch
+    const int psv_kernel = v3d::option(v3d::kOptPsvKernel);     // developer A/B (v3d_set_option): 0 auto, 1 reuse, 2 gather kernel
+    const bool plain_gather = psv_kernel == 2;
     if (C == 32 && !plain_gather) {
       const long long rblocks = (long long)n_ref * ((D + kRDB - 1) / kRDB) * ((h * w + kRPix - 1) / kRPix);
       V3D_REQUIRE(rblocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "v3d_psv_variance_f32: grid too large");
       p.n_ptile = (h * w + kRPix - 1) / kRPix;
-      static const bool reuse_env = getenv("V3D_PSV_REUSE") != nullptr || kRDB != 8;   // developer A/B switch: round-2 kernel
+      const bool reuse_env = psv_kernel == 1 || kRDB != 8;   // (the round-2 kernel)
       // the window kernel's tap words keep their sign bit as a flag: feature maps beyond 2 GB take the reuse kernel
       const bool no_window = reuse_env || psv_feat_bytes(n_img, C, Hf, Wf) >= ((size_t)1 << 31);
       V3D_REQUIRE(!cl8 || !no_window, V3D_ERR_UNSUPPORTED,
@@ -1157,7 +1158,7 @@ static int psv_variance_impl(int mode, const float* feat, const float* K, const 
         else psv_variance_window_kernel<false><<<(unsigned)fblocks, 256, 0, s>>>(p);
       }
     } else if (cl8) {
-      return v3d::fail(V3D_ERR_UNSUPPORTED, "v3d_psv_variance_cl8: C=%d unsupported (32) / V3D_PSV_GATHER set", C);
+      return v3d::fail(V3D_ERR_UNSUPPORTED, "v3d_psv_variance_cl8: C=%d unsupported (32) / option psv_kernel = 2", C);
     } else if (split) V3D_PSV(32, true);
     else if (C == 32) V3D_PSV(32, false);
     else V3D_PSV(16, false);

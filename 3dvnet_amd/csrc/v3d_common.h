@@ -45,6 +45,22 @@ inline int fail(int code, const char* fmt, ...) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Developer options (v3d_set_option in include/v3d.h): process-wide integers read at launch time.  They replace the environment
+// variables earlier rounds read on the launch paths; none of them is needed in production, every default is the shipped path.
+enum Option {
+  kOptPsvKernel,       // "psv_kernel": 0 auto (window kernel; reuse kernel for feature stacks >= 2 GB), 1 reuse kernel, 2 gather kernel
+  kOptPsvThreads,      // "psv_threads": 64 | 256, workgroup size of the gather kernel
+  kOptC12March,        // "c12_march": 1 conv1 + conv2 as one depth march (conv12z.hip), 0 the two tile kernels
+  kOptC12Nseg,         // "c12_nseg": 0 auto, else z segments per tile of the conv1 + conv2 march
+  kOptC9Kernel,        // "c9_kernel": 0 tile kernel, 1 depth-march experiment (builds with -DV3D_EXPERIMENTS only), 2 exact-fp32 unfused
+  kOptConvVec,         // "conv_vec": 1 float4 staging of halo rows in the exact-fp32 layer kernel, 0 scalar
+  kOptStopAfter,       // "stop_after": regulariser returns after this layer (-DV3D_PHASE_TIMING builds: isolates a kernel's counters)
+  kOptGemmRounds,      // "gemm_rounds": 1 gather-GEMM in rounds for small M, 0 the one-step kernel
+  kOptGemmRoundRows,   // "gemm_round_rows": 0 auto (32), 32 | 64 | 128 rows per tile of the rounds kernel
+  kOptCount
+};
+int option(Option o);
+
 // Optional per-kernel timing (v3d_timing_* in include/v3d.h): when enabled every launch made through
 // V3D_LAUNCH is bracketed by hipEvents on its own stream.  Off by default (zero overhead).
 bool timing_enabled();

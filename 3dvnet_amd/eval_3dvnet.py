@@ -126,7 +126,11 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
         # Precomputed features that already live on `device`: the slices ARE the tensors stage 2 / 3 need -- no per-chunk copy
         # into a second buffer (the reference fills all_feats_quarter / all_feats_half chunk by chunk because its features come
         # out of the backbone per chunk, eval-3dvnet.py:56-62)
-        dev_feats = has_feats and batch.features_quarter.device == torch.device(device) and batch.features_quarter.dtype == torch.float32
+        # (only when stage 1 takes the batch's features too: a net with its own backbone and a batch with images computes
+        # features_quarter itself -- stages 2 / 3 must then see THOSE, as in the reference, not the batch's)
+        own_backbone = getattr(getattr(net, 'mvsnet', None), 'feat_extractor', None) is not None and batch.images is not None
+        dev_feats = (has_feats and not own_backbone and batch.features_quarter.device == torch.device(device)
+                     and batch.features_quarter.dtype == torch.float32)
         half_is_view = False
         if dev_feats:
             feats_local = batch.features_quarter[r0:r1 + halo]

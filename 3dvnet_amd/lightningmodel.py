@@ -58,7 +58,9 @@ class PL3DVNet(nn.Module):
         the first U-Net level, the unfused hypothesis decoder.  Extra keywords:
         ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
-        ('split_bf16' | 'fp32') selects the MFMA operand precision of every matrix-core kernel (include/v3d.h)."""
+        ('split_bf16' | 'fp32') selects the MFMA operand precision of the matrix-core kernels of stages 1 and 2 (include/v3d.h);
+        the three PropagationNets of stage 3 (``refine_*``) always run split-bf16 operands (``v3d_propagation_f32`` has no exact-fp32
+        variant), on a HIP device, in eval mode."""
         super().__init__()
         if feat_dim not in (16, 32):
             raise ValueError('PL3DVNet: feat_dim=%d is not supported by the HIP path (16 -- the reference\'s signature default -- '
@@ -85,6 +87,32 @@ class PL3DVNet(nn.Module):
         self._ws = _Workspace()
         self._offset_vals = {}
         self._pts_batch = {}
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):
+        """Counterpart of ``PL3DVNet.load_from_checkpoint(path)`` (mv3d/eval-3dvnet.py:134; pytorch-lightning 1.1.2): a Lightning
+        checkpoint is a ``torch.save``d dict with ``'state_dict'`` (keys ``mvsnet.* / pointnet.* / sparse_conv.* / decoder.* /
+        refine_*.*``) and ``'hyper_parameters'`` (the constructor arguments saved by ``save_hyperparameters``,
+        lightningmodel.py:33).  ``kwargs`` override / complete the hyper-parameters (and carry this class's extra keywords,
+        e.g. ``precision``).  The 2D backbone is built when the checkpoint carries ``mvsnet.feat_extractor.*`` keys.
+        ``strict``: as ``nn.Module.load_state_dict``, except that BatchNorm ``num_batches_tracked`` counters may be absent.
+        Sparse-convolution kernels are taken as MinkowskiEngine stores them (``.kernel`` [27, Cin, Cout], offset index with the
+        first spatial dimension fastest, SURVEY.md Appendix A -- parity with a real ME checkpoint is unpinned)."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location or 'cpu', weights_only=False)
+        sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+        hp = dict(ckpt.get('hyper_parameters', {})) if isinstance(ckpt, dict) else {}
+        hp.update(kwargs)
+        for name in ('depth_train', 'depth_test', 'edge_len'):
+            if name not in hp:
+                raise KeyError('load_from_checkpoint: hyper-parameter %r is neither in the checkpoint nor given' % name)
+        if any(k.startswith('mvsnet.feat_extractor.') for k in sd) and 'feat_extractor' not in hp:
+            hp.setdefault('backbone', True)
+        net = cls(**hp)
+        res = net.load_state_dict(sd, strict=False)
+        missing = [k for k in res.missing_keys if not k.endswith('num_batches_tracked')]
+        if strict and (missing or res.unexpected_keys):
+            raise RuntimeError('load_from_checkpoint: missing keys %s, unexpected keys %s' % (missing, list(res.unexpected_keys)))
+        return net.eval()
 
     def make_initial_depth_predictions(self, batch, depth_config):
         """lightningmodel.py:124-130."""
@@ -147,13 +175,17 @@ class PL3DVNet(nn.Module):
                                                  workspace=self._ws, csr=csr)
         # one batch index per point (lightningmodel.py:193-194); the scene driver sweeps the same chunks again and again: the
         # expanded tensor of the last few (storage, version) pairs is kept instead of being rebuilt per call
-        pkey = (depth_batch.data_ptr(), depth_batch._version, n_imgs, n_pts, str(depth_batch.device))
-        pts_batch = self._pts_batch.get(pkey)
+        # (inference-mode tensors carry no version counter: they are never cached)
+        cacheable = not depth_batch.is_inference()
+        pkey = (depth_batch.data_ptr(), depth_batch._version if cacheable else -1, tuple(depth_batch.stride()), str(depth_batch.dtype),
+                n_imgs, n_pts, str(depth_batch.device))
+        pts_batch = self._pts_batch.get(pkey) if cacheable else None
         if pts_batch is None:
             if len(self._pts_batch) >= 16:
                 self._pts_batch.clear()
             pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
-            self._pts_batch[pkey] = (pts_batch, depth_batch)       # (the source is kept alive: its address is the key)
+            if cacheable:
+                self._pts_batch[pkey] = (pts_batch, depth_batch)   # (the source is kept alive: its address is the key)
         else:
             pts_batch = pts_batch[0]
         key = (float(offset), int(n), str(depth_pred.device))

@@ -31,6 +31,12 @@ class _Workspace:
         return buf
 
 
+def _psv_kernel_option():
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().v3d_get_option(b'psv_kernel', ctypes.byref(v)), 'v3d_get_option')
+    return v.value
+
+
 def module_state_key(module):
     """Cache key of a module's packed device weights.  ``tensor._version`` alone misses ``module.to(device)``,
     ``p.data = ...``, ``load_state_dict(assign=True)`` and ``swap_tensors`` (new storage, coinciding versions), so the
@@ -393,10 +399,11 @@ class MVSNet(nn.Module):
         (identical depth, no conversion pass in conv0)."""
         precision = precision or self.cnn_3d.precision
         split = not return_intermediates and features_quarter.shape[1] == 32 and precision == 'split_bf16'
-        # exact fp32: the volume in the channel-last fp32 layout conv0's depth march streams (same numbers as the reference
-        # layout; V3D_PSV_REUSE / V3D_PSV_GATHER developer runs keep the reference layout, which only the window kernel lacks)
+        # exact fp32: the volume in the channel-last fp32 layout conv0's depth march streams (same numbers as the reference layout).
+        # Only the window kernel writes it: developer runs of the reuse / gather kernels (v3d_set_option "psv_kernel") and feature
+        # stacks of 2 GB or more (which take the reuse kernel) keep the reference layout and the per-layer conv0.
         cl8 = (not return_intermediates and features_quarter.shape[1] == 32 and precision == 'fp32'
-               and not os.environ.get('V3D_PSV_REUSE') and not os.environ.get('V3D_PSV_GATHER'))
+               and features_quarter.numel() * 4 < 2 ** 31 and _psv_kernel_option() == 0)
         if csr is None:
             # kept on the module: `check_edges()` reads the device builder's status word (a wrong n_ref gives an EMPTY edge
             # table, i.e. a zero variance volume and a plausible-looking depth, not an exception)

@@ -138,6 +138,18 @@ def traffic_for(kernel, refs, cfg_name):
 # ------------------------------------------------------------------------------------------------------------------
 # cfg2 / cfg5: the cost-volume path (rows A1-A6)
 # ------------------------------------------------------------------------------------------------------------------
+def ranks_seen(args, world, dev, dist):
+    """The number of ranks that take part, counted by an all-reduce over the process group (RCCL): must equal --gpus."""
+    if dist is None:
+        assert world == 1 and args.gpus == 1
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(one)
+    seen = int(one.item())
+    assert seen == args.gpus == dist.get_world_size(), 'ranks seen by the all-reduce: %d, --gpus %d' % (seen, args.gpus)
+    return seen
+
+
 def bench_costvolume(args, rank, world, dev, dist):
     syn = importlib.import_module('3dvnet_amd.synthetic')
     mvs = importlib.import_module('3dvnet_amd.mvsnet')
@@ -236,6 +248,7 @@ def bench_costvolume(args, rank, world, dev, dist):
         roofline = kernel_roofline(dom, stats[dom][0] / stats[dom][1], shape)
         roofline.update(kernel=dom, avg_ms=stats[dom][0] / stats[dom][1], traffic=traffic_for(dom, refs, cfg))
 
+    n_seen = ranks_seen(args, world, dev, dist)
     # ---- CPU baseline: the oracle on the host cores (rank 0, N=1 only) --------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -318,16 +331,16 @@ def bench_costvolume(args, rank, world, dev, dist):
     return {
         'metric': 'depth maps/sec (256x320, 96 planes, 7 src)' if cfg == 'cfg2'
                   else 'depth maps/sec (480x640, 192 planes, 10 src)',
-        'value': value, 'unit': 'depth maps/s', 'n_gpus': world, 'steps': args.steps,
+        'value': value, 'value_fp32_exact': value32, 'unit': 'depth maps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'ms_per_step_fp32_exact': elapsed32 / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE,
-        'value_fp32_exact': value32, 'ms_per_step_fp32_exact': elapsed32 / args.steps * 1e3,
         'data': 'synthetic',
         'config': {'workload': workload, 'refs_per_step_per_gpu': refs, 'n_img_per_gpu': inp['n_img'],
                    'edges_per_ref': e,
                    'parallelism': 'ref-view sharding, no collective' if world > 1 else 'single GPU',
                    'launch': launch_mode,
-                   'ranks_seen': world},
+                   'ranks_seen': n_seen},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'kernels': kernels}
 
 
@@ -403,6 +416,29 @@ def bench_scene(args, rank, world, dev, dist):
         elapsed = float(tt.item())
     assert torch.isfinite(d).all()
     value = refs * args.steps / elapsed
+    n_seen = ranks_seen(args, world, dev, dist)
+    # the one collective of the path: the all-gather of the feature-rich point cloud, once per outer iteration -- its
+    # payload and its time on this machine, measured on tensors of the scene's shapes between barriers
+    collective = None
+    if dist is not None:
+        n_pix = drv.DEPTH_CONFIG['size'][0] * drv.DEPTH_CONFIG['size'][1]
+        rows = [(drv.shard_range(refs, g, world)[1] - drv.shard_range(refs, g, world)[0]) * n_pix for g in range(world)]
+        mine = rows[rank]
+        pts, feat = torch.rand((mine, 3), device=dev), torch.rand((mine, 32), device=dev)
+        pb = torch.zeros(mine, dtype=torch.long, device=dev)
+        for _ in range(3):
+            drv.gather_pointcloud(pts, feat, pb, rows, group)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            drv.gather_pointcloud(pts, feat, pb, rows, group)
+        fence()
+        tg = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        collective = dict(op='all_gather_into_tensor of [pts | feat | batch id] rows (3 + 32 + 1 floats), rank order = view order',
+                          per_outer_iteration=1, outer_iterations=len(drv.OFFSETS_LIST), bytes_per_rank=max(rows) * 36 * 4,
+                          bytes_total=sum(rows) * 36 * 4, avg_ms=float(tg.item()) * 1e3,
+                          note='includes packing the three tensors into one send buffer and unpacking the result')
     kernels, roofline = {}, None
     if rank == 0:
         libm.timing_enable(True)
@@ -442,15 +478,26 @@ def bench_scene(args, rank, world, dev, dist):
     parity, cpu_baseline = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.net import OracleNet          # checker / reported baseline only
-        n_chk = 4
+        n_chk = 8
         bs, gts = make(n_chk, 77)
         with torch.no_grad():
             d_hip = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev), upsample=stage3).cpu()
             nt = min(32, os.cpu_count() or 1)
             torch.set_num_threads(nt)
             onet = OracleNet(sds['cr'], sds['pn'], sds['un'], sds['dec'], cfg['img_size'], cfg['edge_len'], pinned=True)
-            t_cpu = time.perf_counter()
+            # SURVEY 8d protocol within a time budget: one warm-up pass (it is also the checker), then as many timed passes as fit
+            # ~20 s (at most 5), median; the sample string says what was run
+            t_w = time.perf_counter()
             d_cpu = drv.process_scene(bs, onet, win, torch.device('cpu'), init_depth_override=gts)
+            t_w = time.perf_counter() - t_w
+            n_timed = max(1, min(5, int(20.0 / max(t_w, 1e-3)))) if getattr(args, 'cpu_timing', True) else 0
+            passes = []
+            for _ in range(n_timed):
+                tp = time.perf_counter()
+                drv.process_scene(bs, onet, win, torch.device('cpu'), init_depth_override=gts)
+                passes.append(time.perf_counter() - tp)
+            t_scene = sorted(passes)[len(passes) // 2] if passes else t_w
+            t_cpu = time.perf_counter()
             if stage3:      # the oracle's stage-3 chain (oracle/scene.py::propagation_net) on the refined plane-grid depths
                 from oracle import scene as osc
                 import torch.nn.functional as F
@@ -458,13 +505,15 @@ def bench_scene(args, rank, world, dev, dist):
                 for sdp, gd in zip(sds_prop, (bs.features_quarter[nb:nb + n_chk], bs.features_half[nb:nb + n_chk],
                                               bs.images[nb:nb + n_chk])):
                     d_cpu = osc.propagation_net(gd, F.interpolate(d_cpu.unsqueeze(1), gd.shape[-2:], mode='nearest'), sdp)
-            t_cpu = time.perf_counter() - t_cpu
+            t_cpu = t_scene + (time.perf_counter() - t_cpu)        # (+ the oracle's stage-3 chain when stage 3 is timed)
         # the reference's CPU path of the WHOLE pipeline (dense-formulation sparse convolutions, torch CPU
-        # grid_sample / Conv3d) timed beside the GPU figure -- the run that also serves as the checker, one pass, no warm-up
+        # grid_sample / Conv3d) timed beside the GPU figure
         cpu_baseline = dict(value=n_chk / t_cpu, unit='depth maps/s', cores=nt, kind='port',
                             sample='one %d-view scene of the same shapes / weights through the same driver on the oracle-backed '
                                    'net (oracle/net.py; sample coordinates with the pinned orders, i.e. elementwise torch ops '
-                                   'instead of bmm), one pass of %.1f s, no warm-up' % (n_chk, t_cpu),
+                                   'instead of bmm): ' % n_chk +
+                                   ('1 warm-up pass (%.1f s, also the checker), then median of %d timed pass(es) (%.1f s per scene)'
+                                    % (t_w, n_timed, t_cpu) if n_timed else 'one pass of %.1f s (the checker), no warm-up' % t_cpu),
                             cpu_model=cpu_info())
         parity = dict(checked_views=n_chk, checker='oracle-backed scene driver (oracle/net.py: oracle/costvolume.py + '
                       'oracle/scene.py), same driver code, CPU',
@@ -489,7 +538,7 @@ def bench_scene(args, rank, world, dev, dist):
                    'refs_per_scene': refs, 'refs_per_gpu': refs // world, 'edges_per_ref': nb + na + 1,
                    'parallelism': ('ref-view sharding + RCCL all-gather of the feature-rich point cloud per outer '
                                    'iteration (the communicating mode)' if world > 1 else 'single GPU'),
-                   'ranks_seen': world if dist is None else dist.get_world_size()},
+                   'ranks_seen': n_seen, 'collective': collective},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'parity': parity, 'kernels': kernels}
 
 
@@ -699,14 +748,14 @@ def main():
             extra = {}
             a5 = copy.copy(args)
             a5.config, a5.refs, a5.steps, a5.warmup = 'cfg5', 8, min(args.steps, 10), 2
-            a5.check_refs, a5.host_check_refs, a5.cpu_timing, a5.graph = 4, 4, False, False
+            a5.check_refs, a5.host_check_refs, a5.cpu_timing, a5.graph = 8, 4, False, False
             extra['cfg5'] = compact(bench_costvolume(a5, rank, world, dev, dist))
             a3 = copy.copy(args)
             a3.config, a3.refs, a3.steps, a3.warmup = 'cfg3', 64, min(args.steps, 10), 2
             extra['cfg3'] = compact(bench_scene(a3, rank, world, dev, dist))
             # ... and the same scene with stage 3 (full-resolution output): BASELINE config 3's "Full 3DVNet" end to end
             a3f = copy.copy(a3)
-            a3f.stage3, a3f.steps = True, min(args.steps, 5)
+            a3f.stage3, a3f.steps, a3f.cpu_timing = True, min(args.steps, 10), False
             line3f = bench_scene(a3f, rank, world, dev, dist)
             extra['cfg3_full'] = compact(line3f)
             extra['cfg3_full']['stage3'] = line3f.get('stage3')

@@ -47,6 +47,21 @@ extern "C" {
 #define V3D_PRECISION_SPLIT_BF16 0
 #define V3D_PRECISION_FP32 1
 
+/* Developer options: process-wide integers the launch paths read (they replace the environment variables of earlier rounds; a
+ * production caller never needs them -- every default is the shipped path).  Names / values:
+ *   "psv_kernel"      0 auto (window kernel; reuse kernel for feature stacks >= 2 GB) | 1 reuse kernel | 2 gather kernel
+ *   "psv_threads"     64 | 256   workgroup size of the gather kernel
+ *   "c12_march"       1 conv1 + conv2 of CostRegNet as one depth march | 0 the two tile kernels (another summation order of conv2)
+ *   "c12_nseg"        0 auto | z segments per tile of that march
+ *   "c9_kernel"       0 tile kernel | 1 depth-march experiment (libraries built with -DV3D_EXPERIMENTS only) | 2 exact-fp32 unfused
+ *   "conv_vec"        1 | 0      float4 staging in the exact-fp32 per-layer kernel
+ *   "stop_after"      layer after which v3d_costreg_depth_* returns (-DV3D_PHASE_TIMING builds)
+ *   "gemm_rounds"     1 | 0      gather-GEMM in rounds for small M (bit-identical to the one-step kernel)
+ *   "gemm_round_rows" 0 auto | 32 | 64 | 128
+ * Unknown names -> V3D_ERR_BAD_ARG; an option this build cannot honour -> V3D_ERR_UNSUPPORTED. */
+int v3d_set_option(const char* name, int value);
+int v3d_get_option(const char* name, int* value);
+
 /* ABI version (bumped on any signature change) and last error text of the calling thread. */
 int v3d_version(void);
 const char* v3d_last_error(void);

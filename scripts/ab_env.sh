@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer A/B of runtime switches on one box: alternates `bench_layers.py` between environment settings (each argument one
-# setting, "" = default), N rounds, prints every run; e.g.  bash scripts/ab_env.sh 4 "" "V3D_PSV_REUSE=1"
+# setting, "" = default), N rounds, prints every run; e.g.  bash scripts/ab_env.sh 4 "" "V3D_OPTIONS=psv_kernel=1"
+# (V3D_OPTIONS: developer options of the library, applied by 3dvnet_amd/_lib.py through v3d_set_option)
 N=$1; shift
 for r in $(seq 1 $N); do
   for e in "$@"; do

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer check: the regularised volume and depth of two seeded cost-volume inputs (a cfg1 batch; a volume with partial
 28-wide x tiles and a ragged edge list) written to an .npz -- run once per conv9+prob kernel (default = tile kernel,
-V3D_C9_MARCH=1 = the depth-march experiment, csrc/conv9z.hip: the switch is read once per process) and compare."""
+`--option c9_kernel=1` = the depth-march experiment, csrc/conv9z.hip, -DV3D_EXPERIMENTS builds only; `--option c12_march=0` = the conv1 /
+conv2 tile kernels) and compare.  Exit code 3: the library refuses the option (experiment not in this build)."""
 import importlib
 import os
 import sys
@@ -17,6 +18,13 @@ syn = importlib.import_module('3dvnet_amd.synthetic')
 mvs = importlib.import_module('3dvnet_amd.mvsnet')
 Batch = importlib.import_module('3dvnet_amd.batch').Batch
 dev = torch.device('cuda:0')
+opts = {}
+for a in sys.argv[2:]:
+    if a.startswith('--option='):                      # developer options of the library (include/v3d.h: v3d_set_option)
+        name, val = a[len('--option='):].split('=')
+        opts[name] = int(val)
+        if libm.load().v3d_set_option(name.encode(), int(val)) == -5:       # V3D_ERR_UNSUPPORTED
+            sys.exit(3)
 out = {}
 sd = syn.costregnet_weights(seed=3, sharpen=200.0)
 inp = syn.make_costvolume_inputs('cfg1', n_ref=3, seed=21)
@@ -39,5 +47,5 @@ b2 = Batch(None, R, tv, K, None, edges).to(dev)
 with torch.no_grad():
     depth, _, reg = net2.cost_volume_depth(feat.to(dev), b2, 0.5, 0.1, D, plane_size, return_intermediates=True)
 out['depth_b'], out['reg_b'] = depth.cpu().numpy(), reg.cpu().numpy()
-out['kernel'] = 'conv9z_kernel' if os.environ.get('V3D_C9_MARCH') else 'conv9_prob_kernel'
+out['kernel'] = 'conv9z_kernel' if opts.get('c9_kernel') == 1 else 'conv9_prob_kernel'
 np.savez(sys.argv[1], **out)

@@ -34,6 +34,6 @@ ms = t0.elapsed_time(t1) / 10
 msg = 'M=%d C=%d: %.1f us = %.1f TFLOP/s' % (M, C, ms * 1e3, 2.0 * M * 27 * (1 - args.absent) * C * C / ms / 1e9)
 if hasattr(lib, 'v3d_debug_gemm_phase_read'):
     fn = lib.v3d_debug_gemm_phase_read; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-    buf = (ctypes.c_ulonglong * 8)(); rows = int(os.environ.get('V3D_GEMM_ROUND_ROWS', '32')); nb = (M + rows - 1) // rows; fn(buf, nb); tot = sum(buf)
+    buf = (ctypes.c_ulonglong * 8)(); rows = dict(i.split('=') for i in filter(None, os.environ.get('V3D_OPTIONS', '').split(','))).get('gemm_round_rows', '32'); rows = int(rows) or 32; nb = (M + rows - 1) // rows; fn(buf, nb); tot = sum(buf)
     msg += '; cycles/workgroup %.0f: ' % (tot / nb) + ' '.join('%d:%.0f' % (i, v / nb) for i, v in enumerate(buf))
 print(msg)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer check: SHA-256 of the variance volume for a few seeded inputs -- run once per kernel variant (default = window
-kernel, V3D_PSV_REUSE=1 = round-2 reuse kernel, V3D_PSV_GATHER=1 = plain gather) and compare: the variants must agree bit for
+kernel, `--option psv_kernel=1` = round-2 reuse kernel, `--option psv_kernel=2` = plain gather) and compare: the variants must agree bit for
 bit.  Besides the bench geometries: 7 edges (division path of the mean), and camera pairs for which the window kernel's
 16 x 4-cell window cannot hold a wave's footprints (source camera zoomed 3x / rolled by 90 degrees / far off to the side), on a
 plane grid that is not a multiple of the 8-pixel tiles and a plane count that is not a multiple of 8 -- fp32 and split output."""
@@ -15,6 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 syn = importlib.import_module('3dvnet_amd.synthetic')
 mvs = importlib.import_module('3dvnet_amd.mvsnet')
 dev = torch.device('cuda:0')
+for a in sys.argv[1:]:
+    if a.startswith('--option='):                      # developer options of the library (include/v3d.h: v3d_set_option)
+        name, val = a[len('--option='):].split('=')
+        importlib.import_module('3dvnet_amd._lib').set_option(name, int(val))
 for cfg, n_ref, seed in (('cfg2', 4, 1), ('cfg1', 3, 2), ('cfg2', 2, 3)):
     inp = syn.make_costvolume_inputs(cfg, n_ref=n_ref, seed=seed)
     d0, dd, D = inp['depth']

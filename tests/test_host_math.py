@@ -1,5 +1,9 @@
 """CPU checks of arithmetic identities the HIP kernels rely on (numpy emulation of the fp32 instruction sequences)."""
+import importlib
+
 import numpy as np
+import pytest
+import torch
 
 
 def _fma32(a, b, c):
@@ -152,3 +156,45 @@ def test_pack_cache_key_sees_replaced_and_moved_parameters():
     assert mvs.module_state_key(m) != k2
     m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
     assert mvs.module_state_key(m) != k2
+
+
+def test_whole_model_state_dict_keys_and_checkpoint_round_trip(tmp_path):
+    """``PL3DVNet.state_dict()`` against the reference's key list (tests/golden/H_state_dict_keys.json, generated by importing the
+    reference's modules: CostRegNet, PointNet, the decoder's Conv1d stack, the three PropagationNets -- names AND shapes), the
+    MinkowskiEngine naming of SURVEY.md 8b for ``sparse_conv.*`` (``.kernel`` [27, Cin, Cout] / [Cin, Cout], ``.gn.weight / .gn.bias``,
+    no biases), and a Lightning-style checkpoint ({'state_dict', 'hyper_parameters'}) through ``PL3DVNet.load_from_checkpoint``
+    (mv3d/eval-3dvnet.py:134): every tensor comes back bit for bit."""
+    import json
+    import os
+    lm = importlib.import_module('3dvnet_amd.lightningmodel')
+    hp = dict(depth_train={'size': (56, 56)}, depth_test={'size': (56, 56)}, edge_len=0.08, feat_dim=32, img_size=(256, 320))
+    net = lm.PL3DVNet(**hp)
+    sd = net.state_dict()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'H_state_dict_keys.json')))
+    for k, shape in gold.items():
+        assert k in sd, 'reference key %s missing' % k
+        assert list(sd[k].shape) == shape, (k, list(sd[k].shape), shape)
+    ours = {k for k in sd if k.split('.')[0] in ('pointnet', 'decoder', 'refine_quarter', 'refine_half', 'refine_full')
+            or k.startswith('mvsnet.cnn_3d.')}
+    assert ours == set(gold), sorted(ours ^ set(gold))[:10]
+    sparse = {k: v for k, v in sd.items() if k.startswith('sparse_conv.')}
+    assert sparse and all(k.endswith(('.kernel', '.gn.weight', '.gn.bias')) for k in sparse), \
+        [k for k in sparse if not k.endswith(('.kernel', '.gn.weight', '.gn.bias'))][:5]
+    for k, v in sparse.items():
+        if k.endswith('.kernel'):
+            assert (v.dim() == 3 and v.shape[0] == 27) or v.dim() == 2, (k, tuple(v.shape))
+    assert set(k.split('.')[0] for k in sd) == {'mvsnet', 'pointnet', 'sparse_conv', 'decoder', 'refine_quarter', 'refine_half',
+                                                'refine_full'}
+    g = torch.Generator().manual_seed(5)
+    rnd = {k: (torch.rand(v.shape, generator=g) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    path = str(tmp_path / 'model.ckpt')
+    torch.save({'state_dict': rnd, 'hyper_parameters': hp, 'epoch': 3}, path)
+    net2 = lm.PL3DVNet.load_from_checkpoint(path)
+    assert not net2.training and net2.hparams.edge_len == 0.08
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, rnd[k]), k
+    bad = dict(rnd)
+    bad['decoder.net.9.weight'] = torch.zeros(1)
+    torch.save({'state_dict': bad, 'hyper_parameters': hp}, path)
+    with pytest.raises(RuntimeError, match='unexpected'):
+        lm.PL3DVNet.load_from_checkpoint(path)

@@ -572,15 +572,12 @@ def test_gather_gemm_rounds_kernel_bit_identical_to_one_step_kernel(M, C, N, cud
     nbr = nbr.to(torch.int32).to(cuda).contiguous()
     res = torch.randn(M, N, generator=g).to(cuda)
     outs = {}
-    for tag, env in (('rounds', None), ('one_step', '1')):
-        if env is None:
-            os.environ.pop('V3D_GEMM_NO_ROUNDS', None)
-        else:
-            os.environ['V3D_GEMM_NO_ROUNDS'] = env
+    for tag, rounds in (('rounds', 1), ('one_step', 0)):
+        old = v3d('_lib').set_option('gemm_rounds', rounds)          # developer option (include/v3d.h: v3d_set_option)
         try:
             outs[tag] = pk(M, [x] * 27, idxs=[nbr[k] for k in range(27)], use_gn=True, residual=res, relu_out=True)
         finally:
-            os.environ.pop('V3D_GEMM_NO_ROUNDS', None)
+            v3d('_lib').set_option('gemm_rounds', old)
     torch.cuda.synchronize()
     assert torch.isfinite(outs['rounds']).all()
     assert torch.equal(outs['rounds'], outs['one_step'])
