@@ -1,7 +1,9 @@
 """A CPU 'net' with the PL3DVNet inference surface whose arithmetic is the oracle -- used by tests to
 exercise the scene driver's chunking / sharding logic without a GPU and as the checker of the HIP
 driver run (tests/test_driver.py; bench.py's cfg3 parity leg).  TEST INFRASTRUCTURE: never imported by the
-product package.  ``pinned=True`` evaluates rows A1-A4 with the host-independent orders of oracle/pinned.py."""
+product package.  ``pinned=True`` evaluates rows A1-A4 and the back-projections of rows B2 / C1 with the host-independent
+orders of oracle/pinned.py.  (In rows B2 / C1 the variance FEATURES of the points still come from this host's torch ops --
+continuous inputs of PointNet and the decoder; the point COORDINATES decide which voxel cell a point falls into.)"""
 import torch
 
 from oracle import costvolume as ocv
@@ -22,7 +24,8 @@ class OracleNet:
         return d, batch.images_batch[ref_idx], None, batch.features_quarter, None, ref_idx
 
     def model_scene(self, depth, depth_batch, feats, rot, tv, K, edges, return_pts=False, gather_fn=None):
-        pts, pf, pb = osc.feature_rich_pointcloud(depth, depth_batch, feats, rot, tv, K, edges, self.img_size)
+        pts, pf, pb = osc.feature_rich_pointcloud(depth, depth_batch, feats, rot, tv, K, edges, self.img_size,
+                                                  pinned=self.pinned)
         if gather_fn is not None:
             pts, pf, pb = gather_fn(pts, pf, pb)
         a_pts, a_idx, a_batch, e = osc.voxelize(pts, pb, self.edge_len)
@@ -33,4 +36,4 @@ class OracleNet:
 
     def run_pointflow(self, xs, depth, depth_batch, feats, rot, tv, K, edges, offset, n):
         return osc.run_pointflow(xs, depth, depth_batch, feats, rot, tv, K, edges, offset, n,
-                                 self.sd['dec'], self.img_size)
+                                 self.sd['dec'], self.img_size, pinned=self.pinned)

@@ -72,6 +72,26 @@ def world_points(K, R, t, ref, depth_start, depth_interval, n_planes, img_size, 
     return torch.stack([dot3_chain(Rr[0, j], c[0], Rr[1, j], c[1], Rr[2, j], c[2]) for j in range(3)])
 
 
+def backproject_points(K, R, t, depth, img_size):
+    """Rows B1-B2 / C1 (lightningmodel.py:138-144, 201-205) with the pinned orders of row A1: X = R^T (K^-1 (p * depth) - t) for
+    the pixel grid of build_img_pts, cameras [n,3,3] / [n,3] of the reference views themselves, depth [n, h, w] -> [n, 3, h*w].
+    The same chains as ``world_points`` (csrc/v3d_common.h: world_point): torch.bmm's last bits depend on the host BLAS, and ONE
+    ulp of a back-projected coordinate next to a voxel boundary moves a point into another cell -- which the sparse U-Net's global
+    receptive field turns into centimetres of depth for thousands of pixels (scripts/parity_scene.py)."""
+    K, R, t, depth = _t(K), _t(R), _t(t), _t(depth)
+    Kinv = torch.linalg.inv(K.double()).float()
+    H, W = img_size
+    n, h, w = depth.shape
+    xs = torch.from_numpy(np.linspace(0, W - 1, w, dtype=np.float32))
+    ys = torch.from_numpy(np.linspace(0, H - 1, h, dtype=np.float32))
+    d = depth.reshape(n, -1)
+    p0 = xs[None, :].expand(h, w).reshape(1, -1) * d
+    p1 = ys[:, None].expand(h, w).reshape(1, -1) * d
+    p2 = d
+    c = [dot3_chain(Kinv[:, i, 0:1], p0, Kinv[:, i, 1:2], p1, Kinv[:, i, 2:3], p2) - t[:, i:i + 1] for i in range(3)]
+    return torch.stack([dot3_chain(R[:, 0, j:j + 1], c[0], R[:, 1, j:j + 1], c[1], R[:, 2, j:j + 1], c[2]) for j in range(3)], dim=1)
+
+
 def sample_positions(X, P_src, img_size, feat_size):
     """Row A2 + grid_sample's un-normalisation for one edge: world points X [3,N] -> (ix, iy) float32 [N]."""
     H, W = img_size

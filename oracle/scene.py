@@ -56,15 +56,20 @@ def _variance_over_edges(img_feats, pts, rotmats, tvecs, K, ref_src_edges, gathe
 
 
 def feature_rich_pointcloud(depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
-                            img_size):
-    """Row B2 (lightningmodel.py:132-174): -> pts [Np,3], pts_feat [Np,C], pts_batch [Np]."""
+                            img_size, pinned=False):
+    """Row B2 (lightningmodel.py:132-174): -> pts [Np,3], pts_feat [Np,C], pts_batch [Np].  ``pinned``: the back-projection
+    with the host-independent evaluation orders of oracle/pinned.py instead of this host's torch.bmm."""
     ref_idx, gather_idx = torch.unique(ref_src_edges[0], return_inverse=True)
     n_imgs = depth_pred.shape[0]
-    K_inv = torch.inverse(K[ref_idx])
-    R_T = rotmats[ref_idx].transpose(2, 1)
-    pts_img = build_img_pts(img_size, depth_pred.shape[1:])[None].repeat(n_imgs, 1, 1)
-    pts_img = pts_img * depth_pred.reshape(n_imgs, 1, -1)
-    pts = torch.bmm(R_T, torch.bmm(K_inv, pts_img) - tvecs[ref_idx].unsqueeze(-1))
+    if pinned:
+        from oracle import pinned as opin
+        pts = opin.backproject_points(K[ref_idx], rotmats[ref_idx], tvecs[ref_idx], depth_pred, img_size)
+    else:
+        K_inv = torch.inverse(K[ref_idx])
+        R_T = rotmats[ref_idx].transpose(2, 1)
+        pts_img = build_img_pts(img_size, depth_pred.shape[1:])[None].repeat(n_imgs, 1, 1)
+        pts_img = pts_img * depth_pred.reshape(n_imgs, 1, -1)
+        pts = torch.bmm(R_T, torch.bmm(K_inv, pts_img) - tvecs[ref_idx].unsqueeze(-1))
     x_var = _variance_over_edges(img_feats, pts, rotmats, tvecs, K, ref_src_edges, gather_idx, img_size)
     C = img_feats.shape[1]
     P = depth_pred.shape[1] * depth_pred.shape[2]
@@ -75,7 +80,7 @@ def feature_rich_pointcloud(depth_pred, depth_batch, img_feats, rotmats, tvecs, 
 
 
 def pointflow_hypotheses(depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges, offset,
-                         n, img_size):
+                         n, img_size, pinned=False):
     """Row C1 (lightningmodel.py:187-235): hypothesis points depth + i*offset, i in [-n, n], and their
     multi-view variance features.  -> pts_hyp [n_ref*P, 2n+1, 3], pts_feat [n_ref*P, 2n+1, C],
     pts_batch [n_ref*P]."""
@@ -88,8 +93,12 @@ def pointflow_hypotheses(depth_pred, depth_batch, img_feats, rotmats, tvecs, K, 
     pts_batch = depth_batch.unsqueeze(1).expand(n_imgs, n_pts).reshape(-1)
     pts_hyp = torch.empty((n_imgs, 3, 2 * n + 1, n_pts), dtype=torch.float32)
     for i in range(-n, n + 1):
-        pts_h = pts_img * (depth_pred.reshape(n_imgs, 1, -1) + i * offset)
-        pts_h = torch.bmm(R_T, torch.bmm(K_inv, pts_h) - tvecs[ref_idx].unsqueeze(-1))
+        if pinned:
+            from oracle import pinned as opin
+            pts_h = opin.backproject_points(K[ref_idx], rotmats[ref_idx], tvecs[ref_idx], depth_pred + i * offset, img_size)
+        else:
+            pts_h = pts_img * (depth_pred.reshape(n_imgs, 1, -1) + i * offset)
+            pts_h = torch.bmm(R_T, torch.bmm(K_inv, pts_h) - tvecs[ref_idx].unsqueeze(-1))
         pts_hyp[..., i + n, :] = pts_h
     n_hpts = (2 * n + 1) * n_pts
     x_var = _variance_over_edges(img_feats, pts_hyp.view(n_imgs, 3, n_hpts), rotmats, tvecs, K,
@@ -355,10 +364,10 @@ def decoder_net(features, sd, eps=1e-5):
 
 
 def run_pointflow(xs, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges, offset, n,
-                  sd_decoder, img_size):
+                  sd_decoder, img_size, pinned=False):
     """Rows C1-C3 (lightningmodel.py:187-242)."""
     pts_hyp, pts_feat, pts_batch = pointflow_hypotheses(depth_pred, depth_batch, img_feats, rotmats,
-                                                        tvecs, K, ref_src_edges, offset, n, img_size)
+                                                        tvecs, K, ref_src_edges, offset, n, img_size, pinned=pinned)
     preds = decoder_net(decoder_features(xs, pts_hyp, pts_feat, pts_batch), sd_decoder)
     return offset_expectation(preds, offset, n, depth_pred.shape)
 

@@ -340,7 +340,8 @@ def test_bench_line_carries_cfg5_and_cfg3_figures(cuda):
     assert e5['roofline']['kernel'] in e5['top_kernels'] and 0 < e5['roofline']['frac'] < 1
     assert e5['parity']['checked_views'] >= 1 and e5['parity']['max_rel_depth_err_gpu_vs_cpu'] < 1e-4
     assert e3['value'] > 0 and e3['refs_per_scene'] == 64 and e3['edges_per_ref'] == 8
-    assert e3['parity']['checked_views'] == 4 and e3['parity']['max_rel_depth_err_gpu_vs_cpu'] < 1e-4
+    assert e3['parity']['checked_views'] == 8 and e3['parity']['max_rel_depth_err_gpu_vs_cpu'] < 1e-4
+    assert len(e3['parity']['per_outer_iteration']) == 2 and 'points_in_different_cells_at_iteration_2' in e3['parity']['free_running']
     assert e3['parity']['max_abs_refinement_m'] > 0.01       # the sweeps really moved the depths
     assert 'replicas' in d['config']['multi_gpu_note']
 

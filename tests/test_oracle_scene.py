@@ -28,6 +28,20 @@ def test_pointcloud_B2():
     assert np.array_equal(batch.numpy(), g['pts_batch'])
 
 
+def test_pinned_backprojection_reproduces_the_reference_points_bit_for_bit():
+    """oracle/pinned.py::backproject_points (the evaluation orders of the reference run behind the goldens, spelled out with
+    elementwise ops: host-independent) against the reference's own points and hypothesis points (B_pointcloud / C_pointflow
+    goldens): EQUAL.  One ulp of a point coordinate next to a voxel face changes the voxel set of the scene model, so the
+    refinement leg is compared with this version of the oracle (oracle/net.py, pinned=True)."""
+    b, g = load_golden('B_pointcloud'), load_golden('C_pointflow')
+    args = (t(b['depth']), t(b['depth_batch']), t(b['feat']), t(b['rotmats']), t(b['tvecs']), t(b['K']), t(b['edges']))
+    size = tuple(int(v) for v in b['img_size'])
+    pts = osc.feature_rich_pointcloud(*args, size, pinned=True)[0]
+    assert np.array_equal(pts.numpy(), b['pts'])
+    hyp = osc.pointflow_hypotheses(*args, float(g['offset']), int(g['n']), size, pinned=True)[0]
+    assert np.array_equal(hyp.numpy(), g['pts_hyp'])
+
+
 def test_voxelize_B3():
     g = load_golden('B_voxelize')
     a_pts, a_idx, a_batch, a_edges = osc.voxelize(t(g['pts']), t(g['pts_batch']), float(g['edge_len']))

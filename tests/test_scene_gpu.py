@@ -44,6 +44,38 @@ def _net(cuda, img_size, dec_in=352, dec_seed=3, sharpen=50.0):
     return net.to(cuda), sd
 
 
+def test_backprojected_points_equal_the_reference_bit_for_bit(cuda):
+    """Rows B2 / C1: the world points of the HIP back-projection (csrc/backproject.hip, the pinned chains of v3d_common.h) against
+    the reference golden's points and hypothesis points: EQUAL -- and against the pinned oracle on a cfg3-sized 6-view scene.
+    (A point one ulp off next to a voxel face lands in another cell; the sparse U-Net turns that into centimetres of depth for
+    thousands of pixels: scripts/parity_scene.py.)"""
+    g, img_size, d = _scene(cuda)
+    net, _ = _net(cuda, img_size)
+    pts = net.construct_feature_rich_pointcloud(d['depth'], d['depth_batch'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'])[0]
+    assert np.array_equal(pts.cpu().numpy(), g['pts'])
+    c = load_golden('C_pointflow')
+    hyp = v3d('lightningmodel').backproject_variance(d['depth'], d['feat'], d['rotmats'], d['tvecs'], d['K'], d['edges'], img_size,
+                                                     offset=float(c['offset']), n=int(c['n']))[0]
+    assert np.array_equal(hyp.cpu().numpy().reshape(c['pts_hyp'].shape), c['pts_hyp'])
+    from oracle import scene as osc
+    syn = v3d('synthetic')
+    cfg = syn.CONFIGS['cfg3']
+    edges, n_img = syn.make_edges(6, 4, 3)
+    rot, tv, K = syn.make_cameras(n_img, cfg['img_size'], seed=9)
+    feat = syn.make_features(n_img, 32, *cfg['feat_size'], seed=9)
+    depth = syn.ray_box_depth(rot[4:10], tv[4:10], K[4:10], cfg['img_size'], (56, 56))
+    depth = depth + 0.02 * torch.randn(depth.shape, generator=torch.Generator().manual_seed(3))
+    db = torch.zeros(6, dtype=torch.long)
+    net3 = v3d('lightningmodel').PL3DVNet(None, {'size': (56, 56)}, 0.04, feat_dim=32, img_size=cfg['img_size']).eval().to(cuda)
+    p_hip = net3.construct_feature_rich_pointcloud(*(x.to(cuda) for x in (depth, db, feat, rot, tv, K, edges)))[0]
+    p_cpu = osc.feature_rich_pointcloud(depth, db, feat, rot, tv, K, edges, cfg['img_size'], pinned=True)[0]
+    assert torch.equal(p_hip.cpu(), p_cpu)
+    h_hip = v3d('lightningmodel').backproject_variance(depth.to(cuda), feat.to(cuda), rot.to(cuda), tv.to(cuda), K.to(cuda),
+                                                       edges.to(cuda), cfg['img_size'], offset=0.025, n=3)[0]
+    h_cpu = osc.pointflow_hypotheses(depth, db, feat, rot, tv, K, edges, 0.025, 3, cfg['img_size'], pinned=True)[0]
+    assert torch.equal(h_hip.cpu().reshape(h_cpu.shape), h_cpu)
+
+
 def test_backproject_pointcloud_B2(cuda):
     g, img_size, d = _scene(cuda)
     net, _ = _net(cuda, img_size)
