@@ -108,6 +108,12 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
     'v3d_decoder_fused_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'v3d_conv_pack': (c_int, [c_float_p, c_float_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'v3d_conv_free': (None, [c_void_p]),
+    'v3d_conv_nhwc_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
+    'v3d_depthwise_nhwc_f32': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_void_p]),
+    'v3d_stem_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
+    'v3d_nhwc_to_nchw_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
 }

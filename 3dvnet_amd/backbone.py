@@ -12,14 +12,23 @@ reference checkpoint carries under ``mvsnet.feat_extractor.*`` / ``mvsnet.feat_s
     additions, 3x3 output convolutions, all with bias -- returning ``feat_dim`` channels per level, finest first
     (mvsnet.py:83-105).
 
-Stock 2D convolutions executed by PyTorch-ROCm (MIOpen), as in the reference; nothing here is a hand-written kernel.
+The ``nn.Module`` classes are the PARAMETER CONTAINERS (torchvision's key names) and, on the CPU, the restated arithmetic the
+device path is tested against.  On a HIP device ``NativeBackbone`` runs both networks on the library's own kernels
+(csrc/backbone.hip, round 5): channels-last fp32 activations, eval-mode BatchNorm folded into weights / bias, bias + ReLU +
+residual (inverted-residual skip, FPN top-down addition) in the epilogues, 1x1 / 3x3 convolutions as GEMMs on exact-fp32 matrix
+instructions, depthwise and stem kernels -- 2.x ms per 71 images at 256 x 320 where the stock modules on MIOpen took 8.0.
 PARITY UNPINNED: torchvision is not installed, so neither the module tree nor the arithmetic can be compared with the real
-package here; ``tests/test_backbone.py`` pins shapes, strides and key names as documented for torchvision 0.8.2.
-Pretrained ImageNet weights are unavailable offline: ``synthetic.backbone_weights`` provides seeded ones.
+package here; ``tests/test_backbone.py`` pins shapes, strides and key names as documented for torchvision 0.8.2 and the device
+kernels against these modules on the CPU.  Pretrained ImageNet weights are unavailable offline: ``synthetic.backbone_weights``
+provides seeded ones.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
 
 _BN_MOMENTUM = 1 - 0.9997          # torchvision's MnasNet batch-norm momentum (irrelevant in eval mode)
 
@@ -123,3 +132,133 @@ class FeatureShrinker(nn.Module):
 def build_backbone(feat_dim):
     """(feat_extractor, feat_shrinker) as ``MVSNet.__init__`` creates them (mvsnet.py:172-173), in eval mode."""
     return FeatureExtractor().eval(), FeatureShrinker(feat_dim).eval()
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# HIP forward (csrc/backbone.hip)
+# ----------------------------------------------------------------------------------------------------------------------------
+def _fold(conv, bn):
+    """(weight * scale per output channel, bias) of Conv2d followed by eval-mode BatchNorm2d."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    return conv.weight.detach() * scale.view(-1, 1, 1, 1), bn.bias.detach() - bn.running_mean.detach() * scale
+
+
+class _Gemm:
+    """A packed 1x1 / 3x3 convolution (v3d_conv_pack): weight [Cout, Cin, kh, kw] + bias."""
+
+    def __init__(self, weight, bias):
+        lib = _lib.load()
+        co, ci, kh, kw = weight.shape
+        self.taps, self.cin, self.cout = kh * kw, ci, co
+        w = weight.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).float().contiguous().cpu()
+        b = bias.float().contiguous().cpu()
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.v3d_conv_pack(ctypes.cast(w.data_ptr(), _lib.c_float_p), ctypes.cast(b.data_ptr(), _lib.c_float_p),
+                                     co, kh * kw * ci, ctypes.byref(self.handle)), 'v3d_conv_pack')
+
+    def __del__(self):
+        try:       # (at interpreter shutdown the binding module may already be gone: the process frees the image anyway)
+            if getattr(self, 'handle', None) and self.handle.value and _lib is not None:
+                _lib.load().v3d_conv_free(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def __call__(self, x, relu=False, res=None, res_mode=0):
+        n, H, W, _ = x.shape
+        out = torch.empty((n, H, W, self.cout), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().v3d_conv_nhwc_f32(self.handle, x.data_ptr(), n, H, W, self.cin, self.taps, int(relu), res_mode,
+                                                 _lib.ptr(res), out.data_ptr(), _lib.stream_ptr(x.device)), 'v3d_conv_nhwc_f32')
+        return out
+
+
+class _Depthwise:
+    def __init__(self, weight, bias, stride, device):
+        c, _, k, _ = weight.shape
+        self.k, self.stride, self.c = k, stride, c
+        self.w = weight.reshape(c, k * k).t().float().contiguous().to(device)          # [k*k][C]
+        self.b = bias.float().contiguous().to(device)
+
+    def __call__(self, x, relu=True):
+        n, H, W, _ = x.shape
+        s = self.stride
+        out = torch.empty((n, (H + s - 1) // s, (W + s - 1) // s, self.c), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().v3d_depthwise_nhwc_f32(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), n, H, W, self.c, self.k, s,
+                                                      int(relu), out.data_ptr(), _lib.stream_ptr(x.device)), 'v3d_depthwise_nhwc_f32')
+        return out
+
+
+class NativeBackbone:
+    """``(feat_extractor, feat_shrinker)`` on the HIP kernels: ``forward(images [n, 3, H, W]) -> (half, quarter, eighth,
+    sixteenth, thirtysecond)`` in the reference layout [n, feat_dim, h, w] -- what ``feat_shrinker(*feat_extractor(images))``
+    returns (mvsnet.py:66-73, 89-105).  H and W must be multiples of 32 (every pyramid level exactly half the previous one) and
+    ``feat_dim`` a multiple of 32; ``supports()`` says whether a call qualifies (the modules themselves are the fallback)."""
+
+    def __init__(self, feat_extractor, feat_shrinker):
+        self.fe, self.fs = feat_extractor, feat_shrinker
+        self._key, self._ops = None, None
+
+    def supports(self, images):
+        from .mvsnet import module_device
+        return (isinstance(self.fe, FeatureExtractor) and isinstance(self.fs, FeatureShrinker) and images.is_cuda
+                and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] % 32 == 0 and images.shape[3] % 32 == 0
+                and self.fs.fpn.layer_blocks[0].out_channels % 32 == 0 and not self.fe.training and not self.fs.training
+                and module_device(self.fe) == images.device)
+
+    def _build(self, device):
+        from .mvsnet import module_state_key
+        key = (str(device),) + module_state_key(self.fe) + module_state_key(self.fs)
+        if key == self._key:
+            return self._ops
+        l1 = self.fe.layer1
+        w0, b0 = _fold(l1[0], l1[1])
+        ops = dict(stem_w=w0.permute(1, 2, 3, 0).reshape(27, 32).float().contiguous().to(device), stem_b=b0.float().contiguous().to(device))
+        w1, b1 = _fold(l1[3], l1[4])
+        ops['stem_dw'] = _Depthwise(w1, b1, 1, device)
+        ops['stem_pw'] = _Gemm(*_fold(l1[6], l1[7]))
+        stages = []
+        for layer in (self.fe.layer2, self.fe.layer3, self.fe.layer4, self.fe.layer5):
+            blocks = []
+            for stack in layer:
+                for blk in stack:
+                    L = blk.layers
+                    wd, bd = _fold(L[3], L[4])
+                    blocks.append((_Gemm(*_fold(L[0], L[1])), _Depthwise(wd, bd, L[3].stride[0], device), _Gemm(*_fold(L[6], L[7])),
+                                   blk.apply_residual))
+            stages.append(blocks)
+        ops['stages'] = stages
+        fpn = self.fs.fpn
+        ops['inner'] = [_Gemm(m.weight.detach(), m.bias.detach()) for m in fpn.inner_blocks]
+        ops['outer'] = [_Gemm(m.weight.detach(), m.bias.detach()) for m in fpn.layer_blocks]
+        self._key, self._ops = key, ops
+        return ops
+
+    def __call__(self, images):
+        lib = _lib.load()
+        dev = images.device
+        ops = self._build(dev)
+        img = images.contiguous().float()
+        n, _, H, W = img.shape
+        x = torch.empty((n, H // 2, W // 2, 32), dtype=torch.float32, device=dev)
+        _lib.check(lib.v3d_stem_f32(img.data_ptr(), ops['stem_w'].data_ptr(), ops['stem_b'].data_ptr(), n, H, W, x.data_ptr(),
+                                    _lib.stream_ptr(dev)), 'v3d_stem_f32')
+        x = ops['stem_pw'](ops['stem_dw'](x, relu=True), relu=False)
+        maps = [x]                                                  # C1 .. C5, channels-last
+        for blocks in ops['stages']:
+            for expand, dw, project, residual in blocks:
+                y = project(dw(expand(x, relu=True), relu=True), relu=False, res=x if residual else None, res_mode=1 if residual else 0)
+                x = y
+            maps.append(x)
+        inner = ops['inner'][4](maps[4])
+        outs = [None] * 5
+        outs[4] = ops['outer'][4](inner)
+        for i in (3, 2, 1, 0):
+            inner = ops['inner'][i](maps[i], res=inner, res_mode=2)
+            outs[i] = ops['outer'][i](inner)
+        res = []
+        for o in outs:                                              # -> the reference layout [n, C, h, w]
+            nn_, h, w, c = o.shape
+            t = torch.empty((nn_, c, h, w), dtype=torch.float32, device=dev)
+            _lib.check(lib.v3d_nhwc_to_nchw_f32(o.data_ptr(), t.data_ptr(), nn_, c, h * w, _lib.stream_ptr(dev)), 'v3d_nhwc_to_nchw_f32')
+            res.append(t)
+        return tuple(res)

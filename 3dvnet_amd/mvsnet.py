@@ -376,6 +376,8 @@ class MVSNet(nn.Module):
         self.img_size = img_size
         self.feat_extractor = feat_extractor
         self.feat_shrinker = feat_shrinker
+        self.native_backbone = True          # False: the backbone modules run as stock PyTorch modules (MIOpen)
+        self._native_backbone = None
         self.cnn_3d = CostRegNet(feat_dim, 8, precision=precision)
         self._ws = _Workspace()
         self._depth_vals = {}
@@ -428,8 +430,17 @@ class MVSNet(nn.Module):
 
     def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size, n_ref=None):
         if self.feat_extractor is not None:
-            features_half, features_quarter, features_eighth, _, _ = \
-                self.feat_shrinker(*self.feat_extractor(batch.images))
+            # the library's own backbone kernels when the call qualifies (our MnasNet + FPN containers on a HIP device, image
+            # sides multiples of 32); any other pair of modules runs as given
+            if getattr(self, '_native_backbone', None) is None or self._native_backbone.fe is not self.feat_extractor \
+                    or self._native_backbone.fs is not self.feat_shrinker:
+                from .backbone import NativeBackbone
+                self._native_backbone = NativeBackbone(self.feat_extractor, self.feat_shrinker)
+            if self.native_backbone and self._native_backbone.supports(batch.images):
+                features_half, features_quarter, features_eighth, _, _ = self._native_backbone(batch.images)
+            else:
+                features_half, features_quarter, features_eighth, _, _ = \
+                    self.feat_shrinker(*self.feat_extractor(batch.images))
         else:
             features_half = getattr(batch, 'features_half', None)
             features_quarter = batch.features_quarter

