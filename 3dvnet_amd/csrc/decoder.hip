@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
   // this wave's three 1 KB pieces of the slab at `base` -> ring slot `slot` (hand-written LDS-DMA: M0 carries the LDS address, the
   // global address is an SGPR base + lane * 16)
   auto dma_issue = [&](const char* base, int slot) __attribute__((always_inline)) {
-    if (V3D_FUSED_ABLATE == 3 || V3D_FUSED_ABLATE == 9) return;
+    if (V3D_FUSED_ABLATE == 3 || V3D_FUSED_ABLATE == 9 || V3D_FUSED_ABLATE == 12) return;
     base += wave * (kDPieces * 1024);
     const unsigned dst = ring_lds + (unsigned)slot * kDSlab + (unsigned)wave * (kDPieces * 1024);
     const unsigned voff = (unsigned)(threadIdx.x & 63) * 16u;
@@ -295,7 +295,9 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
     else if constexpr (W == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(W == 0, "mid_sync: unsupported wait");
     FPHASE_MARK(0);
+#if V3D_FUSED_ABLATE != 11 && V3D_FUSED_ABLATE != 12        // (11: timing experiment without the rendezvous -- results are wrong)
     __syncthreads();
+#endif
     FPHASE_MARK(7);
     dma_issue(next2, slot == 0 ? 2 : slot - 1);
   };
