@@ -105,7 +105,7 @@ SIGNATURES = {
     'v3d_decoder_fused_f32': (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
                                       ctypes.POINTER(c_int), ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_void_p,
-                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
     'v3d_decoder_fused_workspace_bytes': (c_size_t, [c_int, c_int]),
     'v3d_conv_pack': (c_int, [c_float_p, c_float_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -172,6 +172,7 @@ struct FusedParams {
   const float* vals;          // [n_hyp] offset values or null
   float* preds;               // [n_pts, n_hyp]
   float* expect;              // [n_pts] or null
+  float* depth_io;            // [n_pts] or null: depth_io[pt] += expected offset (the caller's `depth += offset`, eval-3dvnet.py:99)
 };
 
 __device__ __forceinline__ unsigned fused_pack_bf16x2(float a, float b) {
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(kDThreads, 2) void decoder_fused_kernel(FusedParams
       if (g == 0 && pt < p.n_pts) {
         if (hyp_ok) p.preds[(size_t)pt * n_hyp + h] = pr;
         if (h == 0 && p.expect) p.expect[pt] = e;
+        if (h == 0 && p.depth_io) p.depth_io[pt] += e;
       }
     }
     FPHASE_MARK(2);
@@ -723,7 +725,7 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
                                      const float* const* level_min_pts_host, const float* level_res_host,
                                      const float* pts, const int64_t* pts_batch, const float* pts_feat, int c_feat,
                                      int n_pts, int n_hyp, const float* offset_vals, float* preds, float* expect,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     float* depth_inout, void* workspace, size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(layers_host && head_weight && head_bias && level_table_host && level_n_host && level_feats_host &&
                   level_C_host && level_stride_host && level_min_pts_host && level_res_host && pts && pts_batch && preds,
               V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: null argument");
@@ -732,7 +734,7 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   V3D_REQUIRE((long long)n_pts * n_hyp < (1ll << 24), V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: n_pts=%d too large for one call", n_pts);
   V3D_REQUIRE(c_feat >= 0 && c_feat % 16 == 0 && (c_feat == 0 || pts_feat), V3D_ERR_UNSUPPORTED,
               "v3d_decoder_fused_f32: c_feat=%d must be a multiple of 16 (with pts_feat given)", c_feat);
-  V3D_REQUIRE(!expect || offset_vals, V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: expect without offset_vals");
+  V3D_REQUIRE((!expect && !depth_inout) || offset_vals, V3D_ERR_BAD_ARG, "v3d_decoder_fused_f32: expect / depth_inout without offset_vals");
   V3D_REQUIRE(workspace && workspace_bytes >= v3d_decoder_fused_workspace_bytes(n_pts, n_hyp), V3D_ERR_WORKSPACE_TOO_SMALL,
               "v3d_decoder_fused_f32: workspace of %zu bytes, need %zu", workspace_bytes,
               v3d_decoder_fused_workspace_bytes(n_pts, n_hyp));
@@ -769,7 +771,7 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   V3D_REQUIRE(p.nstep1 >= 2, V3D_ERR_UNSUPPORTED, "v3d_decoder_fused_f32: the first layer needs at least 32 input channels");
   p.ctab = reinterpret_cast<const u32x2*>(workspace);
   p.pts_feat = pts_feat; p.c_feat = c_feat; p.n_pts = n_pts; p.n_hyp = n_hyp;
-  p.head_w = head_weight; p.head_b = head_bias; p.vals = offset_vals; p.preds = preds; p.expect = expect;
+  p.head_w = head_weight; p.head_b = head_bias; p.vals = offset_vals; p.preds = preds; p.expect = expect; p.depth_io = depth_inout;
   cp.pts = pts; cp.pts_batch = (const long long*)pts_batch; cp.n_hyp = n_hyp; cp.n_q = n_pts * n_hyp;
   cp.out = reinterpret_cast<u32x2*>(workspace);
   if (n_pts == 0) return V3D_OK;

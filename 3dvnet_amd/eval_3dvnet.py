@@ -206,12 +206,16 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                                  gather_fn=gather_fn, **hints)
             for offset in offsets:
                 for b0, b1, e, csr in chunks:
-                    kw = {} if csr is None else {'csr': csr}
-                    # (`all_depth[b0:b1] += ...` is add_ on the view followed by a copy of the view onto itself)
-                    all_depth[b0:b1].add_(net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
-                                                            feats_local[b0:b1 + halo], rot[b0:b1 + halo],
-                                                            tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3,
-                                                            **kw))
+                    # `all_depth[b0:b1] += offset` (eval-3dvnet.py:99): inside the decoder kernel when the net offers it (the
+                    # HIP net; the slice is a contiguous view), else here
+                    if csr is not None:
+                        net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1], feats_local[b0:b1 + halo],
+                                          rot[b0:b1 + halo], tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3, csr=csr,
+                                          add_to_depth=True)
+                    else:
+                        all_depth[b0:b1].add_(net.run_pointflow(xs, all_depth[b0:b1], depth_batch[b0:b1],
+                                                                feats_local[b0:b1 + halo], rot[b0:b1 + halo],
+                                                                tv[b0:b1 + halo], K[b0:b1 + halo], e, offset, 3))
         if hints:
             unet.flush_checks()             # hash-table range checks of both scene models: one wait here, not two in between
         if upsample:

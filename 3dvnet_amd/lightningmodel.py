@@ -160,14 +160,17 @@ class PL3DVNet(nn.Module):
                                                       e0.shape[0], feat_c.shape[1], _lib.ptr(x), _lib.stream_ptr(pts.device)),
                    'v3d_pointnet_input_f32')
         x = self.pointnet(x, anchor_pts_edges[0], n_anchors)
+        # (utils.voxelize shifts every batch element's minimum index to 0, utils.py:61-62: the U-Net needs no reduction for it)
         xs = self.sparse_conv(x, anchor_pts, anchor_idx3d, anchor_batch, self.edge_len, n_batches=n_batches,
-                              defer_checks=defer_checks)
+                              defer_checks=defer_checks, idx_min_zero=True)
         return (xs, pts) if return_pts else xs
 
     def run_pointflow(self, xs, depth_pred, depth_batch, img_feats, rotmats, tvecs, K, ref_src_edges,
-                      offset, n, csr=None):
+                      offset, n, csr=None, add_to_depth=False):
         """lightningmodel.py:187-242 -> offset prediction [n_ref, h, w].  ``csr`` (optional) is the result of
-        ``mvsnet.edges_to_csr(ref_src_edges)`` when the caller sweeps the same edge list repeatedly."""
+        ``mvsnet.edges_to_csr(ref_src_edges)`` when the caller sweeps the same edge list repeatedly.  ``add_to_depth``: the
+        caller's ``depth_pred += offset`` (eval-3dvnet.py:99) happens inside the decoder kernel (``depth_pred`` must be a
+        contiguous fp32 tensor; it is modified in place and the offset is still returned)."""
         n_imgs = depth_pred.shape[0]
         n_pts = depth_pred.shape[1] * depth_pred.shape[2]
         pts_hyp, pts_feat = backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges,
@@ -193,8 +196,14 @@ class PL3DVNet(nn.Module):
             self._offset_vals[key] = torch.linspace(-n * offset, n * offset, 2 * n + 1).to(depth_pred.device)
         offset_vals = self._offset_vals[key]
         if self.decoder.can_fuse(xs, pts_hyp, pts_feat):
-            _, expect = self.decoder.decode_fused(xs, pts_hyp, pts_feat, pts_batch, offset_vals)
+            fuse_add = add_to_depth and depth_pred.is_contiguous() and depth_pred.dtype == torch.float32
+            _, expect = self.decoder.decode_fused(xs, pts_hyp, pts_feat, pts_batch, offset_vals,
+                                                  depth_inout=depth_pred if fuse_add else None)
+            if add_to_depth and not fuse_add:
+                depth_pred.add_(expect.view(n_imgs, *depth_pred.shape[1:]))
         else:
             feats = self.decoder.features(xs, pts_hyp, pts_feat, pts_batch)
             _, expect = self.decoder.decode(feats, offset_vals)
+            if add_to_depth:
+                depth_pred.add_(expect.view(n_imgs, *depth_pred.shape[1:]))
         return expect.view(n_imgs, *depth_pred.shape[1:])

@@ -117,9 +117,10 @@ class HypothesisDecoder(nn.Module):
                 and cf % 16 == 0 and all(x['feats'].shape[1] % 16 == 0 for x in xs)
                 and sum(x['feats'].shape[1] for x in xs) + cf == self.in_dim)
 
-    def decode_fused(self, xs, pts, pts_feat, pts_batch, offset_vals=None):
+    def decode_fused(self, xs, pts, pts_feat, pts_batch, offset_vals=None, depth_inout=None):
         """Rows C2a + C2b (+ C3) in one kernel: interpolation, the three conv1d layers, head and softmax
-        (and the expected offset when offset_vals is given); nothing of size [Nq, in_dim, n_hyp] is materialised."""
+        (and the expected offset when offset_vals is given); nothing of size [Nq, in_dim, n_hyp] is materialised.
+        ``depth_inout`` (contiguous fp32 [Nq], optional): the expected offset is also added to it in place."""
         assert not self.training, 'inference only: BatchNorm is folded with running statistics'
         lib = _lib.load()
         dev = pts.device
@@ -157,7 +158,7 @@ class HypothesisDecoder(nn.Module):
         ws = self._ws.get('fused', lib.v3d_decoder_fused_workspace_bytes(n_pts, n_hyp), dev)
         rc = lib.v3d_decoder_fused_f32(layers, w_last.data_ptr(), b_last.data_ptr(), tables, n_in, feats, chans, strides,
                                        mins, res, pts.data_ptr(), pts_batch.data_ptr(), _lib.ptr(pts_feat), cf, n_pts,
-                                       n_hyp, _lib.ptr(offset_vals), preds.data_ptr(), _lib.ptr(expect),
+                                       n_hyp, _lib.ptr(offset_vals), preds.data_ptr(), _lib.ptr(expect), _lib.ptr(depth_inout),
                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, 'v3d_decoder_fused_f32')
         return preds if expect is None else (preds, expect)

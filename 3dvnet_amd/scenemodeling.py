@@ -230,6 +230,38 @@ class SparseLevel:
         return nbr
 
 
+class LevelInfo(dict):
+    """One level of ``SparseUNet.forward``'s result (scenemodeling.py:210-237): keys ``feats, pts, res, batch, idx, stride,
+    sparse``.  ``pts`` (= idx * res + pts_min[batch], :225-226), ``idx`` and ``batch`` are derived from the level's coordinate
+    map ON FIRST ACCESS: the HIP decoder consumes the hash table, the features and the level's minimum point only, so a scene
+    sweep never launches the nine elementwise kernels that materialise them (they cost ~40 launches per scene)."""
+
+    _LAZY = ('pts', 'idx', 'batch')
+
+    def __init__(self, level, res, pts_min, like):
+        super().__init__()
+        self._level, self._res, self._pts_min, self._like = level, res, pts_min, like
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        c = self._level.coords
+        if key == 'idx':
+            v = c[:, 1:].type_as(self._like)
+        elif key == 'batch':
+            v = c[:, 0].type_as(self._like)
+        else:
+            v = self['idx'] * self._res + self._pts_min[self['batch']]
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key in self._LAZY or super().__contains__(key)
+
+    def keys(self):
+        return list(super().keys()) + [k for k in self._LAZY if not super().__contains__(k)]
+
+
 class SparseUNet(nn.Module):
     """Reference ``SparseUNet(dims, n_groups, n_res)`` (scenemodeling.py:147-237):
     ``forward(F, pts, idx, batch, res) -> list[dict(feats, pts, res, batch, idx, stride, sparse)]``,
@@ -312,7 +344,7 @@ class SparseUNet(nn.Module):
         for lv in pending:
             lv.check()
 
-    def forward(self, F, pts, idx, batch, res, n_batches=None, defer_checks=False):
+    def forward(self, F, pts, idx, batch, res, n_batches=None, defer_checks=False, idx_min_zero=False):
         if not F.is_cuda:
             raise _lib.V3DLibraryError('SparseUNet: tensors must live on a HIP device (no CPU fallback)')
         self._dev = F.device
@@ -346,7 +378,6 @@ class SparseUNet(nn.Module):
                 x = self._residual(g[('res_up', i, l)], blk, x, same_rev[i + 1])
             out.append((tgt, x))
 
-        out_info = []
         if n_batches is None:
             n_batches = int(torch.max(batch).item()) + 1                               # scenemodeling.py:221
         # rows the hash tables refused (range check): read the status words now (one readback each, after the last kernel of
@@ -357,37 +388,44 @@ class SparseUNet(nn.Module):
             self.flush_checks()
         # scenemodeling.py:222-231 per batch element b: pts_min = pts[batch == b][0] - idx[batch == b][0] * res and
         # x_pts = x_idx * res + pts_min -- the same numbers without a boolean-mask gather (and its host synchronisation) per
-        # level and batch element: the first row of every batch element.  With few batch elements that is the first True of a
-        # [n_batches, N] comparison (argmax returns the first maximum); a scatter-min of the row index serialises its atomics
-        # on n_batches addresses (1.3 ms for 60 k rows of one scene) and is kept for many small batch elements only
-        if n_batches <= 32:
-            ids = torch.arange(n_batches, device=batch.device, dtype=batch.dtype)
-            first = (batch[None, :] == ids[:, None]).to(torch.uint8).argmax(dim=1)
+        # level and batch element: the first row of every batch element.  One batch element (a scene): that is row 0.  A few:
+        # the first True of a [n_batches, N] comparison (argmax returns the first maximum); a scatter-min of the row index
+        # serialises its atomics on n_batches addresses (1.3 ms for 60 k rows of one scene) and is kept for many small batch
+        # elements only
+        if n_batches == 1:
+            pts_min = pts[0:1] - idx[0:1] * res                                        # [1, 3]
         else:
-            rows = torch.arange(batch.shape[0], device=batch.device)
-            first = torch.full((n_batches,), batch.shape[0], dtype=rows.dtype, device=batch.device) \
-                .scatter_reduce_(0, batch.to(rows.dtype), rows, 'amin')
-        pts_min = pts[first] - idx[first] * res                                        # [n_batches, 3]
+            if n_batches <= 32:
+                ids = torch.arange(n_batches, device=batch.device, dtype=batch.dtype)
+                first = (batch[None, :] == ids[:, None]).to(torch.uint8).argmax(dim=1)
+            else:
+                rows = torch.arange(batch.shape[0], device=batch.device)
+                first = torch.full((n_batches,), batch.shape[0], dtype=rows.dtype, device=batch.device) \
+                    .scatter_reduce_(0, batch.to(rows.dtype), rows, 'amin')
+            pts_min = pts[first] - idx[first] * res                                    # [n_batches, 3]
         # One batch element: x_pts is monotone in x_idx per axis (fl(fl(i * res) + pts_min), res > 0), so the minimum of a level's
         # x_pts is that formula at the level's minimum index, and a level of stride s holds floor(c / s) * s of the finest
-        # coordinates c: ONE integer reduction over the finest level instead of a float reduction per level
+        # coordinates c: ONE integer reduction over the finest level instead of a float reduction per level -- and none at all
+        # when the caller vouches that every axis' minimum index is 0 (``idx_min_zero``: utils.voxelize shifts them there,
+        # utils.py:61-62), in which case the minimum point of every level IS pts_min
         idx_min = None
-        if n_batches == 1:
-            fine = min((lv for lv, _ in out), key=lambda l: l.stride)
+        fine = min(levels, key=lambda l: l.stride)
+        if n_batches == 1 and not idx_min_zero:
             idx_min = fine.coords[:, 1:].amin(dim=0, keepdim=True)                      # [1, 3] int32
+        out_info = []
         for lv, xf in out:
-            x_idx = lv.coords[:, 1:].type_as(batch)
-            x_batch = lv.coords[:, 0].type_as(batch)
-            x_pts = x_idx * res + pts_min[x_batch]
             lv.feats = xf
+            info = LevelInfo(lv, res, pts_min, batch)
             # scatter(x.pts, x.batch, reduce='min') of the interpolation (refinement.py:33), here where the number of batch
             # elements is known: the decoder would have to read it back from the device in front of its first launch
-            if n_batches == 1:
+            if n_batches == 1 and idx_min_zero:
+                min_pts = pts_min
+            elif n_batches == 1:
                 lv_min = torch.div(idx_min, lv.stride, rounding_mode='floor') * lv.stride if lv.stride != fine.stride else idx_min
                 min_pts = lv_min.type_as(batch) * res + pts_min[0:1]
             else:
-                sel = x_batch[None, :, None] == torch.arange(n_batches, device=x_batch.device)[:, None, None]
-                min_pts = torch.where(sel, x_pts[None], x_pts.new_full((), float('inf'))).amin(dim=1)
-            out_info.append({'feats': xf, 'pts': x_pts, 'res': lv.stride * res, 'batch': x_batch,
-                             'idx': x_idx, 'stride': lv.stride, 'sparse': lv, '_min_pts': min_pts})
+                sel = info['batch'][None, :, None] == torch.arange(n_batches, device=batch.device)[:, None, None]
+                min_pts = torch.where(sel, info['pts'][None], info['pts'].new_full((), float('inf'))).amin(dim=1)
+            info.update({'feats': xf, 'res': lv.stride * res, 'stride': lv.stride, 'sparse': lv, '_min_pts': min_pts})
+            out_info.append(info)
         return out_info

@@ -365,6 +365,8 @@ int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* feat
  *                 stride, per-batch minimum point [n_batch, 3] (refinement.py:33), x.res
  *   pts [n_pts, n_hyp, 3], pts_batch [n_pts] int64, pts_feat [n_pts, n_hyp, c_feat] or NULL (c_feat 0 or a multiple of 16),
  *   n_hyp <= 8; head_weight [1, 128, 3], head_bias [1]; offset_vals [n_hyp] or NULL; preds [n_pts, n_hyp]; expect [n_pts] or NULL
+ *   depth_inout   [n_pts] or NULL: the expected offset is also ADDED to it in place (the driver's `depth += offset`,
+ *                 mv3d/eval-3dvnet.py:99: one elementwise launch less per sweep)
  *   workspace     v3d_decoder_fused_workspace_bytes(n_pts, n_hyp) bytes, 16-byte aligned (ABI version 3) */
 size_t v3d_decoder_fused_workspace_bytes(int n_pts, int n_hyp);
 int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const float* head_weight, const float* head_bias,
@@ -372,8 +374,8 @@ int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const floa
                           const float* const* level_feats_host, const int* level_C_host, const int* level_stride_host,
                           const float* const* level_min_pts_host, const float* level_res_host, const float* pts,
                           const int64_t* pts_batch, const float* pts_feat, int c_feat, int n_pts, int n_hyp,
-                          const float* offset_vals, float* preds, float* expect, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          const float* offset_vals, float* preds, float* expect, float* depth_inout, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SURVEY.md 8f rank 3 -- the 2D feature extractor of MVSNet (mv3d/subnetworks/mvsnet.py:55-105: torchvision MnasNet-1.0 trunk +

@@ -50,7 +50,7 @@ drv.process_scene(b, net, k, dev); torch.cuda.synchronize()
 print('host-side copy sites of one scene:')
 for key, n in sorted(copies.items(), key=lambda kv: -kv[1])[:40]:
     print('%5d  %-12s %s' % (n, key[0], key[1]))
-sys.exit(0)
+if not os.environ.get("V3D_TRACE_PROFILER"): sys.exit(0)
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     drv.process_scene(b, net, k, dev); torch.cuda.synchronize()
 by = collections.Counter(); dur = collections.Counter()

@@ -311,6 +311,10 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         p_f, e_f = dec.decode_fused(xs, pts, pf, pts_batch, vals)
         p_f2, _ = dec.decode_fused(xs, pts, pf, pts_batch, vals)
         assert torch.equal(p_f, p_f2)                           # deterministic (see the repeated-launch test below)
+        d0 = torch.rand(667, device=cuda)                        # the driver's `depth += offset` inside the kernel
+        d1 = d0.clone()
+        _, e_f3 = dec.decode_fused(xs, pts, pf, pts_batch, vals, depth_inout=d1)
+        assert torch.equal(e_f3, e_f) and torch.equal(d1, d0 + e_f)
         p_u, e_u = dec.decode(dec.features(xs, pts, pf, pts_batch), vals)
         torch.cuda.synchronize()
         assert float(p_u.max()) > 0.5                      # peaked softmax: the comparison is not vacuous
