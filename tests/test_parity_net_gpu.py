@@ -328,6 +328,44 @@ def test_fused_decoder_matches_unfused_chain_and_golden(cuda):
         assert torch.equal(dec(xs, pts, pf, pts_batch), p_u)
 
 
+@pytest.mark.parametrize('n_hyp', [1, 2, 5, 8])
+def test_fused_decoder_other_hypothesis_counts_and_two_scenes(n_hyp, cuda):
+    """The round-5 kernel owns 8 column slots per query point: hypothesis counts below 8 leave padding slots (their tap masks cut
+    them off), 8 leaves none (the masks alone separate neighbouring points); 1 has no neighbours at all.  Fused path against the
+    5-launch chain on the C_forloop scene (two batch elements), points far outside the scene included (all corners absent:
+    bias-only features), a point count that is not a multiple of the 32-point tile, and the in-place depth update."""
+    import test_scene_gpu as tsg
+    syn, sm, rf = v3d('synthetic'), v3d('scenemodeling'), v3d('refinement')
+    g, u = tsg._unet_inputs(cuda)
+    net = sm.SparseUNet().eval()
+    net.load_state_dict(syn.sparse_unet_weights(seed=int(g['unet_seed'])))
+    xs = net.to(cuda)(u['F'], u['pts'], u['idx'], u['batch'], float(g['edge_len']))
+    from helpers import t
+    base = t(g['pts_hyp']).to(cuda)[:333, 3]                      # centre hypothesis of 333 points
+    pts_batch = t(g['pts_batch']).to(cuda)[:333]
+    gen = torch.Generator().manual_seed(40 + n_hyp)
+    step = torch.randn((333, 1, 3), generator=gen).to(cuda) * 0.03
+    pts = base[:, None, :] + step * (torch.arange(n_hyp, device=cuda).float() - (n_hyp - 1) / 2)[None, :, None]
+    pts[7] += 50.0                                                 # far outside the scene
+    pf = (torch.rand((333, n_hyp, 32), generator=gen) * 0.1).to(cuda)
+    vals = torch.linspace(-0.1, 0.1, n_hyp).to(cuda) if n_hyp > 1 else torch.tensor([0.05], device=cuda)
+    dec = rf.HypothesisDecoder(352, 128, 3, 1).eval()
+    dec.load_state_dict(syn.decoder_weights(in_dim=352, h_dim=128, seed=5, sharpen=20.0), strict=False)
+    dec = dec.to(cuda)
+    assert dec.can_fuse(xs, pts, pf)
+    d0 = torch.rand(333, device=cuda)
+    d1 = d0.clone()
+    p_f, e_f = dec.decode_fused(xs, pts, pf, pts_batch, vals, depth_inout=d1)
+    p_u, e_u = dec.decode(dec.features(xs, pts, pf, pts_batch), vals)
+    torch.cuda.synchronize()
+    assert tuple(p_f.shape) == (333, n_hyp) and torch.isfinite(p_f).all()
+    np.testing.assert_allclose(p_f.sum(dim=1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(p_f.cpu().numpy(), p_u.cpu().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(e_f.cpu().numpy(), e_u.cpu().numpy(), rtol=0, atol=2e-5)
+    assert torch.equal(d1, d0 + e_f)
+    assert set(pts_batch.unique().tolist()) == {0, 1} or int(pts_batch.max()) == 0
+
+
 def test_fused_decoder_is_deterministic_under_load(cuda):
     """Round 2 shipped the fused decoder behind a 96 KB LDS request because results changed from launch to launch with two
     waves per SIMD; round 3 traced that to vectorised (ds_read_b128) reads of a self-written LDS corner table under co-resident
