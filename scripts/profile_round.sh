@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 profiles: rocprofv3 kernel stats + PMC passes of the bench command (cfg2, 64 views; cfg5, 8 views) and the stage-3 /
-# scene kernel stats.  Summaries land in gpurun_out/profile_*; the ones to be judged are copied to profiles/r04_*.
+# scene kernel stats.  Summaries land in gpurun_out/profile_*; the ones to be judged are copied to profiles/r05_*.
 bash scripts/profile_bench.sh cfg2 64 > gpurun_out/r5_profile_cfg2.log 2>&1
 bash scripts/profile_bench.sh cfg5 8 > gpurun_out/r5_profile_cfg5.log 2>&1
 export TMPDIR=/tmp
