@@ -76,6 +76,8 @@ SIGNATURES = {
     'v3d_gemm_gather_f32': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                     ctypes.POINTER(c_int), c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'v3d_sparse_conv_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, ctypes.c_longlong, c_int, c_float, c_void_p,
+                                    c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'v3d_fill_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     'v3d_pointnet_input_f32': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     'v3d_hash_bytes': (c_size_t, [c_int]),

@@ -32,9 +32,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+
+// hi = RNE_bf16(x), lo = RNE_bf16(x - hi) of four floats on packed pairs: v_cvt_pk_bf16_f32 rounds like bf16_rne for finite values
+// (conv0z.hip uses the same pair) at 12 instead of ~50 vector instructions per four values -- the split was the largest item of the
+// staging threads' time in the sparse convolutions
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+__device__ __forceinline__ u32x2 split_hi(f32x4 v) { return (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}; }
+__device__ __forceinline__ u32x2 split_lo(f32x4 v, u32x2 h) {
+  return (u32x2){pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u)),
+                 pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u))};
 }
 
 constexpr int kMaxSeg = 27;
@@ -269,12 +279,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmParams p) {
           // this thread holds k = sc4 .. sc4+3 of the row: half of the 8-wide k group kg = sc4 / 8
           const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
           const int slot = kg ^ ((((row & 15) >> 3) & 1) * 3);
-          const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
-          const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
-          const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+          const u32x2 hp = split_hi(v), lp = split_lo(v, hp);
           u32x2* xh2 = reinterpret_cast<u32x2*>(xs);
-          xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
-          xh2[((kTM + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+          xh2[(row * 4 + slot) * 2 + half] = hp;
+          xh2[((kTM + row) * 4 + slot) * 2 + half] = lp;
         } else {
           float* d = xs + row * kXS + sc4;
           *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
@@ -475,12 +483,10 @@ __global__ __launch_bounds__(256) void gemm_gather_rounds_kernel(GemmParams p) {
             // this thread holds k = sc4 .. sc4+3 of the row: half of the 8-wide k group kg = sc4 / 8
             const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
             const int slot = kg ^ ((((row & 15) >> 3) & 1) * 3);
-            const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
-            const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
-            const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+            const u32x2 hp = split_hi(v), lp = split_lo(v, hp);
             u32x2* xh2 = reinterpret_cast<u32x2*>(xq + j * kTile);
-            xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
-            xh2[((kTM + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+            xh2[(row * 4 + slot) * 2 + half] = hp;
+            xh2[((kTM + row) * 4 + slot) * 2 + half] = lp;
           }
         }
       }
@@ -528,6 +534,231 @@ __global__ __launch_bounds__(256) void gemm_gather_rounds_kernel(GemmParams p) {
   gemm_epilogue<MBW, NB>(p, acc, m0, wave, kq, jn);
   PHASE_MARK(6);
   PHASE_FLUSH;
+}
+
+// ---- the sparse convolution as a loader / matrix pipeline (round 5) ----------------------------------------------------------
+// Phase counters of the rounds kernel on the cfg3 U-Net (13 434 rows x 128 channels, 32-row tiles): of 154 k cycles per
+// workgroup 38 k wait for the gathers, 49 k ISSUE them (the CU's vector-memory path is busy with the 1.77 MB of weight
+// fragments every tile streams: 64 KB per round) and 49 k are the matrix instructions + the wait for those fragments --
+// nothing overlaps, because one wave does all three in turn and its loads retire in order.  Here the roles are separate waves
+// with separate load queues: the loader waves (4 or 8 of them behind the four matrix waves) gather the neighbour rows U rounds
+// ahead (registers), split them and fill a 2-slot LDS ring; waves 0..3 keep the weight fragments of the next AD - 1 rounds in
+// flight and run the matrix instructions; one barrier per round of S steps.  64-row tiles halve the weight stream per row (one workgroup per CU at 13 k rows).  Every load is
+// unconditional (absent rows read row 0 and are masked in registers; rounds behind the end repeat step 0 and are not
+// multiplied), so the compiler's s_waitcnt counting is exact and the prefetch distance survives.  Same step order and MFMA
+// order per accumulator as gemm_gather_kernel<MBW, NB, true>: bit-identical.
+// Step sequence of a tile: the active segments in ascending order x the K chunks, kept as a bit mask + a chunk counter in
+// scalar registers (an LDS step table costs an LDS round trip + v_readfirstlane in front of every load address).
+struct StepIter {
+  unsigned mask;   // active segments not yet finished (wave-uniform)
+  int kc;
+  __device__ __forceinline__ bool next(int nkc, int& sg, int& k) {   // false behind the end (sg = k = 0 then)
+    const bool ok = mask != 0;
+    sg = ok ? __builtin_ctz(mask) : 0;
+    k = ok ? kc : 0;
+    const bool wrap = kc + 1 == nkc;
+    mask = (ok && wrap) ? (mask & (mask - 1)) : mask;
+    kc = ok ? (wrap ? 0 : kc + 1) : kc;
+    return ok;
+  }
+};
+
+#ifndef V3D_PIPE_ABLATE
+#define V3D_PIPE_ABLATE 0     // developer ablations (scripts/micro/sparse_ablate.sh): 1 no MFMAs, 2 no fragment loads, 3 no gathers, 4 no split / LDS writes
+#endif
+// NL: loader waves (4 or 8); AD: depth of the weight-fragment ring of the matrix waves (fragments of AD - 1 rounds in flight)
+template <int MBW, int NB, int NL, int AD, int MINB>
+__global__ __launch_bounds__(256 + 64 * NL, MINB) void gemm_gather_pipe_kernel(GemmParams p) {
+  constexpr int kTM = 16 * NB, MB = 4 * MBW, S = 2, U = 4, NT = 256 + 64 * NL;
+  constexpr int RPP = NL * 8;                       // rows per loader pass: 8 threads x 16 B = one 128-byte row slice
+  constexpr int NPASS = (kTM + RPP - 1) / RPP;
+  constexpr int kWslab = 4 * MBW * 16 * kKC;        // packed floats per (segment, K chunk)
+  constexpr int kTile = 2 * kTM * 4;                // 16-byte slots of one step's activation tile: [hi, lo][row][4 k groups]
+  static_assert(U % AD == 0 && AD >= 2, "the fragment ring must divide the unroll");
+  __shared__ __attribute__((aligned(16))) u32x4 xq[2 * S * kTile];
+  __shared__ int rowtab[kMaxSeg * kTM];
+  __shared__ unsigned s_mask;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = v3d::xcd_contiguous_block() * kTM;
+  const int nkc = p.KP / kKC;
+
+  if (tid == 0) s_mask = 0;
+  __syncthreads();
+  {
+    unsigned mine = 0;
+    for (int e = tid; e < p.n_seg * kTM; e += NT) {
+      const int sg = e / kTM, row = e % kTM, m = m0 + row;
+      const int v = m < p.M ? p.seg[sg].idx[m] : -1;
+      rowtab[e] = v;
+      mine |= (v >= 0 ? 1u : 0u) << sg;
+    }
+    if (mine) atomicOr(&s_mask, mine);
+  }
+  __syncthreads();
+  const unsigned act = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask);
+  const int n_steps = __builtin_popcount(act) * nkc;
+  const int n_rounds = (n_steps + S - 1) / S, n_iter = (n_rounds + U - 1) / U * U;
+  const float* const src = p.seg[0].src;
+  const int ld = p.seg[0].ld;
+
+  if (wave >= 4) {
+    // ---- loader waves ---------------------------------------------------------------------------------------------------------
+    const int ltid = tid - 256, srow = ltid >> 3, sc4 = (ltid & 7) * 4;
+    f32x4 xr[U][S][NPASS];
+    unsigned vm[U];
+    StepIter it = {act, 0};
+    auto issue = [&](f32x4 (&x)[S][NPASS], unsigned& valid) __attribute__((always_inline)) {
+      valid = 0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        int sg, kc;
+        const bool live = it.next(nkc, sg, kc);
+        const int col = kc * kKC + sc4;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+          const int row = srow + RPP * i;
+          const int r = row < kTM ? rowtab[sg * kTM + row] : -1;
+          const bool ok = live && r >= 0 && col < p.K;
+          valid |= (ok ? 1u : 0u) << (j * NPASS + i);
+          const unsigned ofs = (unsigned)(r < 0 ? 0 : r) * (unsigned)ld + (unsigned)(col < p.K ? col : 0);
+#if V3D_PIPE_ABLATE == 3
+          x[j][i] = (f32x4){(float)ofs, 0.f, 0.f, 0.f};
+#else
+          x[j][i] = *reinterpret_cast<const f32x4*>(src + ofs);
+#endif
+        }
+      }
+    };
+    auto commit = [&](int slot, const f32x4 (&x)[S][NPASS], unsigned valid) __attribute__((always_inline)) {
+#if V3D_PIPE_ABLATE == 4
+#pragma unroll
+      for (int j = 0; j < S; ++j)
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) asm volatile("" ::"v"(x[j][i]));
+      return;
+#endif
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+          const int row = srow + RPP * i;
+          if (kTM % RPP == 0 || row < kTM) {
+            f32x4 v = x[j][i];
+            const unsigned keep = 0u - ((valid >> (j * NPASS + i)) & 1u);      // zero row: absent neighbour / behind the end
+            v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
+            v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+            if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
+            const int sl = kg ^ ((((row & 15) >> 3) & 1) * 3);
+            const u32x2 hp = split_hi(v), lp = split_lo(v, hp);
+            u32x2* xh2 = reinterpret_cast<u32x2*>(xq + (slot * S + j) * kTile);
+            xh2[(row * 4 + sl) * 2 + half] = hp;
+            xh2[((kTM + row) * 4 + sl) * 2 + half] = lp;
+          }
+        }
+      }
+    };
+    PHASE_DECL;
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue(xr[u], vm[u]);
+    commit(0, xr[0], vm[0]);
+    issue(xr[0], vm[0]);
+    __syncthreads();
+    PHASE_MARK(7);
+#pragma unroll 1
+    for (int r0 = 0; r0 < n_iter; r0 += U) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        commit((i + 1) & 1, xr[(i + 1) % U], vm[(i + 1) % U]);       // round r + 1 -> the slot the matrix waves left a round ago
+        PHASE_MARK(4);
+        issue(xr[(i + 1) % U], vm[(i + 1) % U]);                     // round r + 1 + U
+        PHASE_MARK(5);
+        __syncthreads();
+        PHASE_MARK(6);
+      }
+    }
+#ifdef V3D_PHASE_TIMING
+    if (threadIdx.x == 256 && blockIdx.x < kPhaseSlots)
+      for (int i_ = 4; i_ < 8; ++i_) g_gg_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_];
+#endif
+    return;
+  }
+
+  // ---- matrix waves ---------------------------------------------------------------------------------------------------------------
+  const int kq = lane >> 4, jn = lane & 15;
+  f32x4 acc[NB][MBW];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) acc[nb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 afr[AD][S][2 * MBW];
+  StepIter ita = {act, 0};
+  const u32x4* const wbase = reinterpret_cast<const u32x4*>(p.wp) + wave * MBW * 64 + lane;
+  auto issue_a = [&](u32x4 (&a)[S][2 * MBW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      int sg, kc;
+      ita.next(nkc, sg, kc);
+      const u32x4* w = wbase + (size_t)(sg * nkc + kc) * (kWslab / 4);
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) {
+#if V3D_PIPE_ABLATE == 2
+        a[j][m] = (u32x4){(unsigned)(size_t)w, 1u, 2u, 3u};
+        a[j][MBW + m] = (u32x4){(unsigned)(size_t)w, 1u, 2u, 3u};
+#else
+        a[j][m] = w[m * 64];
+        a[j][MBW + m] = w[(MB + m) * 64];
+#endif
+      }
+    }
+  };
+  PHASE_DECL;
+#pragma unroll
+  for (int u = 0; u < AD - 1; ++u) issue_a(afr[u]);
+  const int bslot = kq ^ (((jn >> 3) & 1) * 3);
+  __syncthreads();
+  PHASE_MARK(0);
+#pragma unroll 1
+  for (int r0 = 0; r0 < n_iter; r0 += U) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int r = r0 + i;
+      issue_a(afr[(i + AD - 1) % AD]);                               // round r + AD - 1
+      PHASE_MARK(1);
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        if (r * S + j < n_steps) {
+          const u32x4* xs = xq + ((i & 1) * S + j) * kTile;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8 b_hi = __builtin_bit_cast(bf16x8, xs[(nb * 16 + jn) * 4 + bslot]);
+            const bf16x8 b_lo = __builtin_bit_cast(bf16x8, xs[(kTM + nb * 16 + jn) * 4 + bslot]);
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+              const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[i % AD][j][m]), a_lo = __builtin_bit_cast(bf16x8, afr[i % AD][j][MBW + m]);
+#if V3D_PIPE_ABLATE == 1
+              asm volatile("" ::"v"(a_hi), "v"(a_lo), "v"(b_hi), "v"(b_lo));
+#else
+              acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[nb][m], 0, 0, 0);
+              acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[nb][m], 0, 0, 0);
+              acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[nb][m], 0, 0, 0);
+#endif
+            }
+          }
+        }
+      }
+      PHASE_MARK(2);
+      __syncthreads();
+      PHASE_MARK(3);
+    }
+  }
+  gemm_epilogue<MBW, NB>(p, acc, m0, wave, kq, jn);
+#ifdef V3D_PHASE_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < kPhaseSlots)
+    for (int i_ = 0; i_ < 4; ++i_) g_gg_phase[blockIdx.x * 8 + i_] = (unsigned long long)ph_acc[i_];
+#endif
 }
 
 // ---- Conv1d(k = 3, pad 1) over groups of `group_len` consecutive rows (the hypothesis decoder, refinement.py:29-30) ----
@@ -586,12 +817,10 @@ __global__ __launch_bounds__(256) void conv1d_gemm_kernel(GemmParams p) {
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const int kg = sc4 >> 3, half = (sc4 >> 2) & 1;
         const int slot = kg ^ (((row >> 3) & 1) * 3);
-        const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
-        const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
-        const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+        const u32x2 hp = split_hi(v), lp = split_lo(v, hp);
         u32x2* xh2 = reinterpret_cast<u32x2*>(xq);
-        xh2[(row * 4 + slot) * 2 + half] = (u32x2){h0 | (h1 << 16), h2 | (h3 << 16)};
-        xh2[((kRT + row) * 4 + slot) * 2 + half] = (u32x2){l0 | (l1 << 16), l2 | (l3 << 16)};
+        xh2[(row * 4 + slot) * 2 + half] = hp;
+        xh2[((kRT + row) * 4 + slot) * 2 + half] = lp;
       }
     }
   };
@@ -822,7 +1051,40 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
     bool rounds = small && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && v3d::option(v3d::kOptGemmRounds) != 0;
     for (int t = 0; rounds && t < h->n_seg; ++t)
       rounds = p.seg[t].ld % 4 == 0 && (reinterpret_cast<size_t>(p.seg[t].src) & 15) == 0;
-    if (rounds) {
+    // a sparse convolution (one source, a row map per offset): the loader / matrix pipeline
+    bool pipe = rounds && group_len == 0 && h->n_seg * (h->KP / kKC) >= 8 && (size_t)M * (size_t)p.seg[0].ld < ((size_t)1 << 31) &&
+                v3d::option(v3d::kOptGemmPipe) != 0;
+    for (int t = 0; pipe && t < h->n_seg; ++t)
+      pipe = p.seg[t].idx != nullptr && p.seg[t].src == p.seg[0].src && p.seg[t].ld == p.seg[0].ld;
+    if (pipe) {
+      // rows per tile: a tile streams the whole weight image through its CU's vector-memory path (27 x K x N x 4 bytes), so
+      // the tile is as tall as the number of workgroups allows -- about one per CU on the 128-channel levels, two on the wide
+      // 64-channel level
+      const int rows_opt = v3d::option(v3d::kOptGemmRoundRows);
+      V3D_REQUIRE(rows_opt == 0 || rows_opt == 32 || rows_opt == 64 || rows_opt == 128, V3D_ERR_BAD_ARG,
+                  "option gemm_round_rows must be 0, 32, 64 or 128 (got %d)", rows_opt);
+      const int rows = rows_opt ? rows_opt : (h->MBW == 2 ? (M >= 8192 ? 64 : 32) : (M >= 8192 ? 64 : 32));
+      const unsigned rb = (unsigned)((M + rows - 1) / rows);
+      // measured on the cfg3 scene's levels (scripts/micro/sparse_ab.sh; rounds kernel -> here): 13 434 rows x 128 channels 84 -> 60 us
+      // with 64-row tiles and 8 loader waves, 2 719 x 128: 58 -> 40 us with 32-row tiles and 4 loader waves, 59 975 x 64: 90 -> 84 us;
+      // option gemm_pipe = 2 is the first version of the kernel (4 loader waves, fragments of 3 rounds in flight) for A/B runs
+      const bool v2 = v3d::option(v3d::kOptGemmPipe) == 2;
+#define V3D_PIPE(MBW_, NB_, NL_, MINB_)                                                                          \
+  do {                                                                                                           \
+    if (v2) gemm_gather_pipe_kernel<MBW_, NB_, 4, 4, 1><<<rb, 512, 0, s>>>(p);                                   \
+    else gemm_gather_pipe_kernel<MBW_, NB_, NL_, 2, MINB_><<<rb, 256 + 64 * NL_, 0, s>>>(p);                     \
+  } while (0)
+      if (h->MBW == 2) {
+        if (rows == 128) V3D_PIPE(2, 8, 8, 1);
+        else if (rows == 64) V3D_PIPE(2, 4, 8, 1);
+        else V3D_PIPE(2, 2, 4, 2);
+      } else {
+        if (rows == 128) V3D_PIPE(1, 8, 8, 1);
+        else if (rows == 64) V3D_PIPE(1, 4, 8, 1);
+        else V3D_PIPE(1, 2, 4, 2);
+      }
+#undef V3D_PIPE
+    } else if (rounds) {
       // developer A/B: rows per tile (32 / 64 / 128) -- a tile re-reads the whole weight image, so L2 -> CU weight traffic is
       // M / rows x 27 x K x N x 4 bytes (0.8 GB per 64-channel conv on 60 k voxels with 32-row tiles, twice the gathers)
       const int rows_env = v3d::option(v3d::kOptGemmRoundRows);
@@ -845,6 +1107,23 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
   }
   V3D_CHECK_LAUNCH("gemm_gather_kernel");
   return V3D_OK;
+}
+
+extern "C" int v3d_sparse_conv_f32(const v3d_gemm_weights* h, int M, const float* src, int ld_src, const int32_t* nbr,
+                                   long long nbr_stride, int use_gn, float gn_eps, const float* residual, int ld_res,
+                                   int relu_out, float* out, int ld_out, int precision, void* stream) {
+  V3D_REQUIRE(h && src && nbr, V3D_ERR_BAD_ARG, "v3d_sparse_conv_f32: null argument");
+  V3D_REQUIRE(nbr_stride >= M, V3D_ERR_BAD_SHAPE, "v3d_sparse_conv_f32: nbr_stride %lld < M %d", nbr_stride, M);
+  const float* srcs[kMaxSeg];
+  const int32_t* idxs[kMaxSeg];
+  int lds[kMaxSeg];
+  for (int s = 0; s < h->n_seg; ++s) {
+    srcs[s] = src;
+    idxs[s] = nbr + (size_t)s * (size_t)nbr_stride;
+    lds[s] = ld_src;
+  }
+  return v3d_gemm_gather_f32(h, M, srcs, idxs, lds, 0, 0, use_gn, gn_eps, residual, ld_res, relu_out, nullptr, nullptr, 0, out,
+                             ld_out, precision, stream);
 }
 
 extern "C" int v3d_fill_f32(float* ptr, size_t n, float value, void* stream) {

@@ -58,6 +58,8 @@ extern "C" {
  *   "stop_after"      layer after which v3d_costreg_depth_* returns (-DV3D_PHASE_TIMING builds)
  *   "gemm_rounds"     1 | 0      gather-GEMM in rounds for small M (bit-identical to the one-step kernel)
  *   "gemm_round_rows" 0 auto | 32 | 64 | 128
+ *   "gemm_pipe"       1 | 2 | 0  sparse convolutions on the loader / matrix pipeline kernel (2: its first version) | the rounds kernel;
+ *                                bit-identical to each other and to the one-step kernel
  * Unknown names -> V3D_ERR_BAD_ARG; an option this build cannot honour -> V3D_ERR_UNSUPPORTED. */
 int v3d_set_option(const char* name, int value);
 int v3d_get_option(const char* name, int* value);
@@ -255,6 +257,13 @@ int v3d_gemm_gather_f32(const v3d_gemm_weights* handle, int M, const float* cons
                         int relu_in, int use_gn, float gn_eps, const float* residual, int ld_res,
                         int relu_out, float* pool, const int32_t* pool_idx, int ld_pool, float* out,
                         int ld_out, int precision, void* stream);
+/* A sparse convolution as one call (MinkowskiConvolution / ConvolutionTranspose + MinkowskiGroupNorm + residual + ReLU,
+ * scenemodeling.py:16-44,160,181): v3d_gemm_gather_f32 with every segment reading `src` [*, ld_src] through column k of the
+ * neighbour table `nbr` ([n_seg, nbr_stride] int32 from v3d_sparse_neighbors, -1 = absent voxel).  Same kernels, same bits;
+ * the caller passes 4 pointers instead of three host arrays of n_seg entries. */
+int v3d_sparse_conv_f32(const v3d_gemm_weights* handle, int M, const float* src, int ld_src, const int32_t* nbr,
+                        long long nbr_stride, int use_gn, float gn_eps, const float* residual, int ld_res, int relu_out,
+                        float* out, int ld_out, int precision, void* stream);
 int v3d_fill_f32(float* ptr, size_t n, float value, void* stream);
 /* PointNet input of PL3DVNet.model_scene (mv3d/lightningmodel.py:180-183): out[i] = [pts[edge_pt[i]] - anchor_pts[edge_anchor[i]]
  * | pts_feat[edge_pt[i]]], out [n_edges, 3 + C]; pts [*, 3], anchor_pts [*, 3], pts_feat [*, C], edges int64. */

@@ -380,6 +380,36 @@ def test_bench_rank_plumbing_dry_run():
     assert len(lines) == 1 and json.loads(lines[0])['config']['ranks_seen'] == 2
 
 
+def test_bench_checker_processes_return_the_in_process_oracle(monkeypatch):
+    """bench._oracle_views: the oracle of the parity legs computed by spawned worker processes (inputs rebuilt from the seed)
+    returns the bits of the in-process loop at the same team size -- the checker's numbers must not depend on how the bench
+    schedules it."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from oracle import costvolume as ocv
+    syn = v3d('synthetic')
+    inp = syn.make_costvolume_inputs('cfg1', n_ref=4, seed=3)
+    sd = syn.costregnet_weights(seed=0, sharpen=200.0)
+    d0, dd, D = inp['depth']
+    per = inp['edges'].shape[1] // 4
+
+    def run(v0, v1, pinned):
+        with torch.no_grad():
+            return ocv.mvsnet_depth(inp['feat'], inp['rotmats'], inp['tvecs'], inp['K'], inp['edges'][:, v0 * per:v1 * per],
+                                    sd, d0, dd, D, inp['img_size'], inp['plane_size'], pinned=pinned)[0]
+    nt0 = torch.get_num_threads()
+    monkeypatch.setattr(os, 'cpu_count', lambda: 8)         # 8 // (2 * 2) = 2 worker processes of 2 threads each
+    try:
+        pinned, plain = bench._oracle_views('cfg1', 4, 3, [(4, True), (3, False)], 1, 2)
+        torch.set_num_threads(2)                            # (MKL-DNN's blocking follows the team size: 8e-7 between 2 and 8)
+        assert torch.equal(pinned, torch.cat([run(v, v + 1, True) for v in range(4)]))
+        assert torch.equal(plain, torch.cat([run(v, v + 1, False) for v in range(3)]))
+    finally:
+        torch.set_num_threads(nt0)
+
+
 def test_bench_cfg4_dry_run_shards_a_scene_through_the_real_driver():
     """`bench.py --config cfg4 --gpus 2 --dry-run`: the communicating mode's host path on CPU -- the real process_scene
     (ref-view sharding 3 + 2, chunking, one-sided halos, gather_pointcloud with uneven shards, the final all-gather of the

@@ -596,9 +596,11 @@ def test_segment_csr_and_max_equal_scatter_amax(n, n_seg, N, cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M,C,N', [(2816, 128, 128), (13500, 64, 64), (777, 32, 128), (33, 64, 32)])
+@pytest.mark.parametrize('M,C,N', [(2816, 128, 128), (13500, 64, 64), (777, 32, 128), (33, 64, 32), (9001, 128, 128),
+                                   (40000, 64, 64), (8200, 96, 64)])
 def test_gather_gemm_rounds_kernel_bit_identical_to_one_step_kernel(M, C, N, cuda):
-    """The small-M gather-GEMM in rounds of four (offset, K chunk) steps (gemm_gather_rounds_kernel: sparse convolutions) keeps the
+    """The sparse convolution's two small-M kernels -- the loader / matrix pipeline (gemm_gather_pipe_kernel, the default; 32-,
+    64- and 128-row tiles by M and N) and the rounds of four (offset, K chunk) steps (gemm_gather_rounds_kernel) -- keep the
     step order and the MFMA order per accumulator of gemm_gather_kernel: same bits, with absent neighbours, whole absent
     offsets (skipped segments), a ragged last tile, GroupNorm + residual + ReLU in the epilogue."""
     sm = v3d('scenemodeling')
@@ -614,12 +616,15 @@ def test_gather_gemm_rounds_kernel_bit_identical_to_one_step_kernel(M, C, N, cud
     nbr = nbr.to(torch.int32).to(cuda).contiguous()
     res = torch.randn(M, N, generator=g).to(cuda)
     outs = {}
-    for tag, rounds in (('rounds', 1), ('one_step', 0)):
-        old = v3d('_lib').set_option('gemm_rounds', rounds)          # developer option (include/v3d.h: v3d_set_option)
+    for tag, rounds, pipe in (('pipe', 1, 1), ('rounds', 1, 0), ('one_step', 0, 0)):
+        old = v3d('_lib').set_option('gemm_rounds', rounds)          # developer options (include/v3d.h: v3d_set_option)
+        old_p = v3d('_lib').set_option('gemm_pipe', pipe)
         try:
             outs[tag] = pk(M, [x] * 27, idxs=[nbr[k] for k in range(27)], use_gn=True, residual=res, relu_out=True)
         finally:
             v3d('_lib').set_option('gemm_rounds', old)
+            v3d('_lib').set_option('gemm_pipe', old_p)
     torch.cuda.synchronize()
     assert torch.isfinite(outs['rounds']).all()
     assert torch.equal(outs['rounds'], outs['one_step'])
+    assert torch.equal(outs['pipe'], outs['one_step'])
