@@ -119,40 +119,74 @@ struct CornerParams {
   v3dhash::HashTable table[3];
   const float* min_pts[3];     // [n_batch, 3]
   float res[3];                // x.res of the level (= tensor_stride * voxel size)
-  int ts[3];
+  float tsf[3], inv_ts[3];     // tensor stride and its reciprocal (exact when the stride is a power of two)
   const float* pts;            // [n_q, 3]
   const long long* pts_batch;  // [n_pts]
   int n_hyp;
+  unsigned m_hyp;              // v3d::magic_u32 of n_hyp
   int n_q;
   u32x2* out;                  // [n_q][3 levels][8 corners] (feature row, weight bits); absent corner = (0, 0.f)
 };
 
+#ifdef V3D_CORNER_STATS
+// developer build only (scripts/micro/corner_stats.py): [level][0 lookups, 1 probes, 2 longest chain, 3 present]
+__device__ unsigned long long g_corner_stats[12];
+__device__ __forceinline__ int corner_find_counted(const v3dhash::HashTable& t, unsigned long long key, int l) {
+  unsigned slot = v3dhash::hash_u64(key) & t.mask;
+  int row = -1;
+  unsigned probe = 0;
+  for (; probe <= t.mask; ++probe) {
+    const unsigned long long k = t.keys[slot];
+    if (k == key) { row = t.vals[slot]; break; }
+    if (k == v3dhash::kEmpty) break;
+    slot = (slot + 1) & t.mask;
+  }
+  atomicAdd(&g_corner_stats[l * 4 + 0], 1ull);
+  atomicAdd(&g_corner_stats[l * 4 + 1], (unsigned long long)(probe + 1));
+  atomicMax(&g_corner_stats[l * 4 + 2], (unsigned long long)(probe + 1));
+  if (row >= 0) atomicAdd(&g_corner_stats[l * 4 + 3], 1ull);
+  return row;
+}
+#endif
+
 // Rows C2a's index half: the 8 lattice corners of every hypothesis point on the three levels (refinement.py:33-39 feeding
 // MinkowskiInterpolation): query coordinate ((p - min) / x.res) * x.stride in base-voxel units, corner floor(q / ts) ts + {0, ts}^3,
-// weight prod (1 - |q - c| / ts), absent corners contribute nothing (no renormalisation).  One thread per (row, corner).
+// weight prod (1 - |q - c| / ts), absent corners contribute nothing (no renormalisation).  One thread per (row, corner), the three
+// levels in turn.  POW2: the tensor strides are powers of two (the U-Net's 1, 2, 4): x / ts == x * (1 / ts) bit for bit, six of the
+// nine IEEE divisions per level become multiplications.  What bounds the kernel is the number of L2 requests, not the instructions:
+// 34 M random 8-byte key reads + 16 M value reads per 64-view sweep in 0.23 ms are ~0.2 T requests/s, the rate of the L2 channels
+// (one thread per (row, level, corner) -- a third of the instructions per thread, three times the threads re-reading the point --
+// measured 0.28 ms against 0.23).
+template <bool POW2>
 __global__ __launch_bounds__(256) void decoder_corner_kernel(CornerParams cp) {
   const unsigned gid = blockIdx.x * 256u + threadIdx.x;      // (host: 8 n_q < 2^31)
   const unsigned q = gid >> 3;
   const int corner = (int)(gid & 7u);
   if (q >= (unsigned)cp.n_q) return;
-  const int b = (int)cp.pts_batch[q / (unsigned)cp.n_hyp];
+  const int b = (int)cp.pts_batch[v3d::udiv_magic(q, (unsigned)cp.n_hyp, cp.m_hyp)];
   const float px = cp.pts[(size_t)q * 3 + 0], py = cp.pts[(size_t)q * 3 + 1], pz = cp.pts[(size_t)q * 3 + 2];
 #pragma unroll
   for (int l = 0; l < 3; ++l) {
-    const float ts = (float)cp.ts[l], res = cp.res[l];
+    const float ts = cp.tsf[l], res = cp.res[l], its = cp.inv_ts[l];
     const float* mn = cp.min_pts[l] + b * 3;
     const float qx = ((px - mn[0]) / res) * ts, qy = ((py - mn[1]) / res) * ts, qz = ((pz - mn[2]) / res) * ts;
-    const float c0 = floorf(qx / ts) * ts + ((corner & 1) ? ts : 0.f);
-    const float c1 = floorf(qy / ts) * ts + ((corner & 2) ? ts : 0.f);
-    const float c2 = floorf(qz / ts) * ts + ((corner & 4) ? ts : 0.f);
+    auto over_ts = [&](float x) __attribute__((always_inline)) { return POW2 ? x * its : x / ts; };
+    const float c0 = floorf(over_ts(qx)) * ts + ((corner & 1) ? ts : 0.f);
+    const float c1 = floorf(over_ts(qy)) * ts + ((corner & 2) ? ts : 0.f);
+    const float c2 = floorf(over_ts(qz)) * ts + ((corner & 4) ? ts : 0.f);
     float w = 1.f;
-    w *= 1.f - fabsf(qx - c0) / ts;
-    w *= 1.f - fabsf(qy - c1) / ts;
-    w *= 1.f - fabsf(qz - c2) / ts;
+    w *= 1.f - over_ts(fabsf(qx - c0));
+    w *= 1.f - over_ts(fabsf(qy - c1));
+    w *= 1.f - over_ts(fabsf(qz - c2));
     int row = -1;
     // (a coordinate outside the key range cannot be present and is never looked up)
-    if (c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard && c0 <= 60000.f && c1 <= 60000.f && c2 <= 60000.f)
+    if (c0 >= -v3dhash::kGuard && c1 >= -v3dhash::kGuard && c2 >= -v3dhash::kGuard && c0 <= 60000.f && c1 <= 60000.f && c2 <= 60000.f) {
+#ifdef V3D_CORNER_STATS
+      row = corner_find_counted(cp.table[l], v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2), l);
+#else
       row = v3dhash::hash_find(cp.table[l], v3dhash::pack_key(b, (int)c0, (int)c1, (int)c2));
+#endif
+    }
     // an absent corner reads feature row 0 with weight 0: the gathers of the fused kernel are unconditional
     cp.out[((size_t)q * 3 + l) * 8 + corner] = (u32x2){row < 0 ? 0u : (unsigned)row, row < 0 ? 0u : __float_as_uint(w)};
   }
@@ -713,6 +747,14 @@ extern "C" int v3d_debug_fused_phase_read(unsigned long long* out8_host, int n_b
 }
 #endif
 
+#ifdef V3D_CORNER_STATS
+extern "C" int v3d_debug_corner_stats(unsigned long long* out12, int reset) {
+  if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_corner_stats), sizeof(unsigned long long) * 12) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_corner_stats), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 extern "C" size_t v3d_decoder_fused_workspace_bytes(int n_pts, int n_hyp) {
   if (n_pts <= 0 || n_hyp <= 0) return 256;
   return (size_t)n_pts * (size_t)n_hyp * 24 * sizeof(u32x2) + 256;
@@ -745,6 +787,7 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   memset(&p, 0, sizeof(p));
   memset(&cp, 0, sizeof(cp));
   int k1 = c_feat;
+  bool pow2 = true;
   for (int l = 0; l < 3; ++l) {
     V3D_REQUIRE(level_table_host[l] && level_feats_host[l] && level_min_pts_host[l] && level_n_host[l] > 0 &&
                     level_C_host[l] > 0 && level_C_host[l] % 16 == 0 && level_stride_host[l] > 0 && level_res_host[l] > 0.f,
@@ -755,7 +798,9 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
     V3D_REQUIRE((long long)level_n_host[l] * level_C_host[l] * 4 < (1ll << 31) && level_n_host[l] < (1 << 24), V3D_ERR_UNSUPPORTED,
                 "v3d_decoder_fused_f32: level %d holds %d x %d floats (2 GB limit)", l, level_n_host[l], level_C_host[l]);
     cp.table[l] = v3dhash::table_view(const_cast<void*>(level_table_host[l]), level_n_host[l]);
-    cp.min_pts[l] = level_min_pts_host[l]; cp.res[l] = level_res_host[l]; cp.ts[l] = level_stride_host[l];
+    cp.min_pts[l] = level_min_pts_host[l]; cp.res[l] = level_res_host[l];
+    cp.tsf[l] = (float)level_stride_host[l]; cp.inv_ts[l] = 1.f / (float)level_stride_host[l];
+    pow2 = pow2 && (level_stride_host[l] & (level_stride_host[l] - 1)) == 0;
     p.feats[l] = level_feats_host[l]; p.C[l] = level_C_host[l];
     k1 += level_C_host[l];
   }
@@ -790,7 +835,9 @@ extern "C" int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host,
   {
     v3d::TimedScope ts("decoder_corners", s);
     const long long n_thr = (long long)cp.n_q * 8;
-    decoder_corner_kernel<<<(unsigned)((n_thr + 255) / 256), 256, 0, s>>>(cp);
+    cp.m_hyp = v3d::magic_u32((unsigned long long)cp.n_q, (unsigned)n_hyp);
+    if (pow2) decoder_corner_kernel<true><<<(unsigned)((n_thr + 255) / 256), 256, 0, s>>>(cp);
+    else decoder_corner_kernel<false><<<(unsigned)((n_thr + 255) / 256), 256, 0, s>>>(cp);
   }
   V3D_CHECK_LAUNCH("decoder_corner_kernel");
   {
