@@ -516,7 +516,8 @@ def bench_scene(args, rank, world, dev, dist):
             stage3_info = dict(stage3_kernel_ms_per_scene=round(all_ms, 3), conv_kernel_ms_per_scene=round(conv_ms, 3),
                                roofline=dict(bound='mfma', achieved=a3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0, unit='TFLOP/s',
                                              frac=a3 / (PEAK_BF16_MFMA_TFLOPS / 3.0), kernel='propagation_conv1..4 (all three '
-                                             'resolutions)', avg_ms=conv_ms / 12.0, traffic=None))
+                                             'resolutions)', avg_ms=conv_ms / 12.0,
+                                             traffic=traffic_for('propagation_conv', refs, 'cfg3')))
         if dom in ('conv1d_gemm', 'decoder_fused'):
             # decoder conv1d stack: 2*7*P*(3*352*128 + 2*3*128*128 + 3*128) FLOP per view per sweep, 6 sweeps
             P = drv.DEPTH_CONFIG['size'][0] * drv.DEPTH_CONFIG['size'][1]

@@ -24,7 +24,8 @@ NAMES = [('psv_variance_window_kernel<true, false>', 'psv_variance'), ('psv_vari
          ('convg_bf16x2_kernel<CG<8, 16', 'costreg_conv1'), ('convg_bf16x2_kernel<CG<16, 16', 'costreg_conv2'),
          ('convg_bf16x2_kernel<CG<16, 32', 'costreg_conv3'), ('convg_bf16x2_kernel<CG<32, 32', 'costreg_conv4'),
          ('deconvg_bf16x2_kernel<DG<32, 16', 'costreg_conv8'), ('soft_argmin_kernel', 'soft_argmin'),
-         ('decoder_fused_kernel', 'decoder_fused'), ('gemm_gather_rounds_kernel<2, 2, 4>', 'sparse_conv_gemm'),
+         ('decoder_fused_kernel', 'decoder_fused'), ('decoder_corner_kernel', 'decoder_corners'),
+         ('gemm_gather_rounds_kernel<2, 2, 4>', 'sparse_conv_gemm'),
          ('backproject_variance_kernel', 'backproject_variance')]
 FETCH_CORRECTION = 2.0
 
@@ -39,8 +40,28 @@ def read(path):
     return out
 
 
+def weighted(path, match):
+    """dispatch-weighted mean of the counter over the kernels whose symbol satisfies `match`, and their dispatch count"""
+    tot, n = 0.0, 0
+    for row in csv.DictReader(open(path)):
+        if match(row['kernel']):
+            tot += float(row['avg_value_per_dispatch']) * int(row['dispatches'])
+            n += int(row['dispatches'])
+    return (tot / n if n else 0.0), n
+
+
+# kernel families with several template instances per scene: the sparse convolutions of the U-Net (pipeline kernel, 32- / 64-row
+# tiles, 64 / 128 channels) and the twelve conv launches of stage 3 (FLAT instances of convg_bf16x2_kernel: "..., true> >")
+FAMILIES = [('sparse_conv_gemm', lambda k: 'gemm_gather_pipe_kernel' in k),
+            ('propagation_conv', lambda k: 'convg_bf16x2_kernel' in k and k.rstrip().endswith('true> >'))]
+
+
 def main():
     fetch, write = read(sys.argv[1]), read(sys.argv[2])
+    for name, match in FAMILIES:
+        (f, nf), (w, nw) = weighted(sys.argv[1], match), weighted(sys.argv[2], match)
+        if nf and nw:
+            fetch[name], write[name] = f, w
     kernels = {}
     for k in sorted(fetch.keys() | write.keys()):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
