@@ -136,8 +136,8 @@ __device__ __forceinline__ int corner_find_counted(const v3dhash::HashTable& t, 
   int row = -1;
   unsigned probe = 0;
   for (; probe <= t.mask; ++probe) {
-    const unsigned long long k = t.keys[slot];
-    if (k == key) { row = t.vals[slot]; break; }
+    const unsigned long long k = t.entries[slot].key;
+    if (k == key) { row = t.entries[slot].val; break; }
     if (k == v3dhash::kEmpty) break;
     slot = (slot + 1) & t.mask;
   }

@@ -11,9 +11,9 @@ namespace {
 
 using namespace v3dhash;
 
-__global__ void hash_clear_kernel(unsigned long long* keys, unsigned cap, int* status) {
+__global__ void hash_clear_kernel(HashEntry* entries, unsigned cap, int* status) {
   unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i < cap) keys[i] = kEmpty;
+  if (i < cap) entries[i] = HashEntry{kEmpty, -1, 0};
   if (i == 0) *status = 0;
 }
 
@@ -28,8 +28,8 @@ __global__ void hash_insert_kernel(HashTable t, const int* __restrict__ coords, 
   const unsigned long long key = pack_key(cb, cx, cy, cz);
   unsigned slot = hash_u64(key) & t.mask;
   for (unsigned probe = 0; probe <= t.mask; ++probe) {
-    const unsigned long long prev = atomicCAS(&t.keys[slot], kEmpty, key);
-    if (prev == kEmpty || prev == key) { t.vals[slot] = i; return; }   // coordinates are unique rows
+    const unsigned long long prev = atomicCAS(&t.entries[slot].key, kEmpty, key);
+    if (prev == kEmpty || prev == key) { t.entries[slot].val = i; return; }   // coordinates are unique rows
     slot = (slot + 1) & t.mask;
   }
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" size_t v3d_hash_bytes(int n) { return (size_t)table_capacity(n) * 12 + 16; }
+extern "C" size_t v3d_hash_bytes(int n) { return (size_t)table_capacity(n) * sizeof(HashEntry) + 16; }
 
 extern "C" int v3d_hash_status(const void* table, int n, void* stream) {
   V3D_REQUIRE(table && n > 0, V3D_ERR_BAD_ARG, "v3d_hash_status: bad argument");
@@ -129,7 +129,7 @@ extern "C" int v3d_hash_build(const int32_t* coords, int n, void* table, size_t 
   hipStream_t s = (hipStream_t)stream;
   HashTable t = table_view(table, n);
   v3d::TimedScope ts("hash_build", s);
-  hash_clear_kernel<<<(t.mask + 256) / 256, 256, 0, s>>>(t.keys, t.mask + 1, t.status);
+  hash_clear_kernel<<<(t.mask + 256) / 256, 256, 0, s>>>(t.entries, t.mask + 1, t.status);
   hash_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(t, coords, n);
   V3D_CHECK_LAUNCH("hash_insert_kernel");
   return V3D_OK;

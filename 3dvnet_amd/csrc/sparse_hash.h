@@ -18,9 +18,16 @@ __device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
   return (unsigned)k;
 }
 
+// One 16-byte entry per slot: a lookup is ONE memory request whether the key is present or not.  (Keys and values in two arrays --
+// rounds 1-4 -- cost a second, dependent request per hit; the lookup kernels are bound by the number of L2 requests)
+struct __attribute__((aligned(16))) HashEntry {
+  unsigned long long key;
+  int val;
+  int pad;
+};
+
 struct HashTable {          // device layout inside the caller-provided buffer
-  unsigned long long* keys; // [cap]
-  int* vals;                // [cap]
+  HashEntry* entries;       // [cap]
   int* status;              // [1] != 0: a coordinate did not fit the packed key (v3d_hash_status)
   unsigned mask;            // cap - 1 (cap = power of two)
 };
@@ -31,9 +38,11 @@ constexpr int kCoordMax = 65535 - 2 * kGuard;
 
 __device__ __forceinline__ int hash_find(const HashTable& t, unsigned long long key) {
   unsigned slot = hash_u64(key) & t.mask;
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   for (unsigned probe = 0; probe <= t.mask; ++probe) {
-    const unsigned long long k = t.keys[slot];
-    if (k == key) return t.vals[slot];
+    const u32x4_ e = *reinterpret_cast<const u32x4_*>(t.entries + slot);
+    const unsigned long long k = ((unsigned long long)e.y << 32) | e.x;
+    if (k == key) return (int)e.z;
     if (k == kEmpty) return -1;
     slot = (slot + 1) & t.mask;
   }
@@ -53,9 +62,8 @@ inline unsigned table_capacity(int n) {
 inline HashTable table_view(void* buf, int n) {
   HashTable t;
   const unsigned cap = table_capacity(n);
-  t.keys = (unsigned long long*)buf;
-  t.vals = (int*)((char*)buf + (size_t)cap * 8);
-  t.status = (int*)((char*)buf + (size_t)cap * 12);
+  t.entries = (HashEntry*)buf;
+  t.status = (int*)((char*)buf + (size_t)cap * sizeof(HashEntry));
   t.mask = cap - 1;
   return t;
 }
