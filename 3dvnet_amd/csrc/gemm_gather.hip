@@ -1048,7 +1048,8 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
     else gemm_gather_kernel<MBW_, NB_, true><<<blocks, 256, 0, s>>>(p);                    \
   } while (0)
     // small M, split-bf16, every segment 16-byte loadable: the rounds kernel (four steps per pair of barriers)
-    bool rounds = small && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && v3d::option(v3d::kOptGemmRounds) != 0;
+    const int rounds_opt = v3d::option(v3d::kOptGemmRounds);
+    bool rounds = (small || rounds_opt == 2) && !fp32_path && h->K % 4 == 0 && h->n_seg * (h->KP / kKC) >= 2 && h->KP / kKC <= 8 && rounds_opt != 0;
     for (int t = 0; rounds && t < h->n_seg; ++t)
       rounds = p.seg[t].ld % 4 == 0 && (reinterpret_cast<size_t>(p.seg[t].src) & 15) == 0;
     // a sparse convolution (one source, a row map per offset): the loader / matrix pipeline
@@ -1090,7 +1091,7 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
       const int rows_env = v3d::option(v3d::kOptGemmRoundRows);
       V3D_REQUIRE(rows_env == 0 || rows_env == 32 || rows_env == 64 || rows_env == 128, V3D_ERR_BAD_ARG,
                   "option gemm_round_rows must be 0, 32, 64 or 128 (got %d)", rows_env);
-      const int rows = rows_env ? rows_env : 32;
+      const int rows = rows_env ? rows_env : small ? 32 : 128;
       const unsigned rb = (unsigned)((M + rows - 1) / rows);
       if (h->MBW == 2) {
         if (rows == 128) gemm_gather_rounds_kernel<2, 8, 2><<<rb, 256, 0, s>>>(p);

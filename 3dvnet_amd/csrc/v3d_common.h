@@ -55,7 +55,7 @@ enum Option {
   kOptC9Kernel,        // "c9_kernel": 0 tile kernel, 1 depth-march experiment (builds with -DV3D_EXPERIMENTS only), 2 exact-fp32 unfused
   kOptConvVec,         // "conv_vec": 1 float4 staging of halo rows in the exact-fp32 layer kernel, 0 scalar
   kOptStopAfter,       // "stop_after": regulariser returns after this layer (-DV3D_PHASE_TIMING builds: isolates a kernel's counters)
-  kOptGemmRounds,      // "gemm_rounds": 1 gather-GEMM in rounds for small M, 0 the one-step kernel
+  kOptGemmRounds,      // "gemm_rounds": 1 gather-GEMM in rounds for small M, 0 the one-step kernel, 2 rounds for every M (measured: PointNet's 200 k-row layers 1.25 -> 1.21 ms per scene, not the default)
   kOptGemmRoundRows,   // "gemm_round_rows": 0 auto, 32 | 64 | 128 rows per tile of the rounds / pipeline kernel
   kOptGemmPipe,        // "gemm_pipe": 1 sparse convolutions on the loader / matrix pipeline kernel (2: its first version), 0 the rounds kernel
   kOptCount

@@ -56,7 +56,7 @@ extern "C" {
  *   "c9_kernel"       0 tile kernel | 1 depth-march experiment (libraries built with -DV3D_EXPERIMENTS only) | 2 exact-fp32 unfused
  *   "conv_vec"        1 | 0      float4 staging in the exact-fp32 per-layer kernel
  *   "stop_after"      layer after which v3d_costreg_depth_* returns (-DV3D_PHASE_TIMING builds)
- *   "gemm_rounds"     1 | 0      gather-GEMM in rounds for small M (bit-identical to the one-step kernel)
+ *   "gemm_rounds"     1 | 0 | 2  gather-GEMM in rounds for small M | the one-step kernel | rounds for every M (bit-identical)
  *   "gemm_round_rows" 0 auto | 32 | 64 | 128
  *   "gemm_pipe"       1 | 2 | 0  sparse convolutions on the loader / matrix pipeline kernel (2: its first version) | the rounds kernel;
  *                                bit-identical to each other and to the one-step kernel

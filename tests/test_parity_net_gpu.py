@@ -596,6 +596,33 @@ def test_segment_csr_and_max_equal_scatter_amax(n, n_seg, N, cuda):
 
 
 @pytest.mark.gpu
+def test_sparse_conv_entry_point_equals_the_gather_gemm_call(cuda):
+    """v3d_sparse_conv_f32 (the U-Net's one-call convolution: source, neighbour table, stride) is v3d_gemm_gather_f32 with the 27
+    segment arrays built in C: same bits, with GroupNorm, residual and ReLU; a short neighbour stride is refused."""
+    sm, libm = v3d('scenemodeling'), v3d('_lib')
+    lib = libm.load()
+    M, C, N = 5000, 64, 128
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(27, C, N, generator=g) * 0.05
+    pk = sm.PackedGemm(w, C * N, 1, N, 27, N, C, gn_w=torch.rand(N, generator=g) + 0.5, gn_b=torch.randn(N, generator=g) * 0.1)
+    x = torch.randn(M + 7, C, generator=g).to(cuda)                 # more source rows than outputs (a strided convolution)
+    nbr = torch.randint(0, M + 7, (27, M), generator=g)
+    nbr[torch.rand(27, M, generator=g) < 0.5] = -1
+    nbr = nbr.to(torch.int32).to(cuda).contiguous()
+    res = torch.randn(M, N, generator=g).to(cuda)
+    ref = pk(M, [x] * 27, idxs=[nbr[k] for k in range(27)], use_gn=True, residual=res, relu_out=True)
+    out = torch.empty_like(ref)
+    rc = lib.v3d_sparse_conv_f32(pk.handle, M, x.data_ptr(), C, nbr.data_ptr(), M, 16, 1e-5, res.data_ptr(), N, 1, out.data_ptr(), N,
+                                 libm.precision_code('split_bf16'), libm.stream_ptr(cuda))
+    libm.check(rc, 'v3d_sparse_conv_f32')
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    rc = lib.v3d_sparse_conv_f32(pk.handle, M, x.data_ptr(), C, nbr.data_ptr(), M - 1, 16, 1e-5, None, 0, 1, out.data_ptr(), N,
+                                 libm.precision_code('split_bf16'), libm.stream_ptr(cuda))
+    assert rc != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,C,N', [(2816, 128, 128), (13500, 64, 64), (777, 32, 128), (33, 64, 32), (9001, 128, 128),
                                    (40000, 64, 64), (8200, 96, 64)])
 def test_gather_gemm_rounds_kernel_bit_identical_to_one_step_kernel(M, C, N, cuda):
