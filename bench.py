@@ -157,11 +157,15 @@ def _oracle_views(cfg, refs, seed, legs, chunk, nt):
         for v0 in range(0, n, per_part):
             jobs.append((cfg, refs, seed, v0, min(v0 + per_part, n), chunk, pinned, nt))
             owner.append(li)
-    if workers == 1:
+    res = None
+    if workers > 1:
+        try:
+            with multiprocessing.get_context('spawn').Pool(min(workers, len(jobs))) as pool:
+                res = pool.map(_oracle_views_job, jobs, chunksize=1)
+        except Exception as e:      # a host that cannot spawn workers: the same jobs in this process (slower, same numbers)
+            sys.stderr.write('oracle worker pool failed (%s: %s): running the checker in-process\n' % (type(e).__name__, e))
+    if res is None:
         res = [_oracle_views_job(j) for j in jobs]
-    else:
-        with multiprocessing.get_context('spawn').Pool(min(workers, len(jobs))) as pool:
-            res = pool.map(_oracle_views_job, jobs, chunksize=1)
     return [torch.from_numpy(np.concatenate([r for r, o in zip(res, owner) if o == li])) for li in range(len(legs))]
 
 
