@@ -172,7 +172,9 @@ extern "C" int v3d_backproject_variance_f32(const float* depth, const float* fea
                                             int h, int w, double offset, int n_half, float* pts,
                                             float* var, void* workspace, size_t workspace_bytes,
                                             void* stream) {
-  V3D_REQUIRE(depth && feat && K && R && t && ref_img && edge_ofs && edge_src && pts && var && workspace,
+  // feat == NULL: `workspace` still holds the channel-last copy a previous call made of the same feature tensor (the scene
+  // driver back-projects against the same 46 MB of features eight times per scene: 23 us of transposition per call)
+  V3D_REQUIRE(depth && K && R && t && ref_img && edge_ofs && edge_src && pts && var && workspace,
               V3D_ERR_BAD_ARG, "v3d_backproject_variance_f32: null pointer argument");
   V3D_REQUIRE(C == 32 || C == 16, V3D_ERR_UNSUPPORTED, "v3d_backproject_variance_f32: C=%d unsupported", C);
   V3D_REQUIRE((long long)n_img * Hf * Wf * C < (1ll << 31), V3D_ERR_BAD_SHAPE,
@@ -183,8 +185,10 @@ extern "C" int v3d_backproject_variance_f32(const float* depth, const float* fea
               V3D_ERR_WORKSPACE_TOO_SMALL, "v3d_backproject_variance_f32: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* featT = (float*)workspace;
-  v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
-  V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
+  if (feat) {
+    v3d::transpose_channel_last(feat, featT, n_img, C, Hf * Wf, s);
+    V3D_CHECK_LAUNCH("transpose_channel_last_kernel");
+  }
   BpParams p;
   p.depth = depth; p.featT = featT; p.K = K; p.R = R; p.t = t;
   p.ref_img = ref_img; p.edge_ofs = edge_ofs; p.edge_src = edge_src; p.pts = pts; p.var = var;

@@ -32,15 +32,27 @@ def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges
     var = torch.empty((n_ref * h * w, n_hyp, C), dtype=torch.float32, device=dev)
     nbytes = lib.v3d_backproject_workspace_bytes(n_img, C, Hf, Wf)
     ws = (workspace or _Workspace()).get('bp', nbytes, dev)
+    # the library keeps a channel-last copy of the features in the workspace: a caller that passes its workspace and the same
+    # (unmodified) feature tensor again -- the scene driver, eight times per scene -- skips that copy.  The tag holds the
+    # previous tensor alive, so its address cannot be handed to another tensor in between.
+    tag = None
+    if workspace is not None and not feat.is_inference():
+        tag = (feat.data_ptr(), feat._version, tuple(feat.shape), tuple(feat.stride()), ws.data_ptr(), str(dev), _lib.stream_ptr(dev))
+    prev = workspace.tags.get('bp') if workspace is not None else None
+    reuse = tag is not None and prev is not None and prev[0] == tag
     Kc, Rc, tc = (x.to(dev).contiguous().float() for x in (K, rotmats, tvecs))
     d = depth_pred.contiguous().float()
-    rc = lib.v3d_backproject_variance_f32(d.data_ptr(), feat.data_ptr(), Kc.data_ptr(), Rc.data_ptr(),
+    if workspace is not None:
+        workspace.tags['bp'] = None              # (an exception below leaves no claim on the workspace's contents)
+    rc = lib.v3d_backproject_variance_f32(d.data_ptr(), None if reuse else feat.data_ptr(), Kc.data_ptr(), Rc.data_ptr(),
                                           tc.data_ptr(), ref_img.data_ptr(), edge_ofs.data_ptr(),
                                           edge_src.data_ptr(), n_img, n_ref, edge_src.shape[0], C, Hf, Wf,
                                           int(img_size[0]), int(img_size[1]), h, w, float(offset), int(n),
                                           pts.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(),
                                           _lib.stream_ptr(dev))
     _lib.check(rc, 'v3d_backproject_variance_f32')
+    if workspace is not None and tag is not None:
+        workspace.tags['bp'] = (tag, feat)
     return pts, var
 
 

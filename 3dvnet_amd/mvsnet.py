@@ -22,12 +22,14 @@ class _Workspace:
 
     def __init__(self):
         self._bufs = {}
+        self.tags = {}          # name -> what a caller left in the buffer (its own key), dropped when the buffer is replaced
 
     def get(self, name, nbytes, device):
         buf = self._bufs.get(name)
         if buf is None or buf.numel() < nbytes or buf.device != device:
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._bufs[name] = buf
+            self.tags.pop(name, None)
         return buf
 
 

@@ -221,6 +221,8 @@ int v3d_costreg_layer_split_f32(const v3d_costreg_weights* handle, int layer, co
  *   hypotheses depth + i*offset, i in [-n_half, n_half] (n_half = 0: the depth itself);
  *   pts [n_ref*h*w, 2*n_half+1, 3] out, var [n_ref*h*w, 2*n_half+1, C] out (= pts_hyp / pts_feat of
  *   lightningmodel.py:231-235; for n_half = 0: pts / pts_feat of :171-172).
+ *   The call keeps a channel-last copy of `feat` in `workspace`; feat == NULL means "the workspace still holds the copy the
+ *   previous call made of the same feature tensor" (a driver that sweeps one scene's features repeatedly skips the copy).
  * ------------------------------------------------------------------------------------------ */
 size_t v3d_backproject_workspace_bytes(int n_img, int C, int Hf, int Wf);
 int v3d_backproject_variance_f32(const float* depth, const float* feat, const float* K, const float* R,

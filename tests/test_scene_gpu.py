@@ -96,6 +96,31 @@ def test_backproject_hypotheses_C1(cuda):
     _close(var.cpu(), c['pts_feat'], atol=5e-5)
 
 
+def test_backproject_reuses_the_channel_last_feature_copy_only_for_the_same_features(cuda):
+    """backproject_variance keeps the channel-last feature copy in the caller's workspace: the same (unmodified) tensor again
+    skips the copy and gives the same bits; an in-place change of the features, another tensor, or another workspace do not reuse."""
+    g, img_size, d = _scene(cuda)
+    lm, mvs = v3d('lightningmodel'), v3d('mvsnet')
+    args = (d['rotmats'], d['tvecs'], d['K'], d['edges'], img_size)
+    ws = mvs._Workspace()
+    feat = d['feat'].clone()
+    fresh = lambda f: lm.backproject_variance(d['depth'], f, *args, offset=0.03, n=2)[1]
+    a = lm.backproject_variance(d['depth'], feat, *args, offset=0.03, n=2, workspace=ws)[1]
+    assert ws.tags['bp'] is not None and torch.equal(a, fresh(feat))
+    b = lm.backproject_variance(d['depth'], feat, *args, offset=0.03, n=2, workspace=ws)[1]       # reused copy
+    assert torch.equal(a, b)
+    feat.mul_(1.5)                                                                                # version bump: copied again
+    c = lm.backproject_variance(d['depth'], feat, *args, offset=0.03, n=2, workspace=ws)[1]
+    assert torch.equal(c, fresh(feat)) and not torch.equal(c, a)
+    other = feat * 0.5                                                                            # another tensor
+    e = lm.backproject_variance(d['depth'], other, *args, offset=0.03, n=2, workspace=ws)[1]
+    assert torch.equal(e, fresh(other))
+    with torch.inference_mode():                                                                  # no version counter: never reused
+        inf = feat.clone()
+        lm.backproject_variance(d['depth'], inf, *args, offset=0.03, n=2, workspace=ws)
+        assert ws.tags['bp'] is None
+
+
 def test_voxelize_B3_on_device(cuda):
     g = load_golden('B_voxelize')
     a_pts, a_idx, a_batch, a_edges = v3d('utils').voxelize(t(g['pts']).to(cuda), t(g['pts_batch']).to(cuda),
