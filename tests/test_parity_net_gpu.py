@@ -596,6 +596,30 @@ def test_segment_csr_and_max_equal_scatter_amax(n, n_seg, N, cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M', [7, 100, 9000])
+def test_sparse_conv_without_any_neighbour_is_the_epilogue_of_zero(M, cuda):
+    """A tile (here: every tile) whose 27 offsets are all absent runs no step at all on any of the three small-M kernels: the output
+    is the epilogue of a zero accumulator -- GroupNorm of the bias (none: zeros -> the GroupNorm bias), + residual, ReLU."""
+    sm, libm = v3d('scenemodeling'), v3d('_lib')
+    C = N = 128
+    g = torch.Generator().manual_seed(M)
+    gn_w, gn_b = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    pk = sm.PackedGemm(torch.randn(27, C, N, generator=g) * 0.05, C * N, 1, N, 27, N, C, gn_w=gn_w, gn_b=gn_b)
+    x = torch.randn(M, C, generator=g).to(cuda)
+    nbr = torch.full((27, M), -1, dtype=torch.int32, device=cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    want = torch.relu(gn_b.to(cuda)[None, :] + res)
+    for rounds, pipe in ((1, 1), (1, 0), (0, 0)):
+        old, old_p = libm.set_option('gemm_rounds', rounds), libm.set_option('gemm_pipe', pipe)
+        try:
+            out = pk(M, [x] * 27, idxs=[nbr[k] for k in range(27)], use_gn=True, residual=res, relu_out=True)
+        finally:
+            libm.set_option('gemm_rounds', old), libm.set_option('gemm_pipe', old_p)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (rounds, pipe)
+
+
+@pytest.mark.gpu
 def test_sparse_conv_entry_point_equals_the_gather_gemm_call(cuda):
     """v3d_sparse_conv_f32 (the U-Net's one-call convolution: source, neighbour table, stride) is v3d_gemm_gather_f32 with the 27
     segment arrays built in C: same bits, with GroupNorm, residual and ReLU; a short neighbour stride is refused."""
