@@ -89,7 +89,7 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // distinct slots; weight fragments are split and packed on the host.
 // ---- epilogue shared by the GEMM kernels: bias -> GroupNorm(16) -> residual -> ReLU -> scatter-max -> store -----------
 template <int MBW, int NB>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NB][MBW], int m0, int wave, int kq, int jn) {
+__device__ __forceinline__ void gemm_epilogue_generic(const GemmParams& p, f32x4 (&acc)[NB][MBW], int m0, int wave, int kq, int jn) {
   // ---- epilogue: lane (kq, jn) holds channels co0 .. co0+3 of row m0 + nb*16 + jn -------------------
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -144,6 +144,88 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
               if (co0 + r < p.N) o[r] = v[r];
           }
         }
+      }
+    }
+  }
+}
+
+// The same epilogue for the shapes every hot caller has (N a multiple of 16, 16-byte aligned rows of `out` / `residual`, no
+// scatter-max): the generic code above loads bias / GroupNorm affine / residual one float at a time inside the (row block,
+// channel block) loops and waits for each -- the compiler cannot move a load across the stores of the previous block -- which made
+// the epilogue 28 k of the 46 k cycles of a PointNet layer's workgroup (scripts/micro/phase_dense_gemm.py) and ~10 % of a sparse
+// convolution.  Here the per-channel constants are read once as float4, the residual rows of the whole tile are requested before
+// the first is used, and nothing but the stores is predicated.  Same arithmetic, same order: bit-identical.
+template <int MBW, int NB>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NB][MBW], int m0, int wave, int kq, int jn) {
+  const bool fast = p.N % 16 == 0 && !p.pool && (!p.out || (p.ld_out % 4 == 0 && (reinterpret_cast<size_t>(p.out) & 15) == 0)) &&
+                    (!p.residual || (p.ld_res % 4 == 0 && (reinterpret_cast<size_t>(p.residual) & 15) == 0)) &&
+                    (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0) &&
+                    (!p.gn_w || ((reinterpret_cast<size_t>(p.gn_w) & 15) == 0 && (reinterpret_cast<size_t>(p.gn_b) & 15) == 0));
+  if (!fast) {
+    gemm_epilogue_generic<MBW, NB>(p, acc, m0, wave, kq, jn);
+    return;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 b4[MBW], gw4[MBW], gb4[MBW];
+  int coc[MBW];
+  bool cok[MBW];
+#pragma unroll
+  for (int mw = 0; mw < MBW; ++mw) {
+    const int co0 = (wave * MBW + mw) * 16 + kq * 4;
+    cok[mw] = co0 < p.N;
+    coc[mw] = cok[mw] ? co0 : 0;                    // a channel block behind N reads block 0 and stores nothing
+    b4[mw] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + coc[mw]) : zero4;
+    if (!cok[mw]) b4[mw] = zero4;                   // (the generic code adds no bias there; the GroupNorm of such a block is never stored)
+    gw4[mw] = p.gn_w ? *reinterpret_cast<const f32x4*>(p.gn_w + coc[mw]) : zero4;
+    gb4[mw] = p.gn_w ? *reinterpret_cast<const f32x4*>(p.gn_b + coc[mw]) : zero4;
+  }
+  // the residual rows of four row blocks at a time are requested before the first is used (all of a 64-row tile)
+  constexpr int G = NB < 4 ? NB : 4;
+#pragma unroll
+  for (int g0 = 0; g0 < NB; g0 += G) {
+    f32x4 res[G][MBW];
+    if (p.residual) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int m = m0 + (g0 + g) * 16 + jn, mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int mw = 0; mw < MBW; ++mw)
+          res[g][mw] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mc * p.ld_res + coc[mw]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int nb = g0 + g, m = m0 + nb * 16 + jn;
+#pragma unroll
+      for (int mw = 0; mw < MBW; ++mw) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[nb][mw][r] + b4[mw][r];
+        if (p.gn_w) {
+          const float ginv = p.gn8 ? 1.f / 8.f : 1.f / 16.f;
+          float sum = v[0] + v[1] + v[2] + v[3];
+          sum += __shfl_xor(sum, 16);
+          if (!p.gn8) sum += __shfl_xor(sum, 32);
+          const float mean = sum * ginv;
+          float sq = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq += (v[r] - mean) * (v[r] - mean);
+          sq += __shfl_xor(sq, 16);
+          if (!p.gn8) sq += __shfl_xor(sq, 32);
+          const float rstd = 1.f / sqrtf(sq * ginv + p.gn_eps);      // biased variance (torch GN)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (v[r] - mean) * rstd * gw4[mw][r] + gb4[mw][r];
+        }
+        if (p.residual) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += res[g][mw][r];
+        }
+        if (p.relu_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.out && m < p.M && cok[mw])
+          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ld_out + coc[mw]) = (f32x4){v[0], v[1], v[2], v[3]};
       }
     }
   }
