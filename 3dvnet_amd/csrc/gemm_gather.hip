@@ -1184,6 +1184,16 @@ extern "C" int v3d_gemm_gather_f32(const v3d_gemm_weights* h, int M, const float
         else if (rows == 64) gemm_gather_rounds_kernel<1, 4, 4><<<rb, 256, 0, s>>>(p);
         else gemm_gather_rounds_kernel<1, 2, 4><<<rb, 256, 0, s>>>(p);
       }
+    } else if (!small && v3d::option(v3d::kOptGemmRoundRows) == 64) {
+      // developer A/B: 64-row tiles for large M on the one-step kernel (half the accumulators, one more workgroup per CU)
+      const unsigned b64 = (unsigned)((M + 63) / 64);
+#define V3D_GG64(MBW_)                                                                     \
+  do {                                                                                     \
+    if (fp32_path) gemm_gather_kernel<MBW_, 4, false><<<b64, 256, 0, s>>>(p);              \
+    else gemm_gather_kernel<MBW_, 4, true><<<b64, 256, 0, s>>>(p);                         \
+  } while (0)
+      if (h->MBW == 2) V3D_GG64(2); else V3D_GG64(1);
+#undef V3D_GG64
     } else if (h->MBW == 2) { if (small) V3D_GG(2, 2); else V3D_GG(2, 8); }
     else { if (small) V3D_GG(1, 2); else V3D_GG(1, 8); }
 #undef V3D_GG
