@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 PRECISION = {'split_bf16': 0, 'fp32': 1}      # V3D_PRECISION_* of include/v3d.h
 
 

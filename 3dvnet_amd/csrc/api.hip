@@ -8,7 +8,7 @@
 
 #include "v3d_common.h"
 
-extern "C" int v3d_version(void) { return 3; }
+extern "C" int v3d_version(void) { return 4; }
 
 extern "C" const char* v3d_last_error(void) { return v3d::err_buf(); }
 
