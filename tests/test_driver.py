@@ -344,6 +344,12 @@ def test_bench_line_carries_cfg5_and_cfg3_figures(cuda):
     assert len(e3['parity']['per_outer_iteration']) == 2 and 'points_in_different_cells_at_iteration_2' in e3['parity']['free_running']
     assert e3['parity']['max_abs_refinement_m'] > 0.01       # the sweeps really moved the depths
     assert 'replicas' in d['config']['multi_gpu_note']
+    # the stage-3 leg prices its twelve conv launches against the matrix peak and carries their HBM traffic from the committed
+    # PMC passes (profiles/<round>_traffic_cfg3.json); the from-images figure is the sum of the two timed stages
+    s3 = d['extra']['cfg3_full']['stage3']
+    assert s3['roofline']['bound'] == 'mfma' and 0 < s3['roofline']['frac'] < 1 and s3['roofline']['traffic'] > 1e8
+    assert d['extra']['cfg3']['roofline']['traffic'] > 1e8
+    assert d['extra']['from_images']['value'] > 0 and d['extra']['backbone']['ms_per_batch'] > 0
 
 
 def test_bench_rank_plumbing_dry_run():

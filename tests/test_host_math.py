@@ -1,5 +1,6 @@
 """CPU checks of arithmetic identities the HIP kernels rely on (numpy emulation of the fp32 instruction sequences)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -198,3 +199,28 @@ def test_whole_model_state_dict_keys_and_checkpoint_round_trip(tmp_path):
     torch.save({'state_dict': bad, 'hyper_parameters': hp}, path)
     with pytest.raises(RuntimeError, match='unexpected'):
         lm.PL3DVNet.load_from_checkpoint(path)
+
+
+def test_traffic_json_aggregates_kernel_families(tmp_path):
+    """profiles/make_traffic.py: single kernels by substring, kernel families (the sparse-convolution pipeline's instances, the FLAT
+    conv launches of stage 3) as the dispatch-weighted mean; the gfx950 x2 on FETCH_SIZE applied to every entry."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = 'kernel,counter,dispatches,avg_value_per_dispatch\n'
+    fetch = head + 'decoder_fused_kernel,FETCH_SIZE,6,100.0\n"gemm_gather_pipe_kernel<2, 4, 8, 2, 1>",FETCH_SIZE,20,10.0\n' \
+                   '"gemm_gather_pipe_kernel<2, 2, 4, 2, 2>",FETCH_SIZE,10,40.0\n' \
+                   '"convg_bf16x2_kernel<CG<32, 32, 1, 14, 2, true> >",FETCH_SIZE,6,300.0\n' \
+                   '"convg_bf16x2_kernel<CG<32, 32, 1, 14, 2, false> >",FETCH_SIZE,1,7.0\n'
+    write = fetch.replace('FETCH_SIZE', 'WRITE_SIZE')
+    (tmp_path / 'f.csv').write_text(fetch)
+    (tmp_path / 'w.csv').write_text(write)
+    out = tmp_path / 't.json'
+    subprocess.check_call([sys.executable, os.path.join(root, 'profiles', 'make_traffic.py'), str(tmp_path / 'f.csv'),
+                           str(tmp_path / 'w.csv'), '64', str(out)])
+    k = json.load(open(out))['kernels']
+    assert k['decoder_fused']['hbm_bytes'] == (2 * 100.0 + 100.0) * 1024
+    assert k['sparse_conv_gemm']['fetch_kb_raw'] == pytest.approx((20 * 10.0 + 10 * 40.0) / 30)
+    assert k['propagation_conv']['fetch_kb_raw'] == 300.0 and k['costreg_conv4']['fetch_kb_raw'] == 7.0
+
