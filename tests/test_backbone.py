@@ -164,3 +164,47 @@ def test_native_backbone_matches_the_modules_on_the_cpu(cuda):
     # not a multiple of 32: the modules run as given
     assert not bb.NativeBackbone(fe.to(cuda), fs.to(cuda)).supports(torch.zeros(1, 3, 240, 320, device=cuda))
     fe.to('cpu'), fs.to('cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('taps,cin,cout,H,W,res_mode', [(1, 16, 48, 24, 40, 0), (1, 72, 24, 17, 23, 1), (9, 32, 32, 24, 40, 0),
+                                                        (9, 40, 32, 16, 20, 2), (1, 24, 32, 64, 80, 2), (9, 8, 32, 9, 7, 0)])
+def test_conv_entry_point_against_the_plain_convolution(taps, cin, cout, H, W, res_mode, cuda):
+    """v3d_conv_nhwc_f32 through the C ABI against torch's conv2d on the CPU: channel counts that are not multiples of 32, the image
+    borders of the 3x3 taps, a ragged last row block, ReLU and both residual modes (same-resolution and 2x nearest-upsampled)."""
+    import ctypes
+    libm = v3d('_lib')
+    lib = libm.load()
+    g = torch.Generator().manual_seed(taps * 1000 + cin)
+    n = 3
+    w = (torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) * 0.1).contiguous()
+    bias = torch.randn(cout, generator=g)
+    wk = w.permute(0, 2, 3, 1).reshape(cout, taps * cin).contiguous()           # [co, tap * cin + c] (include/v3d.h: v3d_conv_pack)
+    x = torch.randn(n, H, W, cin, generator=g).to(cuda)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(n, H, W, cout, generator=g).to(cuda)
+    elif res_mode == 2:
+        res = torch.randn(n, H // 2, W // 2, cout, generator=g).to(cuda)
+    if res_mode == 2 and (H % 2 or W % 2):
+        pytest.skip('upsampled residual needs even sides')
+    handle = ctypes.c_void_p()
+    libm.check(lib.v3d_conv_pack(wk.numpy().ctypes.data_as(libm.c_float_p), bias.numpy().ctypes.data_as(libm.c_float_p), cout, taps * cin,
+                                 ctypes.byref(handle)), 'v3d_conv_pack')
+    try:
+        out = torch.empty(n, H, W, cout, device=cuda)
+        libm.check(lib.v3d_conv_nhwc_f32(handle, x.data_ptr(), n, H, W, cin, taps, 1, res_mode,
+                                         res.data_ptr() if res is not None else None, out.data_ptr(), libm.stream_ptr(cuda)),
+                   'v3d_conv_nhwc_f32')
+        torch.cuda.synchronize()
+    finally:
+        lib.v3d_conv_free(handle)
+    assert torch.isfinite(out).all()
+    # fp32 matrix instructions are an fmaf chain in another order than the CPU's: 1e-5 of the range
+    ref = torch.nn.functional.conv2d(x.cpu().permute(0, 3, 1, 2), w, bias, padding=1 if taps == 9 else 0).relu()
+    if res_mode == 1:
+        ref = ref + res.cpu().permute(0, 3, 1, 2)
+    elif res_mode == 2:
+        ref = ref + torch.nn.functional.interpolate(res.cpu().permute(0, 3, 1, 2), scale_factor=2, mode='nearest')
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-5 * ref.abs().max()
+
