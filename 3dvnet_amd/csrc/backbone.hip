@@ -36,6 +36,7 @@ struct ConvParams {
   const float* res;      // residual: [n, H, W, Cout] (mode 1) or [n, H / 2, W / 2, Cout] (mode 2) or null
   float* out;            // [n, H, W, Cout]
   int n, H, W, cin, cout, ncb, nsteps, relu, res_mode;
+  unsigned m_hw, m_w;    // v3d::magic_u32 of H * W and W (the upsampled residual's address: two divisions per element otherwise)
   long long P;           // n * H * W
 };
 
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
       if (p.relu) v = fmaxf(v, 0.f);
       if (p.res_mode == 1) v += p.res[q * p.cout + co];
       else if (p.res_mode == 2) {
-        const unsigned hw = (unsigned)(p.H * p.W), img = (unsigned)q / hw, rem = (unsigned)q - img * hw;
-        const unsigned y = rem / (unsigned)p.W, x = rem - y * (unsigned)p.W;
+        const unsigned hw = (unsigned)(p.H * p.W), img = v3d::udiv_magic((unsigned)q, hw, p.m_hw), rem = (unsigned)q - img * hw;
+        const unsigned y = v3d::udiv_magic(rem, (unsigned)p.W, p.m_w), x = rem - y * (unsigned)p.W;
         v += p.res[((size_t)(img * (unsigned)(p.H >> 1) + (y >> 1)) * (unsigned)(p.W >> 1) + (x >> 1)) * p.cout + co];
       }
       p.out[q * p.cout + co] = v;
@@ -310,6 +311,7 @@ extern "C" int v3d_conv_nhwc_f32(const v3d_conv_weights* h, const float* x, int 
   ConvParams p;
   p.x = x; p.wp = h->dev; p.bias = h->dev + h->bias_ofs; p.res = res; p.out = out;
   p.n = n; p.H = H; p.W = W; p.cin = cin; p.cout = h->cout; p.ncb = h->ncb; p.nsteps = h->nsteps; p.relu = relu; p.res_mode = res_mode; p.P = P;
+  p.m_hw = v3d::magic_u32((unsigned long long)P, (unsigned)(H * W)); p.m_w = v3d::magic_u32((unsigned long long)H * W, (unsigned)W);
   hipStream_t s = (hipStream_t)stream;
   // Few positions and a long K (the 1/16 and 1/32 resolution layers): split K over the four waves of a workgroup.  Otherwise a
   // workgroup holds 128 positions and every wave as many column blocks as keep >= ~2 workgroups per CU in flight (a wide tile
