@@ -333,8 +333,10 @@ class SparseUNet(nn.Module):
         # of three ctypes arrays of 27 entries per convolution -- the U-Net forward was bound by this host code, not the kernels
         if x.device != pack.device:
             raise _lib.V3DLibraryError('sparse convolution: weights were packed on %s, input lives on %s' % (pack.device, x.device))
+        if not x.is_contiguous():
+            x = x.contiguous()
         y = torch.empty((n_out, pack.N), dtype=torch.float32, device=x.device)
-        rc = self._lib.v3d_sparse_conv_f32(pack.handle, n_out, x.data_ptr(), x.shape[1], nbr.data_ptr(), nbr.shape[1],
+        rc = _lib.load().v3d_sparse_conv_f32(pack.handle, n_out, x.data_ptr(), x.shape[1], nbr.data_ptr(), nbr.shape[1],
                                            pack.gn_group, eps, residual.data_ptr() if residual is not None else None,
                                            residual.shape[1] if residual is not None else 0, 1, y.data_ptr(), pack.N,
                                            self._prec_code, self._stream)
@@ -357,7 +359,8 @@ class SparseUNet(nn.Module):
         if not F.is_cuda:
             raise _lib.V3DLibraryError('SparseUNet: tensors must live on a HIP device (no CPU fallback)')
         self._dev = F.device
-        self._lib, self._stream, self._prec_code = _lib.load(), _lib.stream_ptr(F.device), _lib.precision_code(self.precision)
+        # (plain integers: a module attribute must survive copy.deepcopy / pickling, a ctypes library handle would not)
+        self._stream, self._prec_code = _lib.stream_ptr(F.device), _lib.precision_code(self.precision)
         g = self._cache.get(self._build, F.device)
         coords = torch.cat((batch.unsqueeze(1), idx), dim=1).int().contiguous()       # [N,4] (b,x,y,z)
         # coordinate maps: stride-2 conv output = unique(floor(c / 2ts) * 2ts), lexicographic order
