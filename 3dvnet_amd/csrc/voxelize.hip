@@ -59,13 +59,19 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restri
   if (threadIdx.x < 7) part[blockIdx.x * 7 + threadIdx.x] = s[threadIdx.x][0];
 }
 
+// one wave: the partials are spread over the 64 lanes and reduced with shuffles (one thread walking 256 partials was 256
+// dependent round trips: 50 us for a 7-word result); minima / maxima do not depend on the order
 __global__ void bbox_finish_kernel(const float* __restrict__ part, int nblocks, float edge, VoxMeta* meta) {
-  if (threadIdx.x != 0) return;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, mb = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
     for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], part[b * 7 + d]); hi[d] = fmaxf(hi[d], part[b * 7 + 3 + d]); }
     mb = fmaxf(mb, part[b * 7 + 6]);
   }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o)); }
+    mb = fmaxf(mb, __shfl_xor(mb, o));
+  }
+  if (threadIdx.x != 0) return;
   long long cum = 1;
   for (int d = 0; d < 3; ++d) {
     meta->bmin[d] = lo[d]; meta->bmax[d] = hi[d];
