@@ -39,6 +39,7 @@
 // The unfused `prob` conv (8 -> 1 channel) is VALU work (a 1-wide GEMM would waste 15/16 of an MFMA)
 // and the depth softmax + expectation is a per-pixel streaming reduction.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -2652,6 +2653,184 @@ extern "C" size_t v3d_costreg_workspace_bytes(const v3d_costreg_weights*, int n_
   return plan_ws(n_ref, D, h, w).total;
 }
 
+namespace {
+int launch_soft_argmin(const float* xreg, const float* depth_vals, float* depth, int n, int D, int H, int W, hipStream_t s) {
+  const size_t npix = (size_t)n * H * W;
+  {
+    v3d::TimedScope ts("soft_argmin", s);
+    soft_argmin_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(xreg, depth_vals, depth, n, D, H * W);
+  }
+  V3D_CHECK_LAUNCH("soft_argmin_kernel");
+  return V3D_OK;
+}
+
+// conv9 + skip + prob: the tile kernel (split-bf16 or exact-fp32 operands)
+int launch_conv9_prob(bool f32, const v3d_costreg_weights* h, const float* u8, const float* c0, float* xreg, int n, int D, int H, int W,
+                      hipStream_t s) {
+  C9Params q;
+  q.u8 = u8; q.c0 = c0; q.wbf = h->dev + (f32 ? h->c9f32_ofs : h->c9bf_ofs); q.bias9 = h->dev + h->bias_ofs[9];
+  q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
+  q.n = n; q.D = D; q.H = H; q.W = W;
+  q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
+  q.zy_order = tile_order(q.ntx, q.nty);
+  const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
+  V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
+  // 32-bit byte offsets inside one view's tensors (conv0 skip: 2 x 16 bytes per voxel / 8 fp32 planes)
+  V3D_REQUIRE((long long)D * H * W < (1ll << 26) && D < (1 << 12) && H < (1 << 12) && W < (1 << 12), V3D_ERR_BAD_SHAPE,
+              "conv9+prob: volume %d x %d x %d too large for 32-bit offsets", D, H, W);
+  q.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)q.ntx);
+  q.m_t1 = v3d::magic_u32((unsigned long long)blocks / q.ntx + 1, (unsigned)(q.zy_order ? q.ntz : q.nty));
+  q.m_t2 = v3d::magic_u32((unsigned long long)blocks / q.ntx / (q.zy_order ? q.ntz : q.nty) + 1, (unsigned)(q.zy_order ? q.nty : q.ntz));
+  {
+    v3d::TimedScope ts(f32 ? "costreg_conv9_prob_f32" : "costreg_conv9_prob", s);
+    // (round 6: a persistent variant -- two workgroups per CU walking their tiles, the weight fragments resident in their own
+    // 18 KB of LDS, the next tile's input slots requested behind the staging barrier / the matrix phase / the u9 assembly --
+    // measured 0.49-0.52 ms against the 0.43-0.45 of one workgroup per tile on the same box, wherever the prefetch sat: DESIGN.md 8.3)
+    if (f32) conv9_prob_kernel<true><<<(unsigned)blocks, 512, 0, s>>>(q);
+    else conv9_prob_kernel<false><<<(unsigned)blocks, 512, 0, s>>>(q);
+  }
+  V3D_CHECK_LAUNCH("conv9_prob_kernel");
+  return V3D_OK;
+}
+
+// Side streams of the regulariser's tail (one set per device, created on first use, never destroyed: the library's only
+// device-side resources besides weight handles).  Non-blocking streams; ordering against the caller's stream is by events.
+constexpr int kTailStreamsMax = 8;
+struct TailStreams { hipStream_t st[kTailStreamsMax]; hipEvent_t fork, done[kTailStreamsMax]; int n; };
+TailStreams* tail_streams(int want) {
+  static TailStreams pool[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  TailStreams& t = pool[dev];
+  if (t.n == 0 && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  while (t.n < want) {
+    if (hipStreamCreateWithFlags(&t.st[t.n], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.done[t.n], hipEventDisableTiming) != hipSuccess) return nullptr;
+    ++t.n;
+  }
+  return &t;
+}
+
+// The split-bf16 regulariser behind conv0: conv1 + conv2 (step 1), conv3 .. conv8 (steps 3 .. 8), conv9 + skip + prob (9),
+// soft-argmin (10), for views [v0, v0 + nv) on stream st.  Every tensor of the chain is per-view contiguous, so a sub-batch
+// is a pointer offset.
+struct TailCtx {
+  const v3d_costreg_weights* h; WsPlan ws; char* base; const float* depth_vals; float* depth; float* xreg; int n, D, H, W;
+};
+int run_tail_steps(const TailCtx& c, int first, int last, int v0, int nv, hipStream_t st) {
+  const v3d_costreg_weights* h = c.h;
+  const int D = c.D, H = c.H, W = c.W;
+  const size_t V0 = (size_t)D * H * W, V1 = V0 / 8, V2 = V1 / 8, V3 = V2 / 8;
+  auto F = [&](size_t o, size_t per_view) { return (float*)(c.base + o) + (size_t)v0 * per_view; };
+  // conv1..conv6 hand their activations on in the split layout; the transposed convolutions read their skips (conv2, conv4)
+  // from the same split copies (DG::SKIP_SPLIT).  The split copies live in the u9 slot of the workspace, which the fused
+  // conv9+prob kernel does not need.
+  float* const c2s_all = (float*)(c.base + c.ws.u9);
+  float* const c4s_all = c2s_all + (size_t)c.n * 16 * V1;
+  float* const c2s = c2s_all + (size_t)v0 * 16 * V1;
+  float* const c4s = c4s_all + (size_t)v0 * 32 * V2;
+  auto W_ = [&](int l) { return h->dev + h->cgbf_ofs[l]; };
+  auto B_ = [&](int l) { return h->dev + h->bias_ofs[l]; };
+  int rc;
+#ifdef V3D_PHASE_TIMING
+  const int stop_after = v3d::option(v3d::kOptStopAfter);   // isolate one kernel's counters
+#else
+  const int stop_after = 99;
+#endif
+  for (int step = first; step <= last; ++step) {
+    if (step > stop_after) return V3D_OK;
+    switch (step) {
+      case 1:
+        // conv1 + conv2: the fused depth march of conv12z.hip (conv1's output never leaves LDS: 0.27 ms per 64 cfg2 views against
+        // 0.176 + 0.146 for the two tile kernels, which remain behind the developer option c12_march = 0 and the per-layer entry points)
+        if (v3d::option(v3d::kOptC12March) != 0) {
+          if ((rc = v3d::launch_conv12z(F(c.ws.c0, 8 * V0), W_(1), W_(2), B_(1), B_(2), c2s, nv, D, H, W, st)) != V3D_OK) return rc;
+        } else {
+          if ((rc = launch_convg<CG<8, 16, 2, 14, kOutSplit>>("costreg_conv1", F(c.ws.c0, 8 * V0), W_(1), B_(1), nullptr, F(c.ws.c1, 16 * V1),
+                                                              nv, D, H, W, st)) != V3D_OK) return rc;
+          if ((rc = launch_convg<CG<16, 16, 1, 14, kOutSplit>>("costreg_conv2", F(c.ws.c1, 16 * V1), W_(2), B_(2), nullptr, c2s, nv, D / 2,
+                                                               H / 2, W / 2, st)) != V3D_OK) return rc;
+        }
+        break;
+      case 3:
+        if ((rc = launch_convg<CG<16, 32, 2, 14, kOutSplit>>("costreg_conv3", c2s, W_(3), B_(3), nullptr, F(c.ws.c3, 32 * V2), nv, D / 2,
+                                                             H / 2, W / 2, st)) != V3D_OK) return rc;
+        break;
+      case 4:
+        if ((rc = launch_convg<CG<32, 32, 1, 14, kOutSplit>>("costreg_conv4", F(c.ws.c3, 32 * V2), W_(4), B_(4), nullptr, c4s, nv, D / 4,
+                                                             H / 4, W / 4, st)) != V3D_OK) return rc;
+        break;
+      case 5:
+        if ((rc = launch_convg<CG<32, 64, 2, 8, kOutSplit>>("costreg_conv5", c4s, W_(5), B_(5), nullptr, F(c.ws.c5, 64 * V3), nv, D / 4,
+                                                            H / 4, W / 4, st)) != V3D_OK) return rc;
+        break;
+      case 6:
+        if ((rc = launch_convg<CG<64, 64, 1, 8, kOutSplit>>("costreg_conv6", F(c.ws.c5, 64 * V3), W_(6), B_(6), nullptr, F(c.ws.c6, 64 * V3),
+                                                            nv, D / 8, H / 8, W / 8, st)) != V3D_OK) return rc;
+        break;
+      case 7:      // conv4 + conv7(x) (mvsnet.py:159)
+        if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit, true>>("costreg_conv7", F(c.ws.c6, 64 * V3), h->dev + h->dgbf_ofs[0], B_(7), c4s,
+                                                                 nullptr, F(c.ws.u7, 32 * V2), nv, D / 8, H / 8, W / 8, st)) != V3D_OK) return rc;
+        break;
+      case 8:      // conv2 + conv8(x) (:160)
+        if ((rc = launch_deconvg<DG<32, 16, 14, kOutSplit, true>>("costreg_conv8", F(c.ws.u7, 32 * V2), h->dev + h->dgbf_ofs[1], B_(8), c2s,
+                                                                  nullptr, F(c.ws.u8, 16 * V1), nv, D / 4, H / 4, W / 4, st)) != V3D_OK) return rc;
+        break;
+      case 9:
+        // conv9 + skip + prob: the tile kernel.  Developer A/B (v3d_set_option "c9_kernel" = 1): the depth-march experiment of
+        // round 4 (conv9z.hip: correct, but 0.51 against 0.46 ms per 64 views, see its header; -DV3D_EXPERIMENTS builds only)
+        if (v3d::option(v3d::kOptC9Kernel) == 1) {
+          if ((rc = v3d::launch_conv9z(F(c.ws.u8, 16 * V1), F(c.ws.c0, 8 * V0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9],
+                                       h->dev + h->prob_w2_ofs, h->dev + h->prob_b_ofs, c.xreg + (size_t)v0 * V0, nv, D, H, W, st)) != V3D_OK)
+            return rc;
+        } else if ((rc = launch_conv9_prob(false, h, F(c.ws.u8, 16 * V1), F(c.ws.c0, 8 * V0), c.xreg + (size_t)v0 * V0, nv, D, H, W, st)) != V3D_OK) {
+          return rc;
+        }
+        break;
+      case 10:
+        if ((rc = launch_soft_argmin(c.xreg + (size_t)v0 * V0, c.depth_vals, c.depth + (size_t)v0 * H * W, nv, D, H, W, st)) != V3D_OK) return rc;
+        break;
+      default: break;      // step 2: conv2 is part of step 1
+    }
+  }
+  return V3D_OK;
+}
+
+// Views are independent through the whole regulariser, and the layers behind conv0 are latency-bound rather than
+// throughput-bound (grids of a few hundred short workgroups, 0.04-0.1 ms each: DESIGN.md 8.3).  Steps [tail_from, tail_to]
+// therefore run as `tail_streams` sub-batches of views on the library's side streams -- the kernels of different sub-batches
+// fill each other's ramp-up, drain and barrier gaps -- forked from and joined back into the caller's stream by events
+// (capturable in a HIP graph: a fork / join inside one capture).  Same kernels on the same data: bit-identical results.
+int run_split_tail(const v3d_costreg_weights* h, const WsPlan& ws, char* base, const float* depth_vals, int n, int D, int H, int W,
+                   float* depth, float* xreg, hipStream_t s) {
+  TailCtx c{h, ws, base, depth_vals, depth, xreg, n, D, H, W};
+  int S = v3d::option(v3d::kOptTailStreams);
+  int first = v3d::option(v3d::kOptTailFrom), last = v3d::option(v3d::kOptTailTo);
+  V3D_REQUIRE(S >= 1 && S <= kTailStreamsMax && first >= 1 && first <= 10 && last >= first && last <= 10, V3D_ERR_BAD_ARG,
+              "options tail_streams (1..%d) / tail_from / tail_to (1..10) out of range", kTailStreamsMax);
+  if (S > n) S = n;
+#ifdef V3D_PHASE_TIMING
+  S = 1;
+#endif
+  int rc;
+  if (S == 1) return run_tail_steps(c, 1, 10, 0, n, s);
+  TailStreams* t = tail_streams(S);
+  V3D_REQUIRE(t, V3D_ERR_HIP, "the regulariser's side streams could not be created");
+  if ((rc = run_tail_steps(c, 1, first - 1, 0, n, s)) != V3D_OK) return rc;
+  V3D_CHECK_HIP(hipEventRecord(t->fork, s));
+  for (int k = 0; k < S; ++k) {
+    const int v0 = (int)((long long)n * k / S), v1 = (int)((long long)n * (k + 1) / S);
+    V3D_CHECK_HIP(hipStreamWaitEvent(t->st[k], t->fork, 0));
+    if ((rc = run_tail_steps(c, first, last, v0, v1 - v0, t->st[k])) != V3D_OK) return rc;
+    V3D_CHECK_HIP(hipEventRecord(t->done[k], t->st[k]));
+  }
+  for (int k = 0; k < S; ++k) V3D_CHECK_HIP(hipStreamWaitEvent(s, t->done[k], 0));
+  return run_tail_steps(c, last + 1, 10, 0, n, s);
+}
+}  // namespace
+
 // in_layout: 0 = reference fp32 [n, C, D, h, w], 1 = split-bf16 hand-off, 2 = fp32 channel-last (v3d_psv_variance_cl8)
 static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const float* var,
                               const float* depth_vals, int n, int D, int H, int W,
@@ -2709,97 +2888,19 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
                                      W, s)) != V3D_OK) return rc;
       }
     }
-#ifdef V3D_PHASE_TIMING
-    const int stop_after = v3d::option(v3d::kOptStopAfter);   // isolate one kernel's counters
-#define V3D_STOP(l) if (stop_after == (l)) return V3D_OK
-#else
-#define V3D_STOP(l)
-#endif
-    // conv1..conv6 hand their activations on in the split layout; the transposed convolutions read their skips (conv2, conv4)
-    // from the same split copies (DG::SKIP_SPLIT; until round 4 conv2 / conv4 wrote a second, fp32 tensor for them).  The
-    // split copies live in the u9 slot of the workspace, which the fused conv9+prob kernel no longer needs.
-#ifndef V3D_SKIP_SPLIT
-#define V3D_SKIP_SPLIT true      // developer A/B: false = conv2 / conv4 also write fp32 tensors, the skips of conv8 / conv7 (rounds 2-3)
-#endif
-    constexpr int V3D_SKIP_OUT = V3D_SKIP_SPLIT ? kOutSplit : (kOutF32 | kOutSplit);
-    float* const c2s = F(ws.u9);
-    float* const c4s = c2s + (size_t)n * 16 * (D / 2) * (H / 2) * (W / 2);
-    auto W_ = [&](int l) { return h->dev + h->cgbf_ofs[l]; };
-    auto B_ = [&](int l) { return h->dev + h->bias_ofs[l]; };
-    V3D_STOP(0);
-    // conv1 + conv2: the fused depth march of conv12z.hip (conv1's output never leaves LDS: 0.27 ms per 64 cfg2 views against 0.176 +
-    // 0.146 for the two tile kernels, which remain behind the developer option c12_march = 0 and the per-layer entry points)
-    const bool c12_march = V3D_SKIP_SPLIT && v3d::option(v3d::kOptC12March) != 0;
-    if (c12_march) {
-      if ((rc = v3d::launch_conv12z(F(ws.c0), W_(1), W_(2), B_(1), B_(2), c2s, n, D, H, W, s)) != V3D_OK) return rc;
-    } else {
-    if ((rc = launch_convg<CG<8, 16, 2, 14, kOutSplit>>("costreg_conv1", F(ws.c0), W_(1), B_(1), nullptr, F(ws.c1), n, D, H, W,
-                                                        s)) != V3D_OK) return rc;
-    V3D_STOP(1);
-    if ((rc = launch_convg<CG<16, 16, 1, 14, V3D_SKIP_OUT>>("costreg_conv2", F(ws.c1), W_(2), B_(2), F(ws.c2), c2s, n,
-                                                            D / 2, H / 2, W / 2, s)) != V3D_OK) return rc;
-    }
-    V3D_STOP(2);
-    if ((rc = launch_convg<CG<16, 32, 2, 14, kOutSplit>>("costreg_conv3", c2s, W_(3), B_(3), nullptr, F(ws.c3), n, D / 2, H / 2,
-                                                         W / 2, s)) != V3D_OK) return rc;
-    V3D_STOP(3);
-    if ((rc = launch_convg<CG<32, 32, 1, 14, V3D_SKIP_OUT>>("costreg_conv4", F(ws.c3), W_(4), B_(4), F(ws.c4), c4s, n,
-                                                            D / 4, H / 4, W / 4, s)) != V3D_OK) return rc;
-    V3D_STOP(4);
-    if ((rc = launch_convg<CG<32, 64, 2, 8, kOutSplit>>("costreg_conv5", c4s, W_(5), B_(5), nullptr, F(ws.c5), n, D / 4, H / 4,
-                                                        W / 4, s)) != V3D_OK) return rc;
-    V3D_STOP(5);
-    if ((rc = launch_convg<CG<64, 64, 1, 8, kOutSplit>>("costreg_conv6", F(ws.c5), W_(6), B_(6), nullptr, F(ws.c6), n, D / 8,
-                                                        H / 8, W / 8, s)) != V3D_OK) return rc;
-    V3D_STOP(6);
-    // conv4 + conv7(x) (mvsnet.py:159), conv2 + conv8(x) (:160)
-    if ((rc = launch_deconvg<DG<64, 32, 8, kOutSplit, V3D_SKIP_SPLIT>>("costreg_conv7", F(ws.c6), h->dev + h->dgbf_ofs[0], B_(7),
-                                                                       V3D_SKIP_SPLIT ? c4s : F(ws.c4), nullptr, F(ws.u7), n, D / 8,
-                                                                       H / 8, W / 8, s)) != V3D_OK) return rc;
-    V3D_STOP(7);
-    if ((rc = launch_deconvg<DG<32, 16, 14, kOutSplit, V3D_SKIP_SPLIT>>("costreg_conv8", F(ws.u7), h->dev + h->dgbf_ofs[1], B_(8),
-                                                                        V3D_SKIP_SPLIT ? c2s : F(ws.c2), nullptr, F(ws.u8), n, D / 4,
-                                                                        H / 4, W / 4, s)) != V3D_OK) return rc;
-    V3D_STOP(8);
-#undef V3D_STOP
+    // conv1 .. conv9 + prob, soft-argmin: see run_split_tail() below (sub-batches of views on concurrent streams)
+    return run_split_tail(h, ws, base, depth_vals, n, D, H, W, depth, xreg, s);
   }
-  if (generic) {
-    RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
-    RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
-    RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
-    RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
-    RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
-    RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
-  }
-  // conv9 + skip + prob: the tile kernel (split-bf16 or exact fp32 operands).  Developer A/B (v3d_set_option "c9_kernel"): 1 selects the depth-march
-  // experiment of round 4 for the split path (conv9z.hip: correct -- the GPU suite passes on it -- but 0.51 against 0.46 ms per 64
-  // views, see its header; -DV3D_EXPERIMENTS builds only); 2 the per-layer conv9 kernel + prob_conv_kernel for the exact-fp32 path (rounds 1-3).
-  const bool tile_kernel = v3d::option(v3d::kOptC9Kernel) != 1;
-  const bool f32_unfused = v3d::option(v3d::kOptC9Kernel) == 2;
-  if (!generic && !tile_kernel) {
-    if ((rc = v3d::launch_conv9z(F(ws.u8), F(ws.c0), h->dev + h->c9bf_ofs, h->dev + h->bias_ofs[9], h->dev + h->prob_w2_ofs,
-                                 h->dev + h->prob_b_ofs, xreg, n, D, H, W, s)) != V3D_OK) return rc;
-  } else if (!generic || !f32_unfused) {
-    C9Params q;
-    q.u8 = F(ws.u8); q.c0 = F(ws.c0); q.wbf = h->dev + (generic ? h->c9f32_ofs : h->c9bf_ofs); q.bias9 = h->dev + h->bias_ofs[9];
-    q.wprob = h->dev + h->prob_w2_ofs; q.bprob = h->dev + h->prob_b_ofs; q.out = xreg;
-    q.n = n; q.D = D; q.H = H; q.W = W;
-    q.ntz = (D + C9::TD - 1) / C9::TD; q.nty = (H + C9::TH - 1) / C9::TH; q.ntx = (W + C9::TW - 1) / C9::TW;
-    q.zy_order = tile_order(q.ntx, q.nty);
-    const long long blocks = (long long)n * q.ntz * q.nty * q.ntx;
-    V3D_REQUIRE(blocks < (1ll << 31), V3D_ERR_BAD_SHAPE, "conv9+prob: grid too large");
-    // 32-bit byte offsets inside one view's tensors (conv0 skip: 2 x 16 bytes per voxel / 8 fp32 planes)
-    V3D_REQUIRE((long long)D * H * W < (1ll << 26) && D < (1 << 12) && H < (1 << 12) && W < (1 << 12), V3D_ERR_BAD_SHAPE,
-                "conv9+prob: volume %d x %d x %d too large for 32-bit offsets", D, H, W);
-    q.m_tx = v3d::magic_u32((unsigned long long)blocks, (unsigned)q.ntx);
-    q.m_t1 = v3d::magic_u32((unsigned long long)blocks / q.ntx + 1, (unsigned)(q.zy_order ? q.ntz : q.nty));
-    q.m_t2 = v3d::magic_u32((unsigned long long)blocks / q.ntx / (q.zy_order ? q.ntz : q.nty) + 1, (unsigned)(q.zy_order ? q.nty : q.ntz));
-    {
-      v3d::TimedScope ts(generic ? "costreg_conv9_prob_f32" : "costreg_conv9_prob", s);
-      if (generic) conv9_prob_kernel<true><<<(unsigned)blocks, 512, 0, s>>>(q);
-      else conv9_prob_kernel<false><<<(unsigned)blocks, 512, 0, s>>>(q);
-    }
-    V3D_CHECK_LAUNCH("conv9_prob_kernel");
+  RUN(3, F(ws.c2), nullptr, F(ws.c3), D / 2, H / 2, W / 2);
+  RUN(4, F(ws.c3), nullptr, F(ws.c4), D / 4, H / 4, W / 4);
+  RUN(5, F(ws.c4), nullptr, F(ws.c5), D / 4, H / 4, W / 4);
+  RUN(6, F(ws.c5), nullptr, F(ws.c6), D / 8, H / 8, W / 8);
+  RUN(7, F(ws.c6), F(ws.c4), F(ws.u7), D / 8, H / 8, W / 8);    // conv4 + conv7(x)  (mvsnet.py:159)
+  RUN(8, F(ws.u7), F(ws.c2), F(ws.u8), D / 4, H / 4, W / 4);    // conv2 + conv8(x)  (:160)
+  // conv9 + skip + prob on exact-fp32 operands: the tile kernel; developer A/B (v3d_set_option "c9_kernel" = 2): the per-layer
+  // conv9 kernel + prob_conv_kernel (rounds 1-3)
+  if (v3d::option(v3d::kOptC9Kernel) != 2) {
+    if ((rc = launch_conv9_prob(true, h, F(ws.u8), F(ws.c0), xreg, n, D, H, W, s)) != V3D_OK) return rc;
   } else {
     RUN(9, F(ws.u8), F(ws.c0), F(ws.u9), D / 2, H / 2, W / 2);    // conv0 + conv9(x)  (:161)
     {
@@ -2811,13 +2912,7 @@ static int costreg_depth_impl(int in_layout, const v3d_costreg_weights* h, const
     V3D_CHECK_LAUNCH("prob_conv_kernel");
   }
 #undef RUN
-  const size_t npix = (size_t)n * H * W;
-  {
-    v3d::TimedScope ts("soft_argmin", s);
-    soft_argmin_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(xreg, depth_vals, depth, n, D, H * W);
-  }
-  V3D_CHECK_LAUNCH("soft_argmin_kernel");
-  return V3D_OK;
+  return launch_soft_argmin(xreg, depth_vals, depth, n, D, H, W, s);
 }
 
 extern "C" int v3d_costreg_depth_f32(const v3d_costreg_weights* h, const float* var, const float* depth_vals, int n,

@@ -58,6 +58,9 @@ enum Option {
   kOptGemmRounds,      // "gemm_rounds": 1 gather-GEMM in rounds for small M, 0 the one-step kernel, 2 rounds for every M (measured: PointNet's 200 k-row layers 1.25 -> 1.21 ms per scene, not the default)
   kOptGemmRoundRows,   // "gemm_round_rows": 0 auto, 32 | 64 | 128 rows per tile of the rounds / pipeline kernel
   kOptGemmPipe,        // "gemm_pipe": 1 sparse convolutions on the loader / matrix pipeline kernel (2: its first version), 0 the rounds kernel
+  kOptTailStreams,     // "tail_streams": sub-batches of views the regulariser's layers behind conv0 run in, on concurrent side streams (1 = the caller's stream only)
+  kOptTailFrom,        // "tail_from": first step of the concurrent section (1 conv1 + conv2, 3 .. 8 conv3 .. conv8, 9 conv9 + prob, 10 soft-argmin)
+  kOptTailTo,          // "tail_to": last step of the concurrent section
   kOptCount
 };
 int option(Option o);

@@ -59,14 +59,15 @@ def backproject_variance(depth_pred, img_feats, rotmats, tvecs, K, ref_src_edges
 class PL3DVNet(nn.Module):
     """Reference ``PL3DVNet`` (lightningmodel.py:14-43), inference surface only."""
 
-    def __init__(self, depth_train, depth_test, edge_len, feat_dim=32, img_size=(256, 320), hyp_ksize=3,
+    def __init__(self, depth_train, depth_test, edge_len, feat_dim=16, img_size=(256, 320), hyp_ksize=3,
                  hyp_pad=1, lr=1e-3, lr_step=100, lr_gamma=0.1, finetune=False, feat_extractor=None,
                  feat_shrinker=None, precision='split_bf16', backbone=False):
-        """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20), except the DEFAULT of ``feat_dim``: the
-        reference's signature says 16, but its config (mv3d/config.py:42) and the hparams of every released checkpoint say
-        32, the width the fast kernels are specialised for -- so ``PL3DVNet(depth_train, depth_test, edge_len)`` builds
-        the network the reference actually ships.  ``feat_dim=16`` runs too (round 4): the cost volume through the
-        reference-layout entry points (conv0 on the volume zero-extended to 32 channels), GroupNorm over 8-channel groups on
+        """Arguments up to ``finetune`` are the reference's (lightningmodel.py:18-20), defaults included: ``feat_dim`` defaults
+        to 16 as in the reference's signature -- the same positional call builds the same network.  The reference's config
+        (mv3d/config.py:42) and the hparams of every released checkpoint say 32, the width the fast kernels are specialised
+        for (``load_from_checkpoint`` takes it from the checkpoint; bench.py and the tests pass it explicitly).  ``feat_dim=16``
+        runs on the general entry points: the cost volume through the reference-layout entry points (conv0 on the volume
+        zero-extended to 32 channels), GroupNorm over 8-channel groups on
         the first U-Net level, the unfused hypothesis decoder.  Extra keywords:
         ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``

@@ -60,6 +60,10 @@ extern "C" {
  *   "gemm_round_rows" 0 auto | 32 | 64 | 128
  *   "gemm_pipe"       1 | 2 | 0  sparse convolutions on the loader / matrix pipeline kernel (2: its first version) | the rounds kernel;
  *                                bit-identical to each other and to the one-step kernel
+ *   "tail_streams"    1 .. 8     sub-batches of views in which the regulariser's layers behind conv0 run on concurrent side streams
+ *                                (forked from / joined into the caller's stream by events; same kernels, bit-identical results)
+ *   "tail_from" / "tail_to"      first / last step of that concurrent section: 1 conv1 + conv2, 3 .. 8 conv3 .. conv8, 9 conv9 + prob,
+ *                                10 soft-argmin
  * Unknown names -> V3D_ERR_BAD_ARG; an option this build cannot honour -> V3D_ERR_UNSUPPORTED. */
 int v3d_set_option(const char* name, int value);
 int v3d_get_option(const char* name, int* value);

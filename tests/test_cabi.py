@@ -80,14 +80,15 @@ def test_edges_to_csr_matches_unique_semantics():
 
 
 def test_pl3dvnet_default_construction_and_unsupported_feat_dim():
-    """The reference's default construction PL3DVNet(depth_train, depth_test, edge_len) works and builds the 32-channel
-    network its config and checkpoints use (mv3d/config.py:42); the reference's signature default feat_dim=16 builds the
-    narrower network (module shapes as lightningmodel.py:34-43 gives them); any other width is rejected at construction
-    time instead of failing on an assert deep inside SparseUNet."""
+    """The reference's default construction PL3DVNet(depth_train, depth_test, edge_len) builds what the reference's own
+    signature builds (lightningmodel.py:18: feat_dim=16, module shapes as :34-43 gives them); feat_dim=32 -- the value of
+    mv3d/config.py:42 and of the released checkpoints -- builds the network the fast kernels are specialised for; any other
+    width is rejected at construction time instead of failing on an assert deep inside SparseUNet."""
     lm = v3d('lightningmodel')
-    net = lm.PL3DVNet(None, {'size': (8, 8)}, 0.08)
+    net = lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=32)
     assert net.hparams.feat_dim == 32 and net.sparse_conv.dims == (64, 128, 128)
-    n16 = lm.PL3DVNet(None, {'size': (8, 8)}, 0.08, feat_dim=16)
+    n16 = lm.PL3DVNet(None, {'size': (8, 8)}, 0.08)
+    assert n16.hparams.feat_dim == 16
     assert n16.sparse_conv.dims == (32, 128, 128) and n16.mvsnet.cnn_3d.conv0.conv.in_channels == 16
     assert n16.decoder.in_dim == 128 + 128 + 48 and n16.refine_half.in_dim == 17
     with pytest.raises(ValueError, match='feat_dim'):
