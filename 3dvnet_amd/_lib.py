@@ -155,9 +155,14 @@ def load():
     _lib = lib
     # developer convenience (scripts/): V3D_OPTIONS="name=value,name=value" -> v3d_set_option once at load time.  (The library
     # itself reads no environment variable.)
+    # Every option applied this way is announced on stderr: a stray setting (stop_after, c12_march = 0 ...) changes results
+    # or speed of everything the process runs afterwards.
     for item in filter(None, os.environ.get('V3D_OPTIONS', '').split(',')):
         name, _, val = item.partition('=')
         check(lib.v3d_set_option(name.strip().encode(), int(val)), 'v3d_set_option(%s)' % item)
+        import warnings
+        warnings.warn('3dvnet_amd: developer option %s = %d applied from the V3D_OPTIONS environment variable'
+                      % (name.strip(), int(val)), RuntimeWarning, stacklevel=2)
     return lib
 
 

@@ -146,15 +146,16 @@ def _fold(conv, bn):
 class _Gemm:
     """A packed 1x1 / 3x3 convolution (v3d_conv_pack): weight [Cout, Cin, kh, kw] + bias."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, device):
         lib = _lib.load()
         co, ci, kh, kw = weight.shape
         self.taps, self.cin, self.cout = kh * kw, ci, co
         w = weight.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).float().contiguous().cpu()
         b = bias.float().contiguous().cpu()
         self.handle = ctypes.c_void_p()
-        _lib.check(lib.v3d_conv_pack(ctypes.cast(w.data_ptr(), _lib.c_float_p), ctypes.cast(b.data_ptr(), _lib.c_float_p),
-                                     co, kh * kw * ci, ctypes.byref(self.handle)), 'v3d_conv_pack')
+        with torch.cuda.device(device):          # the library allocates the weight image on the CURRENT device
+            _lib.check(lib.v3d_conv_pack(ctypes.cast(w.data_ptr(), _lib.c_float_p), ctypes.cast(b.data_ptr(), _lib.c_float_p),
+                                         co, kh * kw * ci, ctypes.byref(self.handle)), 'v3d_conv_pack')
 
     def __del__(self):
         try:       # (at interpreter shutdown the binding module may already be gone: the process frees the image anyway)
@@ -191,19 +192,48 @@ class _Depthwise:
 class NativeBackbone:
     """``(feat_extractor, feat_shrinker)`` on the HIP kernels: ``forward(images [n, 3, H, W]) -> (half, quarter, eighth,
     sixteenth, thirtysecond)`` in the reference layout [n, feat_dim, h, w] -- what ``feat_shrinker(*feat_extractor(images))``
-    returns (mvsnet.py:66-73, 89-105).  H and W must be multiples of 32 (every pyramid level exactly half the previous one) and
-    ``feat_dim`` a multiple of 32; ``supports()`` says whether a call qualifies (the modules themselves are the fallback)."""
+    returns (mvsnet.py:66-73, 89-105).  H and W must be multiples of 8 (round 6: the reference's default 240 x 320 gives 15 x 20
+    and 8 x 10 maps at 1/16 and 1/32 -- odd sizes are handled by the strided kernels and by the FPN's nearest top-down
+    addition) and ``feat_dim`` a multiple of 32; ``why_not()`` names the reason when a call does not qualify."""
 
     def __init__(self, feat_extractor, feat_shrinker):
         self.fe, self.fs = feat_extractor, feat_shrinker
         self._key, self._ops = None, None
 
-    def supports(self, images):
+    # (the packed kernels' weight images are a cache: a copy of the owning MVSNet packs again)
+    def __deepcopy__(self, memo):
+        import copy
+        return NativeBackbone(copy.deepcopy(self.fe, memo), copy.deepcopy(self.fs, memo))
+
+    def __reduce__(self):
+        return (NativeBackbone, (self.fe, self.fs))
+
+    def is_package_pair(self):
+        """The two modules are this package's own containers (torchvision's module tree restated): the pair the kernels serve."""
+        return isinstance(self.fe, FeatureExtractor) and isinstance(self.fs, FeatureShrinker)
+
+    def why_not(self, images):
+        """None when the call qualifies for the HIP kernels, else the reason (MVSNet.forward raises with it)."""
         from .mvsnet import module_device
-        return (isinstance(self.fe, FeatureExtractor) and isinstance(self.fs, FeatureShrinker) and images.is_cuda
-                and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] % 32 == 0 and images.shape[3] % 32 == 0
-                and self.fs.fpn.layer_blocks[0].out_channels % 32 == 0 and not self.fe.training and not self.fs.training
-                and module_device(self.fe) == images.device)
+        if not self.is_package_pair():
+            return 'feat_extractor / feat_shrinker are not backbone.FeatureExtractor / FeatureShrinker'
+        if not images.is_cuda:
+            return 'images are not on a HIP device (there is no CPU path)'
+        if images.dim() != 4 or images.shape[1] != 3:
+            return 'images must be [n, 3, H, W], got %s' % (tuple(images.shape),)
+        if images.shape[2] % 8 or images.shape[3] % 8:
+            return 'image sides must be multiples of 8, got %d x %d' % (images.shape[2], images.shape[3])
+        if self.fs.fpn.layer_blocks[0].out_channels % 32:
+            return 'feat_dim must be a multiple of 32 (channel-last -> reference layout kernel), got %d' \
+                % self.fs.fpn.layer_blocks[0].out_channels
+        if self.fe.training or self.fs.training:
+            return 'the modules are in training mode (BatchNorm is folded with running statistics)'
+        if module_device(self.fe) != images.device or module_device(self.fs) != images.device:
+            return 'modules on %s / %s, images on %s' % (module_device(self.fe), module_device(self.fs), images.device)
+        return None
+
+    def supports(self, images):
+        return self.why_not(images) is None
 
     def _build(self, device):
         from .mvsnet import module_state_key
@@ -215,7 +245,7 @@ class NativeBackbone:
         ops = dict(stem_w=w0.permute(1, 2, 3, 0).reshape(27, 32).float().contiguous().to(device), stem_b=b0.float().contiguous().to(device))
         w1, b1 = _fold(l1[3], l1[4])
         ops['stem_dw'] = _Depthwise(w1, b1, 1, device)
-        ops['stem_pw'] = _Gemm(*_fold(l1[6], l1[7]))
+        ops['stem_pw'] = _Gemm(*_fold(l1[6], l1[7]), device)
         stages = []
         for layer in (self.fe.layer2, self.fe.layer3, self.fe.layer4, self.fe.layer5):
             blocks = []
@@ -223,13 +253,13 @@ class NativeBackbone:
                 for blk in stack:
                     L = blk.layers
                     wd, bd = _fold(L[3], L[4])
-                    blocks.append((_Gemm(*_fold(L[0], L[1])), _Depthwise(wd, bd, L[3].stride[0], device), _Gemm(*_fold(L[6], L[7])),
+                    blocks.append((_Gemm(*_fold(L[0], L[1]), device), _Depthwise(wd, bd, L[3].stride[0], device), _Gemm(*_fold(L[6], L[7]), device),
                                    blk.apply_residual))
             stages.append(blocks)
         ops['stages'] = stages
         fpn = self.fs.fpn
-        ops['inner'] = [_Gemm(m.weight.detach(), m.bias.detach()) for m in fpn.inner_blocks]
-        ops['outer'] = [_Gemm(m.weight.detach(), m.bias.detach()) for m in fpn.layer_blocks]
+        ops['inner'] = [_Gemm(m.weight.detach(), m.bias.detach(), device) for m in fpn.inner_blocks]
+        ops['outer'] = [_Gemm(m.weight.detach(), m.bias.detach(), device) for m in fpn.layer_blocks]
         self._key, self._ops = key, ops
         return ops
 

@@ -33,7 +33,7 @@ struct ConvParams {
   const float* x;        // [n, H, W, Cin]
   const float* wp;       // packed fragments
   const float* bias;     // [ncb * 32]
-  const float* res;      // residual: [n, H, W, Cout] (mode 1) or [n, H / 2, W / 2, Cout] (mode 2) or null
+  const float* res;      // residual: [n, H, W, Cout] (mode 1) or [n, ceil(H / 2), ceil(W / 2), Cout] (mode 2) or null
   float* out;            // [n, H, W, Cout]
   int n, H, W, cin, cout, ncb, nsteps, relu, res_mode;
   unsigned m_hw, m_w;    // v3d::magic_u32 of H * W and W (the upsampled residual's address: two divisions per element otherwise)
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
       else if (p.res_mode == 2) {
         const unsigned hw = (unsigned)(p.H * p.W), img = v3d::udiv_magic((unsigned)q, hw, p.m_hw), rem = (unsigned)q - img * hw;
         const unsigned y = v3d::udiv_magic(rem, (unsigned)p.W, p.m_w), x = rem - y * (unsigned)p.W;
-        v += p.res[((size_t)(img * (unsigned)(p.H >> 1) + (y >> 1)) * (unsigned)(p.W >> 1) + (x >> 1)) * p.cout + co];
+        // (the coarser map has ceil(H / 2) x ceil(W / 2) positions -- a stride-2 / pad k/2 convolution's output -- and nearest
+        // interpolation to H x W reads floor(y * ceil(H / 2) / H) = y >> 1 for even AND odd H: mvsnet.py:86-88, FPN top-down)
+        v += p.res[((size_t)(img * (unsigned)((p.H + 1) >> 1) + (y >> 1)) * (unsigned)((p.W + 1) >> 1) + (x >> 1)) * p.cout + co];
       }
       p.out[q * p.cout + co] = v;
     }
@@ -302,7 +304,6 @@ extern "C" int v3d_conv_nhwc_f32(const v3d_conv_weights* h, const float* x, int 
   V3D_REQUIRE((taps == 1 || taps == 9) && cin % 8 == 0 && taps * cin == h->k, V3D_ERR_BAD_SHAPE,
               "v3d_conv_nhwc_f32: taps=%d cin=%d against packed K=%d", taps, cin, h->k);
   V3D_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || res), V3D_ERR_BAD_ARG, "v3d_conv_nhwc_f32: residual mode %d", res_mode);
-  V3D_REQUIRE(res_mode != 2 || (H % 2 == 0 && W % 2 == 0), V3D_ERR_BAD_SHAPE, "v3d_conv_nhwc_f32: upsampled residual needs even H, W");
   V3D_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, V3D_ERR_BAD_ARG, "v3d_conv_nhwc_f32: x must be 16-byte aligned");
   const long long P = (long long)n * H * W;
   if (P == 0) return V3D_OK;

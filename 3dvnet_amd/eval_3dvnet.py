@@ -19,12 +19,29 @@ from .batch import Batch
 from . import utils
 from .mvsnet import edges_to_csr
 
-# Reference views per call (the reference: INIT_DEPTH_BATCH = 18, OFFSET_BATCH = 16, eval-3dvnet.py:12-14 -- sized for its GPU's
-# memory).  Results do not depend on the chunking (tests/test_driver.py), and on an MI355X both stages hold a whole 64-view scene
-# at once: 64 views per call is the batch the cost-volume kernels are tuned for (2.5 GB variance volume of 288 GB), and one
-# point-flow call per sweep fills the persistent decoder's tile walk evenly (24.5 tiles per CU instead of 4 x 6.1 -> 4 x 7).
-INIT_DEPTH_BATCH = 64
-OFFSET_BATCH = 64
+# Reference views per call.  The reference's values (eval-3dvnet.py:12-14: INIT_DEPTH_BATCH = 18, OFFSET_BATCH = 16, "change these
+# to scale eval script to your GPU") are the module defaults here too; results do not depend on the chunking
+# (tests/test_driver.py).  `auto_batches(device)` returns what an MI355X-class device should use instead: both stages hold a
+# whole 64-view scene at once (2.5 GB variance volume + regulariser workspace of 288 GB; 64 views per call is the batch the
+# cost-volume kernels are tuned for, and one point-flow call per sweep fills the persistent decoder's tile walk evenly) when
+# at least MI355X_BATCH_MIN_FREE bytes of device memory are free, else the reference's values.  `process_scene` takes
+# `init_depth_batch=None / offset_batch=None` to mean "auto"; bench.py and `pred_func` use that.
+INIT_DEPTH_BATCH = 18
+OFFSET_BATCH = 16
+MI355X_BATCH = 64
+MI355X_BATCH_MIN_FREE = 24 << 30
+
+
+def auto_batches(device):
+    """(init_depth_batch, offset_batch) for `device`: 64 / 64 on a HIP device with >= 24 GB free, else the reference's 18 / 16."""
+    device = torch.device(device)
+    if device.type == 'cuda' and torch.cuda.is_available():
+        free, _ = torch.cuda.mem_get_info(device)
+        if free >= MI355X_BATCH_MIN_FREE:
+            return MI355X_BATCH, MI355X_BATCH
+    return INIT_DEPTH_BATCH, OFFSET_BATCH
+
+
 DEPTH_CONFIG = {'depth_start': 0.5, 'depth_interval': 0.05, 'n_intervals': 96, 'size': (56, 56)}
 OFFSETS_LIST = [[0.05, 0.05, 0.025], [0.05, 0.05, 0.025]]
 
@@ -73,7 +90,7 @@ def gather_pointcloud(pts, pts_feat, pts_batch, sizes=None, group=None):
 
 
 def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, offsets_list=None,
-                  init_depth_batch=INIT_DEPTH_BATCH, offset_batch=OFFSET_BATCH, rank=0, world=1,
+                  init_depth_batch=None, offset_batch=None, rank=0, world=1,
                   group=None, gather_depth=True, upsample=False, init_depth_override=None):
     """Returns the refined depth maps [n_ref, h, w] (all views when gather_depth, else this rank's).
 
@@ -86,6 +103,10 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
     these (bench.py uses surface-like depths because random synthetic features give noise depths)."""
     depth_config = depth_config or DEPTH_CONFIG
     offsets_list = offsets_list or OFFSETS_LIST
+    if init_depth_batch is None or offset_batch is None:       # "auto": by the device's free memory (auto_batches)
+        auto_i, auto_o = auto_batches(device)
+        init_depth_batch = auto_i if init_depth_batch is None else init_depth_batch
+        offset_batch = auto_o if offset_batch is None else offset_batch
     if isinstance(n_src_on_either_side, (tuple, list)):
         k, ka = int(n_src_on_either_side[0]), int(n_src_on_either_side[1])
     else:
@@ -228,4 +249,29 @@ def process_scene(batch, net, n_src_on_either_side, device, depth_config=None, o
                                                    (net.refine_full, imgs)])
         if world > 1 and gather_depth:
             all_depth = all_gather_rows(all_depth, shard_rows, group)
+        # the back-projection's claim on its workspace (the channel-last copy of THIS scene's features, reused across the
+        # sweeps) ends with the scene: it would keep the feature tensor alive until the next call
+        ws = getattr(net, '_ws', None)
+        if ws is not None and hasattr(ws, 'tags'):
+            ws.tags.pop('bp', None)
         return all_depth
+
+
+def pred_func(batch, scene, dset, net):
+    """The reference's ``process_scene(batch, scene, dset, net)`` (mv3d/eval-3dvnet.py:26-129), i.e. the ``pred_func`` shape
+    ``mv3d/eval/main.py:59`` calls: ``depth_preds, init_prob, final_prob = pred_func(batch, scene, dset, net)``.  Returns
+    ``(all_depth.numpy() [n_ref, H, W], None, None)`` -- full-resolution depth maps after stage 3 (the reference always
+    upsamples, :101-125), on the host, as ``eval/main.py:62-75`` consumes them (K rescale from ``depth_preds.shape[-2:]``,
+    ``preds.npz``).  ``scene`` is unused here as in the reference; ``dset.n_src_on_either_side`` is the window (an int, or a
+    ``(before, after)`` pair for this package's one-sided windows); the device is the net's.  Depth / offset configuration:
+    ``net.hparams.depth_test`` when it carries the plane-sweep keys, else the script's DEPTH_CONFIG (eval-3dvnet.py:17-23)."""
+    try:
+        device = next(net.parameters()).device
+    except (AttributeError, StopIteration):      # a parameter-free stand-in (the oracle-backed net of the tests)
+        device = batch.rotmats.device
+    cfg = getattr(getattr(net, 'hparams', None), 'depth_test', None)
+    if not (isinstance(cfg, dict) and all(k in cfg for k in ('depth_start', 'depth_interval', 'n_intervals', 'size'))):
+        cfg = DEPTH_CONFIG
+    depth = process_scene(batch, net, dset.n_src_on_either_side, device, depth_config=cfg, offsets_list=OFFSETS_LIST,
+                          upsample=True)
+    return depth.detach().cpu().numpy(), None, None

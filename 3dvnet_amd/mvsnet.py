@@ -32,6 +32,13 @@ class _Workspace:
             self.tags.pop(name, None)
         return buf
 
+    # scratch is not state: a copied / unpickled module starts with empty buffers (and does not duplicate gigabytes of them)
+    def __deepcopy__(self, memo):
+        return _Workspace()
+
+    def __reduce__(self):
+        return (_Workspace, ())
+
 
 def _psv_kernel_option():
     v = ctypes.c_int(0)
@@ -154,6 +161,13 @@ class CostRegNet(nn.Module):
         if self._handle is not None:
             _lib.load().v3d_costreg_free(self._handle)
             self._handle = None
+
+    def __getstate__(self):
+        # the packed device image (a ctypes handle) is a cache, not state: copy.deepcopy / pickle carry the parameters only and
+        # the copy re-packs on its first forward
+        st = self.__dict__.copy()
+        st['_handle'], st['_packed_key'] = None, None
+        return st
 
     def __del__(self):
         try:
@@ -378,7 +392,7 @@ class MVSNet(nn.Module):
         self.img_size = img_size
         self.feat_extractor = feat_extractor
         self.feat_shrinker = feat_shrinker
-        self.native_backbone = True          # False: the backbone modules run as stock PyTorch modules (MIOpen)
+        self.native_backbone = True          # False (explicit opt-in): the package's backbone containers run as stock PyTorch modules (MIOpen)
         self._native_backbone = None
         self.cnn_3d = CostRegNet(feat_dim, 8, precision=precision)
         self._ws = _Workspace()
@@ -432,14 +446,22 @@ class MVSNet(nn.Module):
 
     def forward(self, batch, depth_start, depth_interval, n_planes, depth_img_size, n_ref=None):
         if self.feat_extractor is not None:
-            # the library's own backbone kernels when the call qualifies (our MnasNet + FPN containers on a HIP device, image
-            # sides multiples of 32); any other pair of modules runs as given
+            # The package's own MnasNet + FPN containers run on the library's backbone kernels (csrc/backbone.hip); a call that
+            # does not qualify RAISES -- there is no silent second backend.  The stock PyTorch modules (MIOpen / rocBLAS) are an
+            # explicit opt-in: `net.native_backbone = False`.  A foreign pair of modules (anything else the caller injected)
+            # is the caller's own code and runs as given.
             if getattr(self, '_native_backbone', None) is None or self._native_backbone.fe is not self.feat_extractor \
                     or self._native_backbone.fs is not self.feat_shrinker:
                 from .backbone import NativeBackbone
                 self._native_backbone = NativeBackbone(self.feat_extractor, self.feat_shrinker)
-            if self.native_backbone and self._native_backbone.supports(batch.images):
-                features_half, features_quarter, features_eighth, _, _ = self._native_backbone(batch.images)
+            nb = self._native_backbone
+            if self.native_backbone and nb.is_package_pair():
+                why = nb.why_not(batch.images)
+                if why is not None:
+                    raise _lib.V3DLibraryError('MVSNet.forward: the HIP backbone cannot take this call (%s); set '
+                                               '`native_backbone = False` on the MVSNet to run the stock PyTorch modules '
+                                               'explicitly' % why)
+                features_half, features_quarter, features_eighth, _, _ = nb(batch.images)
             else:
                 features_half, features_quarter, features_eighth, _, _ = \
                     self.feat_shrinker(*self.feat_extractor(batch.images))

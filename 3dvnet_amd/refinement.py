@@ -113,9 +113,13 @@ class HypothesisDecoder(nn.Module):
         """The fused kernel (v3d_decoder_fused_f32) covers the reference's configuration: three levels, 128 hidden
         channels, level / point-feature widths that are multiples of 32, at most 8 hypotheses, split-bf16 operands."""
         cf = 0 if pts_feat is None else pts_feat.shape[2]
+        # (the kernel's own limits, mirrored so that an oversized call takes the unfused chain instead of raising: level rows
+        # < 2^24 and < 2 GB of features per level -- 24-bit row indices / 32-bit byte offsets in the corner table; the number
+        # of points per call is not a limit: decode_fused splits calls of 2^24 (point, hypothesis) columns or more)
         return (self.fused and self.precision == 'split_bf16' and self.h_dim == 128 and len(xs) == 3 and pts.shape[1] <= 8
                 and cf % 16 == 0 and all(x['feats'].shape[1] % 16 == 0 for x in xs)
-                and sum(x['feats'].shape[1] for x in xs) + cf == self.in_dim)
+                and sum(x['feats'].shape[1] for x in xs) + cf == self.in_dim
+                and all(x['feats'].shape[0] < (1 << 24) and x['feats'].numel() * 4 < (1 << 31) for x in xs))
 
     def decode_fused(self, xs, pts, pts_feat, pts_batch, offset_vals=None, depth_inout=None):
         """Rows C2a + C2b (+ C3) in one kernel: interpolation, the three conv1d layers, head and softmax
@@ -133,6 +137,16 @@ class HypothesisDecoder(nn.Module):
         if pts_feat is not None:
             pts_feat = pts_feat.contiguous().float()
             cf = pts_feat.shape[2]
+        max_pts = ((1 << 24) - 1) // max(n_hyp, 1)          # v3d_decoder_fused_f32: n_pts * n_hyp < 2^24 per call
+        if n_pts > max_pts:
+            # points are independent: pieces of the (contiguous) arguments, the same bits as one call would give
+            outs = [self.decode_fused(xs, pts[s:s + max_pts], None if pts_feat is None else pts_feat[s:s + max_pts],
+                                      pts_batch[s:s + max_pts], offset_vals,
+                                      None if depth_inout is None else depth_inout.view(-1)[s:s + max_pts])
+                    for s in range(0, n_pts, max_pts)]
+            if offset_vals is None:
+                return torch.cat(outs, dim=0)
+            return torch.cat([o[0] for o in outs], dim=0), torch.cat([o[1] for o in outs], dim=0)
         keep = []
         levels = list(xs)[::-1]                      # xs is coarse -> fine; feature rows are finest first (:41)
         for x in levels:

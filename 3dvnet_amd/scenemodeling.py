@@ -103,6 +103,15 @@ class _PackCache:
             self._packs, self._key = builder(), key
         return self._packs
 
+    # the packed images (ctypes handles) are a cache, not state: a deep copy / an unpickled object belongs to the COPIED module
+    # and packs again on first use
+    def __deepcopy__(self, memo):
+        import copy
+        return _PackCache(copy.deepcopy(self._module, memo))
+
+    def __reduce__(self):
+        return (_PackCache, (self._module,))
+
 
 class PointNet(nn.Module):
     """Reference ``PointNet(hidden_dim, out_dim, in_dim=3)`` (scenemodeling.py:116-144):
@@ -258,8 +267,36 @@ class LevelInfo(dict):
     def __contains__(self, key):
         return key in self._LAZY or super().__contains__(key)
 
+    # Every view of the WHOLE dict materialises the lazy keys first, so that the object behaves like the reference's plain
+    # seven-key dict for callers that copy or move a level (`{k: v.cpu() for k, v in x.items()}`, `dict(x)`, `x.get('pts')`).
+    def _materialise(self):
+        for k in self._LAZY:
+            if not super().__contains__(k):
+                self[k]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
     def keys(self):
-        return list(super().keys()) + [k for k in self._LAZY if not super().__contains__(k)]
+        self._materialise()
+        return super().keys()
+
+    def items(self):
+        self._materialise()
+        return super().items()
+
+    def values(self):
+        self._materialise()
+        return super().values()
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return dict.__len__(self) + sum(1 for k in self._LAZY if not dict.__contains__(self, k))
+
+    def copy(self):
+        return dict(self.items())
 
 
 class SparseUNet(nn.Module):

@@ -71,6 +71,11 @@ class PropagationNet(nn.Module):
             _lib.load().v3d_propagation_free(self._handle)
             self._handle = None
 
+    def __getstate__(self):      # (as CostRegNet: the packed image is a cache; a copy re-packs)
+        st = self.__dict__.copy()
+        st['_handle'], st['_packed_key'] = None, None
+        return st
+
     def __del__(self):
         try:
             self.release()

@@ -390,6 +390,9 @@ def bench_costvolume(args, rank, world, dev, dist):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE,
         'data': 'synthetic',
         'config': {'workload': workload, 'refs_per_step_per_gpu': refs, 'n_img_per_gpu': inp['n_img'],
+                   # (the reference's arithmetic type beside the headline, inside `config` so that a record that keeps only the
+                   # contract's keys still carries the VALUES: exact-fp32 MFMA operands, `value` uses split-bf16 x 3)
+                   'value_fp32_exact': value32, 'ms_per_step_fp32_exact': elapsed32 / args.steps * 1e3,
                    'edges_per_ref': e,
                    'parallelism': 'ref-view sharding, no collective' if world > 1 else 'single GPU',
                    'launch': launch_mode,
@@ -437,19 +440,27 @@ def bench_scene(args, rank, world, dev, dist):
     gt = gt.to(dev)
     sds = dict(cr=syn.costregnet_weights(seed=0, sharpen=200.0), pn=syn.pointnet_weights(), un=syn.sparse_unet_weights(),
                dec=syn.decoder_weights(sharpen=50.0))
-    net = lm.PL3DVNet(None, drv.DEPTH_CONFIG, cfg['edge_len'], feat_dim=32, img_size=cfg['img_size']).eval()
-    net.mvsnet.cnn_3d.load_state_dict(sds['cr'], strict=False)
-    net.pointnet.load_state_dict(sds['pn'])
-    net.sparse_conv.load_state_dict(sds['un'])
-    net.decoder.load_state_dict(sds['dec'], strict=False)
     sds_prop = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
-    for m, sdp in zip((net.refine_quarter, net.refine_half, net.refine_full), sds_prop):
-        m.load_state_dict(sdp, strict=False)
-    net = net.to(dev)
+
+    def make_net(precision):
+        n_ = lm.PL3DVNet(None, drv.DEPTH_CONFIG, cfg['edge_len'], feat_dim=32, img_size=cfg['img_size'], precision=precision).eval()
+        n_.mvsnet.cnn_3d.load_state_dict(sds['cr'], strict=False)
+        n_.pointnet.load_state_dict(sds['pn'])
+        n_.sparse_conv.load_state_dict(sds['un'])
+        n_.decoder.load_state_dict(sds['dec'], strict=False)
+        for m, sdp in zip((n_.refine_quarter, n_.refine_half, n_.refine_full), sds_prop):
+            m.load_state_dict(sdp, strict=False)
+        return n_.to(dev)
+    net = make_net('split_bf16')
+    # the reference's arithmetic type: every matrix-core kernel of stages 1 and 2 on exact-fp32 operands
+    # (cost volume: the fp32 chain of cfg2; PointNet / sparse U-Net: v3d_gemm_gather_f32 with V3D_PRECISION_FP32; hypothesis
+    # decoder: the unfused interpolation + conv1d chain on fp32 operands -- the fused kernel is split-bf16 only).  Stage 3's
+    # PropagationNets have no exact-fp32 variant: with --stage3 the figure is "stages 1-2 exact fp32, stage 3 split-bf16".
+    net32 = make_net('fp32') if getattr(args, 'fp32_exact', True) else None
     group = None
 
-    def step():
-        return drv.process_scene(b, net, win, dev, rank=rank, world=world, group=group, gather_depth=False,
+    def step(n_=None):
+        return drv.process_scene(b, n_ or net, win, dev, rank=rank, world=world, group=group, gather_depth=False,
                                  init_depth_override=gt, upsample=stage3)
 
     def fence():
@@ -472,6 +483,22 @@ def bench_scene(args, rank, world, dev, dist):
         elapsed = float(tt.item())
     assert torch.isfinite(d).all()
     value = refs * args.steps / elapsed
+    value32 = ms32 = None
+    if net32 is not None:
+        steps32 = max(2, args.steps // 2)
+        step(net32)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps32):
+            d32 = step(net32)
+        fence()
+        e32 = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([e32], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e32 = float(tt.item())
+        assert torch.isfinite(d32).all()
+        value32, ms32 = refs * steps32 / e32, e32 / steps32 * 1e3
     n_seen = ranks_seen(args, world, dev, dist)
     # the one collective of the path: the all-gather of the feature-rich point cloud, once per outer iteration -- its
     # payload and its time on this machine, measured on tensors of the scene's shapes between barriers
@@ -554,7 +581,7 @@ def bench_scene(args, rank, world, dev, dist):
             # the sparse U-Net's global receptive field turns that into centimetres for thousands of pixels -- in the reference
             # as much as here; at 8 views (25 088 points) every seed tried has 1-3 of them.
             d_free = drv.process_scene(bs, net, win, dev, init_depth_override=gts.to(dev)).cpu()
-            state, errs, t_w, hip_after0, cpu_after0 = gts, [], 0.0, None, None
+            state, errs, errs32, t_w, hip_after0, cpu_after0 = gts, [], [], 0.0, None, None
             # (the oracle's chain depends on the scene, the weights and the window only: the default bench line runs this leg for
             # cfg3 and again for cfg3 + stage 3 -- the second run takes the first one's oracle depths and its timing)
             memo_key = (n_chk, 77, win, cfg['edge_len'])
@@ -569,9 +596,13 @@ def bench_scene(args, rank, world, dev, dist):
                     _ORACLE_CHAIN.setdefault(memo_key, {'states': [], 't_w': 0.0})['states'].append(nxt)
                 t_w += time.perf_counter() - tp
                 errs.append(float(((d_it - nxt).abs() / nxt).max()))
+                if net32 is not None:      # the same teacher-forced iteration on exact-fp32 operands
+                    d32 = drv.process_scene(bs, net32, win, dev, init_depth_override=state.to(dev), offsets_list=[offs]).cpu()
+                    errs32.append(float(((d32 - nxt).abs() / nxt).max()))
                 if it == 0:
                     hip_after0, cpu_after0 = d_it, nxt
                 state = nxt
+            oracle_states = [gts] + list(_ORACLE_CHAIN[memo_key]['states'])
             if memo is not None:
                 t_w = memo['t_w']
             else:
@@ -584,6 +615,26 @@ def bench_scene(args, rank, world, dev, dist):
             p_cpu = osc.feature_rich_pointcloud(cpu_after0, zb, bs.features_quarter, bs.rotmats, bs.tvecs, bs.K, e_chk,
                                                 cfg['img_size'], pinned=True)[0]
             flips = int((cell_ids(p_hip) != cell_ids(p_cpu)).any(dim=1).sum())
+
+            def free_run_stats(n_):
+                """The FREE-RUNNING chain of net n_ (every outer iteration from its own depths) against the oracle's free-running
+                chain: points in different voxel cells at the start of every outer iteration, and the final depths' max / median
+                relative difference and the fraction of pixels within the 1e-4 gate."""
+                cur, flips_it = gts, []
+                for it, offs in enumerate(drv.OFFSETS_LIST):
+                    ph = n_.construct_feature_rich_pointcloud(cur.to(dev), zb.to(dev), bs.features_quarter.to(dev), bs.rotmats.to(dev),
+                                                              bs.tvecs.to(dev), bs.K.to(dev), e_chk.to(dev))[0]
+                    pc = osc.feature_rich_pointcloud(oracle_states[it], zb, bs.features_quarter, bs.rotmats, bs.tvecs, bs.K, e_chk,
+                                                     cfg['img_size'], pinned=True)[0]
+                    flips_it.append(int((cell_ids(ph) != cell_ids(pc)).any(dim=1).sum()))
+                    cur = drv.process_scene(bs, n_, win, dev, init_depth_override=cur.to(dev), offsets_list=[offs]).cpu()
+                rel = ((cur - oracle_states[-1]).abs() / oracle_states[-1]).flatten()
+                return dict(max_rel_depth_err_gpu_vs_cpu=float(rel.max()), median_rel_depth_err=float(rel.median()),
+                            fraction_of_pixels_within_1e_4=float((rel <= 1e-4).float().mean()),
+                            points_in_different_cells_per_outer_iteration=flips_it, pixels=int(rel.numel()))
+            want_free = getattr(args, 'free_stats', True)      # (the default line's cfg3 + stage 3 leg does not repeat them)
+            free_stats = free_run_stats(net) if want_free else None
+            free_stats32 = free_run_stats(net32) if want_free and net32 is not None else None
             # CPU baseline (SURVEY 8d protocol within a time budget): the chain above is one pass over the scene (it is also the
             # checker); as many further timed passes as fit ~20 s (at most 5), median; the sample string says what was run
             n_timed = min(5, int(20.0 / max(t_w, 1e-3))) if getattr(args, 'cpu_timing', True) else 0
@@ -624,9 +675,11 @@ def bench_scene(args, rank, world, dev, dist):
                       protocol='every outer iteration (scene model + 3 sweeps) from the oracle\'s depths at its start: identical '
                                'depths give bit-identical points, hence identical voxel cells; max over the iterations',
                       max_rel_depth_err_gpu_vs_cpu=max(errs + ([stage3_err] if stage3_err is not None else [])),
-                      per_outer_iteration=errs, stage3_from_the_oracles_depths=stage3_err,
+                      per_outer_iteration=errs, per_outer_iteration_fp32_exact=errs32 or None,
+                      max_rel_depth_err_gpu_fp32_exact_vs_cpu=max(errs32) if errs32 else None,
+                      stage3_from_the_oracles_depths=stage3_err,
                       free_running=dict(max_rel_depth_err_gpu_vs_cpu=free_err, points_in_different_cells_at_iteration_2=flips,
-                                        points=int(p_hip.shape[0]),
+                                        points=int(p_hip.shape[0]), stages_1_2=free_stats, stages_1_2_fp32_exact=free_stats32,
                                         note='free-running runs differ by <= 1e-5 m after the first iteration; a point that this '
                                              'moves across a cell face changes the voxel set, which the sparse U-Net\'s global '
                                              'receptive field amplifies to centimetres (discretisation of the algorithm, not '
@@ -641,9 +694,14 @@ def bench_scene(args, rank, world, dev, dist):
         'metric': 'depth maps/sec (256x320, 96 planes, full 3DVNet pipeline: cost volume + scene model + 2x3 sweeps%s)'
                   % (' + stage-3 upsampling to 256x320' if stage3 else ''),
         'value': value, 'unit': 'depth maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'ms_per_step': elapsed / args.steps * 1e3, 'value_fp32_exact': value32, 'ms_per_step_fp32_exact': ms32,
+        'higher_is_better': True,
         'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
-        'config': {'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, %d edges/ref (ref-%d .. ref+%d), '
+        'config': {'value_fp32_exact': value32, 'ms_per_step_fp32_exact': ms32,
+                   'fp32_exact_note': 'stages 1-2 on exact-fp32 matrix operands (the hypothesis decoder as its unfused chain)'
+                                      + ('; stage 3 (PropagationNet) has no exact-fp32 variant and runs split-bf16 in both figures'
+                                         if stage3 else ''),
+                   'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, %d edges/ref (ref-%d .. ref+%d), '
                                '96 planes, 56x56 plane grid, 4 cm voxels; stage A (timed) -> its depths replaced '
                                'by analytic wall depth + 2 cm noise -> 2 x (scene model + 3 point-flow sweeps)%s'
                                % (args.config, refs, nb + na + 1, nb, na,
@@ -683,8 +741,10 @@ def bench_backbone(dev, n_img=71, iters=10):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3, out
     with torch.no_grad():
-        ms_stock, out_s = timed(lambda: fs(*fe(imgs)))
+        ms_stock, out_s = timed(lambda: fs(*fe(imgs)))       # the explicit stock path (`native_backbone = False`): MIOpen / rocBLAS
         ms, out = timed(lambda: nat(imgs))
+        imgs240 = syn.make_images(n_img, (240, 320), seed=9).to(dev)      # the reference's default MVSNet(img_size=(240, 320))
+        ms240, _ = timed(lambda: nat(imgs240))
         libm.timing_enable(True)
         nat(imgs)
         torch.cuda.synchronize()
@@ -696,10 +756,10 @@ def bench_backbone(dev, n_img=71, iters=10):
                         'features: hand-written HIP kernels on channels-last fp32 activations, exact-fp32 matrix instructions'
                         % n_img, 'ms_per_batch': ms, 'images_per_s': n_img / ms * 1e3,
             'kernel_ms_per_batch': round(sum(v[0] for v in st.values()), 3), 'kernels': kern,
-            'stock_pytorch_miopen_ms_per_batch': ms_stock,
+            'ms_per_batch_240x320': ms240, 'stock_pytorch_miopen_ms_per_batch': ms_stock,
             'max_diff_vs_stock_modules_of_range': agree, 'quarter_features': list(out[1].shape),
-            'note': 'parity with torchvision unpinned (absent here); tests/test_backbone.py pins the kernels against the restated '
-                    'modules on the CPU'}
+            'note': 'parity with torchvision unpinned (absent here); tests/test_backbone.py pins the kernels against oracle/backbone.py '
+                    'on the CPU (256x320, 240x320, 248x328)'}
 
 
 def compact(line):
@@ -717,7 +777,10 @@ def compact(line):
                                         'max_rel_depth_err_gpu_vs_host_blas_oracle',
                                         'max_rel_depth_err_gpu_fp32_exact_vs_host_blas_oracle', 'host_blas_checked_views',
                                         'max_rel_depth_spread_pinned_vs_host_blas_oracle', 'max_abs_refinement_m', 'protocol',
-                                        'per_outer_iteration', 'stage3_from_the_oracles_depths', 'free_running') if k in cb}
+                                        'per_outer_iteration', 'per_outer_iteration_fp32_exact', 'stage3_from_the_oracles_depths',
+                                        'free_running') if k in cb}
+    if line['config'].get('fp32_exact_note'):
+        out['fp32_exact_note'] = line['config']['fp32_exact_note']
     if line.get('cpu_baseline') and line.get('parity'):
         out['cpu_baseline'] = line['cpu_baseline']
     top = sorted(line.get('kernels', {}).items(), key=lambda kv: -kv[1].get('share', 0))[:4]
@@ -897,7 +960,7 @@ def main():
             t_leg = time.perf_counter()
             # ... and the same scene with stage 3 (full-resolution output): BASELINE config 3's "Full 3DVNet" end to end
             a3f = copy.copy(a3)
-            a3f.stage3, a3f.steps, a3f.cpu_timing = True, min(args.steps, 10), False
+            a3f.stage3, a3f.steps, a3f.cpu_timing, a3f.free_stats = True, min(args.steps, 10), False, False
             line3f = bench_scene(a3f, rank, world, dev, dist)
             extra['cfg3_full'] = compact(line3f)
             extra['cfg3_full']['stage3'] = line3f.get('stage3')
@@ -912,6 +975,10 @@ def main():
                                         unit='depth maps/s', note='backbone on 71 images (64 reference views + 7 halo images) + '
                                         'the timed cost-volume step; sum of the two separately timed stages')
             line['extra'] = extra
+            # the other configurations' figures also INSIDE `config` (a record that keeps the contract's keys keeps these values)
+            line['config']['other_configs'] = {
+                k: {kk: extra[k].get(kk) for kk in ('value', 'ms_per_step', 'value_fp32_exact', 'ms_per_step_fp32_exact', 'unit')}
+                for k in ('cfg5', 'cfg3', 'cfg3_full', 'from_images')}
             line['config']['multi_gpu_note'] = ('`--gpus N` at this configuration runs N communication-free replicas (weak '
                                                 'scaling: reference views are independent units); the communicating mode is '
                                                 '`--config cfg4 --gpus N` (one scene sharded by reference view, one RCCL '

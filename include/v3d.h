@@ -399,7 +399,7 @@ int v3d_decoder_fused_f32(const v3d_gemm_weights* const* layers_host, const floa
  *   v3d_conv_pack        HOST weight [Cout, K], K = taps * Cin in (tap, channel) order (Conv2d weight permuted to
  *                        [Cout, kh, kw, Cin]), bias [Cout] or NULL -> handle (exact-fp32 MFMA fragments)
  *   v3d_conv_nhwc_f32    1x1 (taps 1) or 3x3 / pad 1 (taps 9) convolution + bias (+ ReLU) (+ residual: res_mode 1 = res
- *                        [n, H, W, Cout]; 2 = nearest-upsampled res [n, H/2, W/2, Cout], the FPN's top-down addition)
+ *                        [n, H, W, Cout]; 2 = nearest-upsampled res [n, ceil(H/2), ceil(W/2), Cout], the FPN's top-down addition; odd H, W allowed)
  *   v3d_depthwise_nhwc_f32  k x k (3 | 5) depthwise, pad k/2, stride 1 | 2, DEVICE w [k*k][C], bias [C] -> [n, ceil(H/s), ceil(W/s), C]
  *   v3d_stem_f32         Conv2d(3 -> 32, k3, s2, p1) + bias + ReLU from the NCHW image; DEVICE w [27][32] ((c, ky, kx) major)
  *   v3d_nhwc_to_nchw_f32 [n, HW, C] -> [n, C, HW] (C a multiple of 32): the layout the cost-volume entry points take

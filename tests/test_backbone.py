@@ -67,9 +67,46 @@ def test_shrinker_is_a_top_down_pyramid():
     assert float(quarter.std()) > 1e-3 and torch.isfinite(quarter).all()
 
 
+def test_oracle_restatement_equals_the_containers_stock_forward():
+    """oracle/backbone.py (functional, from state dicts) against the product's parameter containers run as stock PyTorch
+    modules -- the explicit `native_backbone = False` path -- at the cfg2 size and at the reference's default 240 x 320
+    (odd 15 x 20 and 8 x 10 pyramid levels): the same convolutions in the same order, equal to the last bit on one host."""
+    from oracle import backbone as ob
+    bb, syn = v3d('backbone'), v3d('synthetic')
+    fe, fs = bb.build_backbone(32)
+    sd_e, sd_s = syn.backbone_weights(32, seed=6)
+    assert not fe.load_state_dict(sd_e, strict=False).unexpected_keys
+    fs.load_state_dict(sd_s)
+    for size in ((64, 96), (240, 320)):
+        img = syn.make_images(2, size, seed=3)
+        with torch.no_grad():
+            want = fs(*fe(img))
+        got = ob.backbone_features(fe.state_dict(), fs.state_dict(), img)
+        assert [tuple(g.shape) for g in got] == [tuple(w.shape) for w in want]
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+    assert tuple(got[3].shape[2:]) == (15, 20) and tuple(got[4].shape[2:]) == (8, 10)
+
+
+def test_package_backbone_has_no_silent_stock_path():
+    """MVSNet.forward with the package's own containers raises when the HIP backbone cannot take the call (here: CPU
+    tensors) instead of running the stock modules; `native_backbone = False` is the explicit opt-in."""
+    bb, syn, mvs = v3d('backbone'), v3d('synthetic'), v3d('mvsnet')
+    Batch = v3d('batch').Batch
+    fe, fs = bb.build_backbone(32)
+    net = mvs.MVSNet(32, (64, 96), fe, fs).eval()
+    edges, n_img = syn.make_edges(1, 1, 1)
+    R, tv, K = syn.make_cameras(n_img, (64, 96), seed=5)
+    b = Batch(syn.make_images(n_img, (64, 96), seed=2), R, tv, K, None, edges)
+    with pytest.raises(v3d('_lib').V3DLibraryError, match='native_backbone = False'):
+        net(b, 0.5, 0.05, 8, (16, 24))
+    nb = bb.NativeBackbone(fe, fs)
+    assert nb.is_package_pair() and 'HIP device' in nb.why_not(b.images)
+    assert not bb.NativeBackbone(torch.nn.Identity(), fs).is_package_pair()
+
+
 @pytest.mark.gpu
 def test_mvsnet_forward_from_images(cuda):
-    """MVSNet.forward(batch.images) end to end (mvsnet.py:176-229): backbone on MIOpen -> HIP cost volume; the depth must
+    """MVSNet.forward(batch.images) end to end (mvsnet.py:176-229): HIP backbone -> HIP cost volume; the depth must
     equal the cost-volume path fed with the same quarter features, and match the oracle run on those features."""
     import numpy as np
     from oracle import costvolume as ocv
@@ -133,45 +170,51 @@ def test_backbone_device_arithmetic_matches_cpu(cuda):
 
 
 @pytest.mark.gpu
-def test_native_backbone_matches_the_modules_on_the_cpu(cuda):
+def test_native_backbone_matches_the_oracle(cuda):
     """csrc/backbone.hip through ``NativeBackbone`` (stem, depthwise and conv-as-GEMM kernels on channels-last activations,
-    BatchNorm folded, residuals in the epilogues) against the restated PyTorch modules on the CPU: all five pyramid outputs
-    within 2e-5 of their range at the cfg2 image size (exact-fp32 products, other summation orders), for an odd batch size and
-    for a second image size; and ``MVSNet.forward`` takes this path (equal features) unless ``native_backbone`` is switched off."""
+    BatchNorm folded, residuals in the epilogues) against oracle/backbone.py on the CPU: all five pyramid outputs within 2e-5
+    of their range at the cfg2 image size (exact-fp32 products, other summation orders), for an odd batch size, for a second
+    image size and for the reference's default 240 x 320 (MVSNet(img_size=(240, 320)), mvsnet.py:167: odd 15 x 20 / 8 x 10
+    levels); ``MVSNet.forward`` takes this path, and `native_backbone = False` (the explicit stock path) gives the same maps."""
+    from oracle import backbone as ob
     bb, syn, mvs = v3d('backbone'), v3d('synthetic'), v3d('mvsnet')
     fe, fs = bb.build_backbone(32)
     sd_e, sd_s = syn.backbone_weights(32, seed=6)
     assert not fe.load_state_dict(sd_e, strict=False).unexpected_keys
     fs.load_state_dict(sd_s)
-    fe, fs = fe.eval(), fs.eval()
-    for n, size, seed in ((3, (256, 320), 4), (2, (96, 160), 5)):
+    fe, fs = fe.eval().to(cuda), fs.eval().to(cuda)
+    nb = bb.NativeBackbone(fe, fs)
+    for n, size, seed in ((3, (256, 320), 4), (2, (96, 160), 5), (2, (240, 320), 6), (1, (248, 328), 7)):
         img = syn.make_images(n, size, seed=seed)
+        want = ob.backbone_features(fe.state_dict(), fs.state_dict(), img)
         with torch.no_grad():
-            want = fs(*fe(img))
-            fe_d, fs_d = fe.to(cuda), fs.to(cuda)
-            nb = bb.NativeBackbone(fe_d, fs_d)
-            assert nb.supports(img.to(cuda))
+            assert nb.why_not(img.to(cuda)) is None
             got = nb(img.to(cuda))
             got2 = nb(img.to(cuda))
-            fe.to('cpu'), fs.to('cpu')
         assert [tuple(o.shape) for o in got] == [tuple(o.shape) for o in want]
         for i, (a, b) in enumerate(zip(got, want)):
             scale = float(b.abs().max())
             assert scale > 1e-3 and torch.isfinite(a).all()
             err = float((a.cpu() - b).abs().max()) / scale
-            assert err < 2e-5, 'P%d at %s: native vs CPU modules %.2e of range' % (i + 1, size, err)
+            assert err < 2e-5, 'P%d at %s: native vs oracle %.2e of range' % (i + 1, size, err)
             assert torch.equal(a, got2[i])                      # deterministic
-    # not a multiple of 32: the modules run as given
-    assert not bb.NativeBackbone(fe.to(cuda), fs.to(cuda)).supports(torch.zeros(1, 3, 240, 320, device=cuda))
-    fe.to('cpu'), fs.to('cpu')
+    # sides that are not multiples of 8: a reason, not a silent second path
+    assert 'multiples of 8' in nb.why_not(torch.zeros(1, 3, 244, 320, device=cuda))
+    # the explicit stock path (MIOpen / rocBLAS) agrees with the kernels
+    with torch.no_grad():
+        stock = fs(*fe(img.to(cuda)))
+    for a, b in zip(got, stock):
+        assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max())
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('taps,cin,cout,H,W,res_mode', [(1, 16, 48, 24, 40, 0), (1, 72, 24, 17, 23, 1), (9, 32, 32, 24, 40, 0),
-                                                        (9, 40, 32, 16, 20, 2), (1, 24, 32, 64, 80, 2), (9, 8, 32, 9, 7, 0)])
+                                                        (9, 40, 32, 16, 20, 2), (1, 24, 32, 64, 80, 2), (9, 8, 32, 9, 7, 0), (1, 96, 32, 15, 20, 2),
+                                                        (9, 32, 32, 31, 41, 2)])
 def test_conv_entry_point_against_the_plain_convolution(taps, cin, cout, H, W, res_mode, cuda):
     """v3d_conv_nhwc_f32 through the C ABI against torch's conv2d on the CPU: channel counts that are not multiples of 32, the image
-    borders of the 3x3 taps, a ragged last row block, ReLU and both residual modes (same-resolution and 2x nearest-upsampled)."""
+    borders of the 3x3 taps, a ragged last row block, ReLU and both residual modes (same-resolution and nearest-upsampled from the
+    ceil(H / 2) x ceil(W / 2) map, even and odd sides)."""
     import ctypes
     libm = v3d('_lib')
     lib = libm.load()
@@ -185,9 +228,7 @@ def test_conv_entry_point_against_the_plain_convolution(taps, cin, cout, H, W, r
     if res_mode == 1:
         res = torch.randn(n, H, W, cout, generator=g).to(cuda)
     elif res_mode == 2:
-        res = torch.randn(n, H // 2, W // 2, cout, generator=g).to(cuda)
-    if res_mode == 2 and (H % 2 or W % 2):
-        pytest.skip('upsampled residual needs even sides')
+        res = torch.randn(n, (H + 1) // 2, (W + 1) // 2, cout, generator=g).to(cuda)      # a stride-2 map: ceil(H / 2) x ceil(W / 2)
     handle = ctypes.c_void_p()
     libm.check(lib.v3d_conv_pack(wk.numpy().ctypes.data_as(libm.c_float_p), bias.numpy().ctypes.data_as(libm.c_float_p), cout, taps * cin,
                                  ctypes.byref(handle)), 'v3d_conv_pack')
@@ -205,6 +246,6 @@ def test_conv_entry_point_against_the_plain_convolution(taps, cin, cout, H, W, r
     if res_mode == 1:
         ref = ref + res.cpu().permute(0, 3, 1, 2)
     elif res_mode == 2:
-        ref = ref + torch.nn.functional.interpolate(res.cpu().permute(0, 3, 1, 2), scale_factor=2, mode='nearest')
+        ref = ref + torch.nn.functional.interpolate(res.cpu().permute(0, 3, 1, 2), size=(H, W), mode='nearest')
     assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-5 * ref.abs().max()
 

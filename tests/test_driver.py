@@ -231,6 +231,35 @@ def test_hip_driver_matches_oracle_driver(cuda):
 
 
 @pytest.mark.gpu
+def test_deepcopy_and_pickle_of_a_net_after_a_forward(cuda):
+    """The packed weight images (ctypes handles), scratch workspaces and the native backbone's kernel handles are caches, not
+    state: ``copy.deepcopy`` and ``pickle`` of a net that has already run carry the parameters only, the copies' caches belong
+    to the copies, and they reproduce the original's depths bit for bit; the scene's feature tensor is released afterwards."""
+    import copy
+    import pickle
+    lm, drv = v3d('lightningmodel'), v3d('eval_3dvnet')
+    cr, pn, un, dec = weights()
+    net = lm.PL3DVNet(None, CFG, 0.16, feat_dim=32, img_size=IMG, backbone=True).eval()
+    net.mvsnet.cnn_3d.load_state_dict(cr, strict=False)
+    net.pointnet.load_state_dict(pn)
+    net.sparse_conv.load_state_dict(un)
+    net.decoder.load_state_dict(dec, strict=False)
+    net = net.to(cuda)
+    scene = make_scene()
+    scene.images = v3d('synthetic').make_images(scene.rotmats.shape[0], IMG, seed=3)
+    out = drv.process_scene(scene, net, 1, cuda, CFG, OFFSETS, 2, 3)
+    assert net.mvsnet.cnn_3d._handle is not None and net.sparse_conv._cache._packs is not None
+    assert net.mvsnet._native_backbone is not None and net._ws.tags.get('bp') is None
+    clones = [copy.deepcopy(net), pickle.loads(pickle.dumps(net))]
+    for c in clones:
+        assert c.mvsnet.cnn_3d._handle is None and c.sparse_conv._cache._packs is None
+        assert c.sparse_conv._cache._module is c.sparse_conv and c.decoder._cache._module is c.decoder
+        assert c.mvsnet._native_backbone.fe is c.mvsnet.feat_extractor
+        assert torch.equal(drv.process_scene(scene, c.to(cuda), 1, cuda, CFG, OFFSETS, 2, 3), out)
+    assert torch.equal(drv.process_scene(scene, net, 1, cuda, CFG, OFFSETS, 2, 3), out)      # the original is untouched
+
+
+@pytest.mark.gpu
 def test_hip_driver_feat_dim_16_matches_oracle_driver(cuda):
     """The reference's signature default feat_dim = 16 (lightningmodel.py:18): CostRegNet(16, 8) -- conv0 on the volume
     zero-extended to 32 channels (split-bf16) / the 16-channel exact-fp32 conv0 --, PointNet(64, 32, 19), SparseUNet((32, 128,
@@ -434,3 +463,46 @@ def test_bench_cfg4_dry_run_shards_a_scene_through_the_real_driver():
     assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2
     assert chk['shard_views'] == [3, 2] and chk['gathered_rows_per_outer_iteration'] == 5 * 16
     assert chk['depths_equal_closed_form'] is True
+
+
+def test_pred_func_adapter_has_the_reference_entry_shape():
+    """mv3d/eval-3dvnet.py:26,129 / mv3d/eval/main.py:59: ``depth_preds, init_prob, final_prob = pred_func(batch, scene, dset,
+    net)`` -- a host numpy array of full-resolution depth maps (stage 3 included) and two Nones.  Oracle-backed net on the CPU:
+    the adapter's result equals stages 1-2 of the driver followed by the oracle's stage-3 chain."""
+    import types
+    import torch.nn.functional as F
+    from oracle import scene as osc
+    syn, drv = v3d('synthetic'), v3d('eval_3dvnet')
+    scene = make_scene()
+    n_img = scene.rotmats.shape[0]
+    scene.features_half = syn.make_features(n_img, 32, 2 * FEAT[0], 2 * FEAT[1], seed=7)
+    scene.images = torch.rand((n_img, 3) + IMG, generator=torch.Generator().manual_seed(8))
+    sds = [syn.propagation_weights(33, 32, 5), syn.propagation_weights(33, 32, 6), syn.propagation_weights(4, 32, 7)]
+
+    class Net(OracleNet):
+        hparams = types.SimpleNamespace(depth_test=CFG)
+
+        def make_initial_depth_predictions(self, batch, cfg):
+            d, b, _, fq, _, ref_idx = super().make_initial_depth_predictions(batch, cfg)
+            return d, b, batch.features_half, fq, None, ref_idx
+
+    net = Net(*weights(), IMG, 0.16)
+    for name, sd in zip(('refine_quarter', 'refine_half', 'refine_full'), sds):
+        setattr(net, name, lambda f, d, sd=sd: osc.propagation_net(f, d, sd))
+    dset = types.SimpleNamespace(n_src_on_either_side=1)
+    out = drv.pred_func(scene, '/data/scene0000_00', dset, net)
+    assert isinstance(out, tuple) and len(out) == 3 and out[1] is None and out[2] is None
+    depth = out[0]
+    assert isinstance(depth, np.ndarray) and depth.dtype == np.float32 and depth.shape == (5,) + IMG
+    ref = drv.process_scene(scene, net, 1, torch.device('cpu'), CFG, drv.OFFSETS_LIST)
+    for sd, guide in zip(sds, (scene.features_quarter[1:6], scene.features_half[1:6], scene.images[1:6])):
+        ref = osc.propagation_net(guide, F.interpolate(ref.unsqueeze(1), guide.shape[-2:], mode='nearest'), sd)
+    np.testing.assert_allclose(depth, ref.numpy(), rtol=1e-5, atol=0)
+
+
+def test_batch_sizes_default_to_the_reference_and_auto_on_cpu():
+    """eval-3dvnet.py:12-13: INIT_DEPTH_BATCH = 18, OFFSET_BATCH = 16 are the module defaults; `auto_batches` only raises them
+    on a HIP device with enough free memory."""
+    drv = v3d('eval_3dvnet')
+    assert (drv.INIT_DEPTH_BATCH, drv.OFFSET_BATCH) == (18, 16)
+    assert drv.auto_batches(torch.device('cpu')) == (18, 16)

@@ -224,3 +224,20 @@ def test_traffic_json_aggregates_kernel_families(tmp_path):
     assert k['sparse_conv_gemm']['fetch_kb_raw'] == pytest.approx((20 * 10.0 + 10 * 40.0) / 30)
     assert k['propagation_conv']['fetch_kb_raw'] == 300.0 and k['costreg_conv4']['fetch_kb_raw'] == 7.0
 
+
+
+def test_level_info_behaves_like_the_plain_seven_key_dict():
+    """SparseUNet.forward returns one dict per level with keys feats, pts, res, batch, idx, stride, sparse (scenemodeling.py:
+    210-237); the package derives pts / idx / batch on first access, and every whole-dict view must see them."""
+    import types
+    sm = importlib.import_module('3dvnet_amd.scenemodeling')
+    lvl = types.SimpleNamespace(coords=torch.tensor([[0, 1, 2, 3], [0, 4, 5, 6]]))
+    x = sm.LevelInfo(lvl, 0.5, torch.tensor([[1., 2., 3.]]), torch.zeros(1, dtype=torch.long))
+    x['feats'], x['res'], x['stride'], x['sparse'] = torch.zeros(2, 4), 0.5, 1, lvl
+    want = ['batch', 'feats', 'idx', 'pts', 'res', 'sparse', 'stride']
+    assert len(x) == 7 and 'pts' in x and x.get('nope', 7) == 7
+    assert sorted(x.keys()) == want and sorted(dict(x)) == want and sorted({**x}) == want and sorted(x.copy()) == want
+    assert sorted(k for k in x) == want and sorted(k for k, _ in x.items()) == want and len(list(x.values())) == 7
+    assert torch.equal(x.get('pts'), torch.tensor([[1.5, 3., 4.5], [3., 4.5, 6.]])) and x['batch'].dtype == torch.long
+    moved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in x.items()}
+    assert torch.equal(moved['idx'], torch.tensor([[1, 2, 3], [4, 5, 6]]))
