@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRECISION = {'split_bf16': 0, 'fp32': 1}      # V3D_PRECISION_* of include/v3d.h
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     'v3d_propagation_free': (None, [c_void_p]),
     'v3d_propagation_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int, c_int]),
     'v3d_propagation_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'v3d_propagation_up_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     'v3d_backproject_workspace_bytes': (c_size_t, [c_int] * 4),
     'v3d_backproject_variance_f32': (c_int, [c_void_p] * 8 + [c_int] * 10 + [c_double, c_int] +
                                      [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

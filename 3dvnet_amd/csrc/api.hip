@@ -8,7 +8,7 @@
 
 #include "v3d_common.h"
 
-extern "C" int v3d_version(void) { return 4; }
+extern "C" int v3d_version(void) { return 5; }
 
 extern "C" const char* v3d_last_error(void) { return v3d::err_buf(); }
 
@@ -42,7 +42,7 @@ namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOptDefs[v3d::kOptCount] = {{"psv_kernel", 0}, {"psv_threads", 64}, {"c12_march", 1}, {"c12_nseg", 0}, {"c9_kernel", 0},
                                          {"conv_vec", 1}, {"stop_after", 99}, {"gemm_rounds", 1}, {"gemm_round_rows", 0},
-                                         {"gemm_pipe", 1}, {"tail_streams", 1}, {"tail_from", 3}, {"tail_to", 8}};
+                                         {"gemm_pipe", 1}, {"tail_streams", 1}, {"tail_from", 3}, {"tail_to", 8}, {"prop_fused", 1}};
 std::atomic<int> g_opt[v3d::kOptCount];
 std::atomic<bool> g_opt_init{false};
 void opt_init() {

@@ -61,6 +61,7 @@ enum Option {
   kOptTailStreams,     // "tail_streams": sub-batches of views the regulariser's layers behind conv0 run in, on concurrent side streams (1 = the caller's stream only)
   kOptTailFrom,        // "tail_from": first step of the concurrent section (1 conv1 + conv2, 3 .. 8 conv3 .. conv8, 9 conv9 + prob, 10 soft-argmin)
   kOptTailTo,          // "tail_to": last step of the concurrent section
+  kOptPropFused,       // "prop_fused": 1 PropagationNet as one row-marching kernel (propz.hip), 0 the per-layer kernels (encode + 4 conv + finish)
   kOptCount
 };
 int option(Option o);
@@ -239,6 +240,15 @@ int launch_conv9z(const void* u8_split, const void* c0_split, const float* wbf, 
 // -> conv2 output [n][2 groups][hi, lo][D2][H2][W2]; `w1` / `w2` = the split-bf16 images of conv1 / conv2 (costreg.hip, cgbf)
 int launch_conv12z(const void* c0_split, const float* w1, const float* w2, const float* b1, const float* b2, void* out_split,
                    int n, int D, int H, int W, hipStream_t s);
+
+// PropagationNet as one row-marching kernel (propz.hip, round 6): the fragment images of a layer (layer 0..3; `cinp` = padded input
+// channels of layer 0: 8 | 24 | 40) packed from BN-folded weights [cout][cin][3][3], and the launch.  `depth` is [B, h0, w0]; with
+// index tables iy [H] / ix [W] (device, may be null = identity with h0 == H, w0 == W) the nearest-neighbour resize of the depth
+// (eval-3dvnet.py:103,111,119) happens in the kernel's addressing.
+size_t propz_image_words(int layer, int cinp);
+void propz_pack_layer(int layer, int cinp, int cin, int cout, const float* w_folded, unsigned* out);
+int launch_propz(int cinp, const float* feat, const float* depth, const int* iy, const int* ix, float* out, const float* const w[4],
+                 const float* const bias[4], int B, int Cf, int H, int W, int h0, int w0, hipStream_t s);
 
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);

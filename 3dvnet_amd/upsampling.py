@@ -105,12 +105,53 @@ class PropagationNet(nn.Module):
             _lib.check(rc, 'v3d_propagation_f32')
         return out
 
+    def forward_resized(self, features, depth_lo):
+        """``forward(features, F.interpolate(depth_lo[:, None], features.shape[-2:], mode='nearest'))`` (eval-3dvnet.py:103-107)
+        in one launch: depth_lo [B, h0, w0] -> [B, H, W]; the resize is two index tables in the kernel's addressing."""
+        if not (features.is_cuda and depth_lo.is_cuda):
+            raise _lib.V3DLibraryError('PropagationNet: tensors must live on a HIP device (no CPU fallback)')
+        assert not self.training, 'inference only: BatchNorm is folded with running statistics'
+        lib = _lib.load()
+        dev = features.device
+        features = features.contiguous().float()
+        depth_lo = depth_lo.contiguous().float()
+        B, Cf, H, W = features.shape
+        h0, w0 = depth_lo.shape[-2:]
+        assert depth_lo.shape == (B, h0, w0) and Cf + 1 == self.in_dim, (tuple(depth_lo.shape), tuple(features.shape), self.in_dim)
+        iy, ix = nearest_tables((h0, w0), (H, W), dev)
+        out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        rc = lib.v3d_propagation_up_f32(self.packed_handle(dev), features.data_ptr(), depth_lo.data_ptr(), B, Cf, H, W, h0, w0,
+                                        iy.data_ptr(), ix.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev))
+        _lib.check(rc, 'v3d_propagation_up_f32')
+        return out
+
+
+_NEAREST_TABLES = {}
+
+
+def nearest_tables(src_size, dst_size, device):
+    """Source row / column of every output row / column of ``F.interpolate(x, dst_size, mode='nearest')`` for an input of
+    ``src_size`` -- taken from torch's own rule (an interpolated ``arange``), so the kernel-side resize is the framework's bit
+    for bit.  int32 tensors [H], [W] on ``device``, cached."""
+    key = (tuple(src_size), tuple(dst_size), str(device))
+    if key not in _NEAREST_TABLES:
+        def table(n_src, n_dst):
+            idx = torch.arange(n_src, dtype=torch.float32).view(1, 1, 1, n_src)
+            return F.interpolate(idx, size=(1, n_dst), mode='nearest').view(-1).to(torch.int32)
+        _NEAREST_TABLES[key] = (table(src_size[0], dst_size[0]).to(device), table(src_size[1], dst_size[1]).to(device))
+    return _NEAREST_TABLES[key]
+
 
 def upsample_depth(all_depth, stages, chunk=100):
     """Stage 3 of the scene driver (eval-3dvnet.py:101-125): for each (PropagationNet, guide tensor) pair,
-    nearest-neighbour resize the depth to the guide's resolution and refine it, `chunk` views at a time
-    (UPSAMPLE_BATCH = 100 in the reference)."""
+    nearest-neighbour resize the depth to the guide's resolution and refine it.  With the package's PropagationNet on a HIP device
+    the resize is folded into the kernel's addressing and a stage is ONE launch over all views (``forward_resized``; the
+    reference's UPSAMPLE_BATCH = 100 chunking is a memory limit of its unfold buffer, which does not exist here); any other
+    callable takes the reference's path, `chunk` views at a time."""
     for net, guide in stages:
+        if isinstance(net, PropagationNet) and all_depth.is_cuda and guide.is_cuda:
+            all_depth = net.forward_resized(guide, all_depth)
+            continue
         all_depth = F.interpolate(all_depth.unsqueeze(1), guide.shape[-2:], mode='nearest').squeeze(1)
         for s in range(0, all_depth.shape[0], chunk):
             all_depth[s:s + chunk] = net(guide[s:s + chunk], all_depth[s:s + chunk].unsqueeze(1))

@@ -541,14 +541,19 @@ def bench_scene(args, rank, world, dev, dist):
             H, W = cfg['img_size']
             per_px = lambda cin: 2.0 * 9 * (cin * 32 + 2 * 32 * 32 + 32 * 9)
             flops3 = (refs // world) * ((H // 4) * (W // 4) * per_px(33) + (H // 2) * (W // 2) * per_px(33) + H * W * per_px(4))
-            conv_ms = sum(ms for kk, (ms, _) in st.items() if kk.startswith('propagation_conv'))
+            fused = 'propagation_fused' in st       # round 6: one row-marching kernel per net (csrc/propz.hip)
+            conv_ms = sum(ms for kk, (ms, _) in st.items() if kk.startswith('propagation_fused' if fused else 'propagation_conv'))
             all_ms = sum(ms for kk, (ms, _) in st.items() if kk.startswith('propagation_'))
+            n_launch = sum(c for kk, (_, c) in st.items() if kk.startswith('propagation_fused' if fused else 'propagation_conv'))
             a3 = flops3 / (conv_ms * 1e-3) / 1e12
             stage3_info = dict(stage3_kernel_ms_per_scene=round(all_ms, 3), conv_kernel_ms_per_scene=round(conv_ms, 3),
                                roofline=dict(bound='mfma', achieved=a3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0, unit='TFLOP/s',
-                                             frac=a3 / (PEAK_BF16_MFMA_TFLOPS / 3.0), kernel='propagation_conv1..4 (all three '
-                                             'resolutions)', avg_ms=conv_ms / 12.0,
-                                             traffic=traffic_for('propagation_conv', refs, 'cfg3')))
+                                             frac=a3 / (PEAK_BF16_MFMA_TFLOPS / 3.0),
+                                             kernel=('propagation_fused (one row-marching kernel per net: 4 conv layers + softmax + '
+                                                     '3x3 propagation, nearest resize in the addressing; all three resolutions)'
+                                                     if fused else 'propagation_conv1..4 (all three resolutions)'),
+                                             avg_ms=conv_ms / max(n_launch, 1),
+                                             traffic=traffic_for('propagation_fused' if fused else 'propagation_conv', refs, 'cfg3')))
         if dom in ('conv1d_gemm', 'decoder_fused'):
             # decoder conv1d stack: 2*7*P*(3*352*128 + 2*3*128*128 + 3*128) FLOP per view per sweep, 6 sweeps
             P = drv.DEPTH_CONFIG['size'][0] * drv.DEPTH_CONFIG['size'][1]

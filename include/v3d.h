@@ -60,6 +60,7 @@ extern "C" {
  *   "gemm_round_rows" 0 auto | 32 | 64 | 128
  *   "gemm_pipe"       1 | 2 | 0  sparse convolutions on the loader / matrix pipeline kernel (2: its first version) | the rounds kernel;
  *                                bit-identical to each other and to the one-step kernel
+ *   "prop_fused"      1 | 0      PropagationNet as one row-marching kernel | the per-layer kernels (encode + 4 conv + finish)
  *   "tail_streams"    1 .. 8     sub-batches of views in which the regulariser's layers behind conv0 run on concurrent side streams
  *                                (forked from / joined into the caller's stream by events; same kernels, bit-identical results)
  *   "tail_from" / "tail_to"      first / last step of that concurrent section: 1 conv1 + conv2, 3 .. 8 conv3 .. conv8, 9 conv9 + prob,
@@ -366,6 +367,14 @@ void v3d_propagation_free(v3d_propagation_weights* handle);
 size_t v3d_propagation_workspace_bytes(const v3d_propagation_weights* handle, int B, int H, int W);
 int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* features, const float* depth, int B, int Cf,
                         int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same network with the nearest-neighbour resize that precedes every call of stage 3 (F.interpolate(depth, size, 'nearest'),
+ * mv3d/eval-3dvnet.py:103,111,119) folded into the kernel's addressing (ABI version 5): depth_lo [B, h0, w0] is the depth BEFORE
+ * the resize, iy [H] / ix [W] (DEVICE int32) the source row / column of every output row / column -- the caller obtains them
+ * from the host framework's own nearest rule; both NULL with h0 == H, w0 == W = no resize.  One row-marching kernel (csrc/propz.hip):
+ * the four layers' activations stay in LDS, no workspace.  v3d_propagation_f32 runs the same kernel (developer option
+ * "prop_fused" = 0: the per-layer kernels of round 4, other summation orders). */
+int v3d_propagation_up_f32(const v3d_propagation_weights* handle, const float* features, const float* depth_lo, int B, int Cf,
+                           int H, int W, int h0, int w0, const int32_t* iy, const int32_t* ix, float* out, void* stream);
 
 /* Rows C2a + C2b + C3 fused: MinkowskiInterpolation of the three U-Net levels at the hypothesis
  * points (mv3d/subnetworks/refinement.py:28-41) -> the three Conv1d+BN+ReLU layers along the hypothesis axis (:16-23) ->

@@ -213,6 +213,32 @@ def test_hip_propagation_net_matches_reference_golden_and_oracle_chain(cuda):
     assert torch.equal(out, whole)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=0)
     assert out.shape == (5, 60, 76)
+    # round 6 (csrc/propz.hip): a stage is ONE row-marching kernel with the nearest resize in its addressing.  (a) the folded
+    # resize equals torch's resize followed by forward(); (b) views are independent: any subset of the batch gives the same
+    # bits; (c) the per-layer kernels of round 4 (developer option prop_fused = 0: other summation orders) agree to 2e-5
+    libm = v3d('_lib')
+    with torch.no_grad():
+        d0 = depth.to(cuda)
+        for n, gd in zip(nets, guides):
+            gd = gd.to(cuda)
+            folded = n.forward_resized(gd, d0)
+            resized = F.interpolate(d0.unsqueeze(1), gd.shape[-2:], mode='nearest')
+            assert torch.equal(folded, n(gd, resized))
+            assert torch.equal(n.forward_resized(gd[1:4], d0[1:4]), folded[1:4])
+            old = libm.set_option('prop_fused', 0)
+            try:
+                per_layer = n(gd, resized)
+            finally:
+                libm.set_option('prop_fused', old)
+            np.testing.assert_allclose(folded.cpu().numpy(), per_layer.cpu().numpy(), rtol=2e-5, atol=0)
+            d0 = folded
+        assert torch.equal(d0, out)
+        # widths / heights that are not multiples of the 40-column strips, a single row, a single column strip of 3 columns
+        for (hh, ww) in ((1, 40), (3, 3), (17, 41), (9, 83)):
+            gd = torch.rand((2, 3, hh, ww), generator=gen)
+            dd = 1 + torch.rand((2, 1, hh, ww), generator=gen)
+            got = nets[2](gd.to(cuda), dd.to(cuda))
+            np.testing.assert_allclose(got.cpu().numpy(), osc.propagation_net(gd, dd, sds[2]).numpy(), rtol=2e-5, atol=0)
     assert float((ref - F.interpolate(depth.unsqueeze(1), (60, 76), mode='nearest')[:, 0]).abs().max()) > 1e-3    # it did something
     # feat_dim = 16 (the reference's signature default): 17 guide + depth channels
     sd17 = syn.propagation_weights(17, 32, 8)
