@@ -65,8 +65,8 @@ SIGNATURES = {
     'v3d_propagation_pack': (c_int, [c_float_pp] * 5 + [c_int, c_int, c_float, ctypes.POINTER(c_void_p)]),
     'v3d_propagation_free': (None, [c_void_p]),
     'v3d_propagation_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int, c_int]),
-    'v3d_propagation_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
-    'v3d_propagation_up_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'v3d_propagation_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'v3d_propagation_up_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'v3d_backproject_workspace_bytes': (c_size_t, [c_int] * 4),
     'v3d_backproject_variance_f32': (c_int, [c_void_p] * 8 + [c_int] * 10 + [c_double, c_int] +
                                      [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

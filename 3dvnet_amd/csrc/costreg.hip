@@ -2472,7 +2472,7 @@ struct v3d_propagation_weights {
   int in_dim, cinp;
   float* dev;
   size_t w_ofs[4], b_ofs[4], total;
-  size_t zw_ofs[4], zb_ofs[4];      // fragment images / padded biases of the row-marching kernel (propz.hip)
+  size_t zw_ofs[4], zb_ofs[4], zw32_ofs[4];      // split-bf16 / exact-fp32 fragment images and padded biases of the row-marching kernel (propz.hip)
 };
 
 namespace {
@@ -2583,7 +2583,9 @@ extern "C" int v3d_propagation_pack(const float* const* conv_weight_host, const 
     }
     h->zw_ofs[l] = reserve(v3d::propz_image_words(l, cinp));
     h->zb_ofs[l] = reserve(op);
-    v3d::propz_pack_layer(l, cinp, cin, cout, wf.data(), reinterpret_cast<unsigned*>(host.data() + h->zw_ofs[l]));
+    h->zw32_ofs[l] = reserve(v3d::propz_image_words(l, cinp));
+    v3d::propz_pack_layer(l, cinp, cin, cout, wf.data(), reinterpret_cast<unsigned*>(host.data() + h->zw_ofs[l]), false);
+    v3d::propz_pack_layer(l, cinp, cin, cout, wf.data(), reinterpret_cast<unsigned*>(host.data() + h->zw32_ofs[l]), true);
     for (int co = 0; co < cout; ++co) host[h->zb_ofs[l] + co] = host[h->b_ofs[l] + co];
   }
   h->total = host.size();
@@ -2609,27 +2611,35 @@ extern "C" size_t v3d_propagation_workspace_bytes(const v3d_propagation_weights*
 }
 
 extern "C" int v3d_propagation_up_f32(const v3d_propagation_weights* h, const float* features, const float* depth_lo, int B, int Cf,
-                                      int H, int W, int h0, int w0, const int32_t* iy, const int32_t* ix, float* out, void* stream) {
+                                      int H, int W, int h0, int w0, const int32_t* iy, const int32_t* ix, float* out, int precision,
+                                      void* stream) {
   V3D_REQUIRE(h && features && depth_lo && out, V3D_ERR_BAD_ARG, "v3d_propagation_up_f32: null argument");
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
+              "v3d_propagation_up_f32: unknown precision %d", precision);
   V3D_REQUIRE(B > 0 && H > 0 && W > 0 && h0 > 0 && w0 > 0 && Cf + 1 == h->in_dim, V3D_ERR_BAD_SHAPE,
               "v3d_propagation_up_f32: bad shape (B=%d, Cf=%d, H=%d, W=%d, depth %d x %d; packed for in_dim=%d)", B, Cf, H, W, h0, w0, h->in_dim);
   V3D_REQUIRE((iy && ix) || (!iy && !ix && h0 == H && w0 == W), V3D_ERR_BAD_ARG,
               "v3d_propagation_up_f32: both index tables, or none with a depth of the output size");
+  const bool f32 = precision == V3D_PRECISION_FP32;
   const float* w[4]; const float* b[4];
-  for (int l = 0; l < 4; ++l) { w[l] = h->dev + h->zw_ofs[l]; b[l] = h->dev + h->zb_ofs[l]; }
-  return v3d::launch_propz(h->cinp, features, depth_lo, iy, ix, out, w, b, B, Cf, H, W, h0, w0, (hipStream_t)stream);
+  for (int l = 0; l < 4; ++l) { w[l] = h->dev + (f32 ? h->zw32_ofs[l] : h->zw_ofs[l]); b[l] = h->dev + h->zb_ofs[l]; }
+  return v3d::launch_propz(h->cinp, f32, features, depth_lo, iy, ix, out, w, b, B, Cf, H, W, h0, w0, (hipStream_t)stream);
 }
 
 extern "C" int v3d_propagation_f32(const v3d_propagation_weights* h, const float* features, const float* depth, int B, int Cf,
-                                   int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int H, int W, float* out, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(h && features && depth && out && workspace, V3D_ERR_BAD_ARG, "v3d_propagation_f32: null argument");
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || precision == V3D_PRECISION_FP32, V3D_ERR_BAD_ARG,
+              "v3d_propagation_f32: unknown precision %d", precision);
+  V3D_REQUIRE(precision == V3D_PRECISION_SPLIT_BF16 || v3d::option(v3d::kOptPropFused) != 0, V3D_ERR_UNSUPPORTED,
+              "v3d_propagation_f32: the per-layer kernels (option prop_fused = 0) have split-bf16 operands only");
   V3D_REQUIRE(B > 0 && H > 0 && W > 0 && Cf + 1 == h->in_dim, V3D_ERR_BAD_SHAPE,
               "v3d_propagation_f32: bad shape (B=%d, Cf=%d, H=%d, W=%d; packed for in_dim=%d)", B, Cf, H, W, h->in_dim);
   V3D_REQUIRE(workspace_bytes >= v3d_propagation_workspace_bytes(h, B, H, W), V3D_ERR_WORKSPACE_TOO_SMALL,
               "v3d_propagation_f32: workspace %zu < %zu", workspace_bytes, v3d_propagation_workspace_bytes(h, B, H, W));
   hipStream_t s = (hipStream_t)stream;
   if (v3d::option(v3d::kOptPropFused) != 0)      // one row-marching kernel, no workspace traffic (propz.hip)
-    return v3d_propagation_up_f32(h, features, depth, B, Cf, H, W, H, W, nullptr, nullptr, out, stream);
+    return v3d_propagation_up_f32(h, features, depth, B, Cf, H, W, H, W, nullptr, nullptr, out, precision, stream);
   const size_t N = (size_t)B * H * W;
   V3D_REQUIRE(N * 5 < ((size_t)1 << 31) * 4, V3D_ERR_BAD_SHAPE, "v3d_propagation_f32: batch too large (chunk the views)");
   char* base = (char*)workspace;

@@ -85,14 +85,20 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 }
 
 // ---- matrix waves -------------------------------------------------------------------------------------------------------------
-template <int G, int LAYER>
+// F32 (V3D_PRECISION_FP32, the reference's arithmetic type): the same kernel on v_mfma_f32_16x16x4_f32 -- a pixel slot holds its
+// channels as fp32 (4 bytes per channel where the split layout has 2 + 2: the same 144 / PS0 bytes), the two 16-byte reads of a
+// lane are channels 8 q .. 8 q + 3 and 8 q + 4 .. 8 q + 7, the two fragment registers of a (K step, 16-row block) hold the
+// weights of k slices 0..3 and 4..7 (slice s multiplies channel 8 kq + s): eight exact-fp32 matrix instructions per (block, co
+// block, K step) where the split path has three bf16 ones -- same registers, same LDS, 5.3x the matrix time.
+template <int G, int LAYER, bool F32>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
   constexpr bool L1 = LAYER == 1;
   constexpr int KS = L1 ? Z::KS1 : 9, NCB = LAYER == 4 ? 1 : 2;
   constexpr int PSI = L1 ? Z::PS0 : kPS;                      // pixel stride / row bytes of the ring this layer reads
   constexpr int RBI = kPSL * PSI;
-  constexpr int LO = L1 ? 2 * Z::CIN1P : 64;                   // hi -> lo inside a pixel slot
+  constexpr int CGB = F32 ? 32 : 16;                          // bytes between the first reads of consecutive 8-channel groups
+  constexpr int LO = F32 ? 16 : L1 ? 2 * Z::CIN1P : 64;        // first -> second 16-byte read of a lane (hi -> lo / channels +4)
   constexpr int RIN = LAYER == 1 ? Z::RING0 : LAYER == 2 ? Z::RING1 : LAYER == 3 ? Z::RING2 : Z::RING3;
   constexpr int ROUT = LAYER == 1 ? Z::RING1 : LAYER == 2 ? Z::RING2 : Z::RING3;
   const int kq = lane >> 4, jn = lane & 15;
@@ -128,13 +134,13 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
     for (int ks = 0; ks < KS; ++ks) {
       const int k8 = ks * 4 + kq;
       const int tap = k8 / G < 9 ? k8 / G : 0, cg = k8 / G < 9 ? k8 % G : 0;
-      lofs[ks] = (unsigned)((jn + tap % 3) * PSI + cg * 16);
+      lofs[ks] = (unsigned)((jn + tap % 3) * PSI + cg * CGB);
       lky |= (unsigned)(tap / 3) << (2 * ks);
     }
   } else {
-    lofs[0] = (unsigned)(jn * PSI + kq * 16);
+    lofs[0] = (unsigned)(jn * PSI + kq * CGB);
   }
-  const unsigned wofs = (unsigned)((1 + jn) * kPS + 8 * kq);      // this lane's 8 output bytes (4 channels) inside block 0, co block 0
+  const unsigned wofs = (unsigned)((1 + jn) * kPS + (F32 ? 16 : 8) * kq);   // this lane's 4 output channels inside block 0, co block 0
 
   for (int item = item0; item < n_items; item += item_step) {
     const int b = item / p.nstrip, x0 = (item - b * p.nstrip) * kTWO;
@@ -176,6 +182,19 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
             if constexpr (LO_LDS) alo[cb] = reinterpret_cast<const u32x4*>(smem + Z::WLO)[(ks * NCB + cb) * 64 + lane];
             else alo[cb] = a[ks][cb][LO_LDS ? 0 : 1];
           }
+          if constexpr (F32) {
+            // eight k slices per (block, co block), round robin over the accumulators
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+              for (int blk = 0; blk < kNBLK; ++blk)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                  const float av = __uint_as_float(sl < 4 ? a[ks][cb][0][sl & 3] : alo[cb][sl & 3]);
+                  const float bv = __uint_as_float(sl < 4 ? __builtin_bit_cast(u32x4, bh[blk])[sl & 3] : __builtin_bit_cast(u32x4, bl[blk])[sl & 3]);
+                  acc[blk][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[blk][cb], 0, 0, 0);
+                }
+          } else {
           // three products per (block, co block), round robin over the accumulators (no back-to-back dependent pair)
 #pragma unroll
           for (int prod = 0; prod < 3; ++prod)
@@ -186,6 +205,7 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
                 const bf16x8 av = __builtin_bit_cast(bf16x8, prod == 2 ? alo[cb] : a[ks][cb][0]);
                 acc[blk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, prod == 1 ? bl[blk] : bh[blk], acc[blk][cb], 0, 0, 0);
               }
+          }
         }
         if constexpr (LAYER < 4) {
           // bias + ReLU, zero outside the image, hi / lo split -> this layer's ring: 4 channels = 8 bytes of hi, 8 of lo
@@ -197,10 +217,14 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
               float v[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[blk][cb][q] + bias[cb][q], 0.f) * colmask[blk];
-              u32x2 hp, lp;
-              pz_split4(v[0], v[1], v[2], v[3], hp, lp);
-              *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32) = hp;
-              *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32 + 64) = lp;
+              if constexpr (F32) {
+                *reinterpret_cast<f32x4*>(orow + blk * 16 * kPS + cb * 64) = (f32x4){v[0], v[1], v[2], v[3]};
+              } else {
+                u32x2 hp, lp;
+                pz_split4(v[0], v[1], v[2], v[3], hp, lp);
+                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32) = hp;
+                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32 + 64) = lp;
+              }
             }
         } else {
           // logits (ReLU'd, upsampling.py:6-11,21) -> the wave's scratch [column][12]; then one lane per column: softmax over 9
@@ -250,7 +274,7 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
 }
 
 // ---- helper waves: the input ring + the fp32 depth ring ---------------------------------------------------------------------------
-template <int G>
+template <int G, bool F32>
 __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned char* smem, int htid, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
   constexpr int NQ = Z::CIN1P / 4;                              // channel quads per pixel
@@ -299,10 +323,14 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
         const int task = htid + 256 * i;
         if (task < NTASK) {
           const int ps = task / NQ, q = task - ps * NQ;
-          u32x2 hp, lp;
-          pz_split4(val[i][0], val[i][1], val[i][2], val[i][3], hp, lp);
-          *reinterpret_cast<u32x2*>(row + ps * Z::PS0 + q * 8) = hp;
-          *reinterpret_cast<u32x2*>(row + ps * Z::PS0 + 2 * Z::CIN1P + q * 8) = lp;
+          if constexpr (F32) {
+            *reinterpret_cast<f32x4*>(row + ps * Z::PS0 + q * 16) = (f32x4){val[i][0], val[i][1], val[i][2], val[i][3]};
+          } else {
+            u32x2 hp, lp;
+            pz_split4(val[i][0], val[i][1], val[i][2], val[i][3], hp, lp);
+            *reinterpret_cast<u32x2*>(row + ps * Z::PS0 + q * 8) = hp;
+            *reinterpret_cast<u32x2*>(row + ps * Z::PS0 + 2 * Z::CIN1P + q * 8) = lp;
+          }
         }
       }
       if (htid < kPSL && y >= 0 && y < p.H) reinterpret_cast<float*>(smem + Z::DEPTH)[(y & (kDR - 1)) * kPSL + htid] = dval;
@@ -316,35 +344,35 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
   }
 }
 
-template <int G>
+template <int G, bool F32>
 __global__ __launch_bounds__(kThreads, 2) void propz_kernel(PropzParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_items = p.B * p.nstrip;
   const int item0 = (int)blockIdx.x, item_step = (int)gridDim.x;
-  if (wave == 0) pz_matrix_role<G, 1>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 1) pz_matrix_role<G, 2>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 2) pz_matrix_role<G, 3>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 3) pz_matrix_role<G, 4>(p, smem, lane, item0, item_step, n_items);
-  else pz_helper_role<G>(p, smem, tid - 256, item0, item_step, n_items);
+  if (wave == 0) pz_matrix_role<G, 1, F32>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 1) pz_matrix_role<G, 2, F32>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 2) pz_matrix_role<G, 3, F32>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 3) pz_matrix_role<G, 4, F32>(p, smem, lane, item0, item_step, n_items);
+  else pz_helper_role<G, F32>(p, smem, tid - 256, item0, item_step, n_items);
 }
 
-template <int G>
+template <int G, bool F32>
 int launch_g(const PropzParams& p, hipStream_t s) {
   static bool attr_set[64] = {false};      // per device: the dynamic-LDS opt-in is a per-device function attribute
   int dev = 0;
   V3D_CHECK_HIP(hipGetDevice(&dev));
   V3D_REQUIRE(dev >= 0 && dev < 64, V3D_ERR_UNSUPPORTED, "device ordinal %d", dev);
   if (!attr_set[dev]) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)propz_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PZ<G>::LDS));
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)propz_kernel<G, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PZ<G>::LDS));
     attr_set[dev] = true;
   }
   const long long items = (long long)p.B * p.nstrip;
   const unsigned grid = v3d::persistent_grid(items, 1);
   {
-    v3d::TimedScope ts("propagation_fused", s);
-    propz_kernel<G><<<grid, kThreads, PZ<G>::LDS, s>>>(p);
+    v3d::TimedScope ts(F32 ? "propagation_fused_f32" : "propagation_fused", s);
+    propz_kernel<G, F32><<<grid, kThreads, PZ<G>::LDS, s>>>(p);
   }
   V3D_CHECK_LAUNCH("propz_kernel");
   return V3D_OK;
@@ -361,7 +389,7 @@ size_t v3d::propz_image_words(int layer, int cinp) {
   return (size_t)ks * ncb * 2 * 64 * 4;
 }
 
-void v3d::propz_pack_layer(int layer, int cinp, int cin, int cout, const float* w_folded, unsigned* out) {
+void v3d::propz_pack_layer(int layer, int cinp, int cin, int cout, const float* w_folded, unsigned* out, bool f32) {
   const int G = cinp / 8, KS = layer == 0 ? (9 * G + 3) / 4 : 9, ncb = layer == 3 ? 1 : 2;
   auto rne = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
   auto up = [](unsigned hb) { unsigned u = hb << 16; float f; memcpy(&f, &u, 4); return f; };
@@ -378,25 +406,26 @@ void v3d::propz_pack_layer(int layer, int cinp, int cin, int cout, const float* 
           if (tap < 9 && co < cout && ci < cin) v = w_folded[((size_t)co * cin + ci) * 9 + tap];      // [cout][cin][ky][kx]
           hi[e] = rne(v);
           lo[e] = rne(v - up(hi[e]));
+          if (f32) memcpy(&hi[e], &v, 4);      // exact-fp32 image: part 0 = k slices 0..3, part 1 = 4..7 (slice e <-> channel 8 kq + e)
         }
         for (int part = 0; part < 2; ++part) {
           const unsigned* src = part ? lo : hi;
           unsigned* dst = out + ((((size_t)ks * ncb + cb) * 2 + part) * 64 + lane) * 4;
-          for (int q = 0; q < 4; ++q) dst[q] = src[2 * q] | (src[2 * q + 1] << 16);
+          for (int q = 0; q < 4; ++q) dst[q] = f32 ? hi[4 * part + q] : (src[2 * q] | (src[2 * q + 1] << 16));
         }
       }
 }
 
-int v3d::launch_propz(int cinp, const float* feat, const float* depth, const int* iy, const int* ix, float* out, const float* const w[4],
-                      const float* const bias[4], int B, int Cf, int H, int W, int h0, int w0, hipStream_t s) {
+int v3d::launch_propz(int cinp, bool f32, const float* feat, const float* depth, const int* iy, const int* ix, float* out,
+                      const float* const w[4], const float* const bias[4], int B, int Cf, int H, int W, int h0, int w0, hipStream_t s) {
   PropzParams p;
   p.feat = feat; p.depth = depth; p.iy = iy; p.ix = ix; p.out = out;
   for (int l = 0; l < 4; ++l) { p.w[l] = reinterpret_cast<const u32x4*>(w[l]); p.bias[l] = bias[l]; }
   p.B = B; p.Cf = Cf; p.H = H; p.W = W; p.h0 = h0; p.w0 = w0;
   p.nstrip = (W + kTWO - 1) / kTWO;
   V3D_REQUIRE((long long)B * p.nstrip < (1ll << 31), V3D_ERR_BAD_SHAPE, "propagation: too many strips");
-  if (cinp == 8) return launch_g<1>(p, s);
-  if (cinp == 24) return launch_g<3>(p, s);
-  if (cinp == 40) return launch_g<5>(p, s);
+  if (cinp == 8) return f32 ? launch_g<1, true>(p, s) : launch_g<1, false>(p, s);
+  if (cinp == 24) return f32 ? launch_g<3, true>(p, s) : launch_g<3, false>(p, s);
+  if (cinp == 40) return f32 ? launch_g<5, true>(p, s) : launch_g<5, false>(p, s);
   return v3d::fail(V3D_ERR_UNSUPPORTED, "propagation: %d padded input channels (8, 24, 40)", cinp);
 }

@@ -246,9 +246,9 @@ int launch_conv12z(const void* c0_split, const float* w1, const float* w2, const
 // index tables iy [H] / ix [W] (device, may be null = identity with h0 == H, w0 == W) the nearest-neighbour resize of the depth
 // (eval-3dvnet.py:103,111,119) happens in the kernel's addressing.
 size_t propz_image_words(int layer, int cinp);
-void propz_pack_layer(int layer, int cinp, int cin, int cout, const float* w_folded, unsigned* out);
-int launch_propz(int cinp, const float* feat, const float* depth, const int* iy, const int* ix, float* out, const float* const w[4],
-                 const float* const bias[4], int B, int Cf, int H, int W, int h0, int w0, hipStream_t s);
+void propz_pack_layer(int layer, int cinp, int cin, int cout, const float* w_folded, unsigned* out, bool f32);
+int launch_propz(int cinp, bool f32, const float* feat, const float* depth, const int* iy, const int* ix, float* out,
+                 const float* const w[4], const float* const bias[4], int B, int Cf, int H, int W, int h0, int w0, hipStream_t s);
 
 // [n_img, C, HW] -> [n_img, HW, C] (C in {16, 32}); defined in psv_variance.hip
 int transpose_channel_last(const float* feat, float* featT, int n_img, int C, int HW, hipStream_t s);

@@ -71,9 +71,8 @@ class PL3DVNet(nn.Module):
         the first U-Net level, the unfused hypothesis decoder.  Extra keywords:
         ``feat_extractor`` / ``feat_shrinker`` inject the 2D backbone, ``backbone=True`` builds the MnasNet-1.0 + FPN
         one of the reference (``backbone.py``; random-init, there are no pretrained weights offline); ``precision``
-        ('split_bf16' | 'fp32') selects the MFMA operand precision of the matrix-core kernels of stages 1 and 2 (include/v3d.h);
-        the three PropagationNets of stage 3 (``refine_*``) always run split-bf16 operands (``v3d_propagation_f32`` has no exact-fp32
-        variant), on a HIP device, in eval mode."""
+        ('split_bf16' | 'fp32') selects the MFMA operand precision of the matrix-core kernels of all three stages (include/v3d.h;
+        round 6: the PropagationNets of stage 3, ``refine_*``, included), on a HIP device, in eval mode."""
         super().__init__()
         if feat_dim not in (16, 32):
             raise ValueError('PL3DVNet: feat_dim=%d is not supported by the HIP path (16 -- the reference\'s signature default -- '
@@ -93,10 +92,10 @@ class PL3DVNet(nn.Module):
         self.sparse_conv = SparseUNet(dims=(2 * feat_dim, 128, 128), n_groups=(4, 8, 8), n_res=(1, 2, 3),
                                       precision=precision)
         self.decoder = HypothesisDecoder(128 + 128 + 3 * feat_dim, 128, hyp_ksize, hyp_pad, precision=precision)
-        # stage-3 upsamplers (lightningmodel.py:41-43): stock 2D convolutions, SURVEY.md 8f "next" row
-        self.refine_quarter = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
-        self.refine_half = PropagationNet(in_dim=feat_dim + 1, h_dim=32)
-        self.refine_full = PropagationNet(in_dim=3 + 1, h_dim=32)
+        # stage-3 upsamplers (lightningmodel.py:41-43), SURVEY.md 8f rank 2: the library's row-marching kernel (csrc/propz.hip)
+        self.refine_quarter = PropagationNet(in_dim=feat_dim + 1, h_dim=32, precision=precision)
+        self.refine_half = PropagationNet(in_dim=feat_dim + 1, h_dim=32, precision=precision)
+        self.refine_full = PropagationNet(in_dim=3 + 1, h_dim=32, precision=precision)
         self._ws = _Workspace()
         self._offset_vals = {}
         self._pts_batch = {}

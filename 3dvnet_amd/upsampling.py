@@ -27,8 +27,11 @@ class PropagationNet(nn.Module):
     """``forward(features[B,Cf,H,W], depth[B,1,H,W]) -> [B,H,W]``: each output depth is a convex combination (softmax
     over 9 logits predicted from features+depth) of its 3x3 neighbourhood (upsampling.py:23-36)."""
 
-    def __init__(self, in_dim=4, h_dim=32):
+    def __init__(self, in_dim=4, h_dim=32, precision='split_bf16'):
+        """``precision`` ('split_bf16' | 'fp32', an extra keyword of this package): the MFMA operand precision (include/v3d.h)."""
         super().__init__()
+        _lib.precision_code(precision)
+        self.precision = precision
         self.in_dim, self.h_dim = in_dim, h_dim
         widths = [in_dim, h_dim, h_dim, h_dim, 9]
         for i in range(4):
@@ -101,7 +104,8 @@ class PropagationNet(nn.Module):
             nb = min(step, B - s)
             ws = self._ws.get('prop', lib.v3d_propagation_workspace_bytes(handle, nb, H, W), dev)
             rc = lib.v3d_propagation_f32(handle, features[s:s + nb].data_ptr(), depth[s:s + nb].data_ptr(), nb, Cf, H, W,
-                                         out[s:s + nb].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+                                         out[s:s + nb].data_ptr(), _lib.precision_code(self.precision), ws.data_ptr(), ws.numel(),
+                                         _lib.stream_ptr(dev))
             _lib.check(rc, 'v3d_propagation_f32')
         return out
 
@@ -121,7 +125,8 @@ class PropagationNet(nn.Module):
         iy, ix = nearest_tables((h0, w0), (H, W), dev)
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         rc = lib.v3d_propagation_up_f32(self.packed_handle(dev), features.data_ptr(), depth_lo.data_ptr(), B, Cf, H, W, h0, w0,
-                                        iy.data_ptr(), ix.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev))
+                                        iy.data_ptr(), ix.data_ptr(), out.data_ptr(), _lib.precision_code(self.precision),
+                                        _lib.stream_ptr(dev))
         _lib.check(rc, 'v3d_propagation_up_f32')
         return out
 

@@ -454,8 +454,8 @@ def bench_scene(args, rank, world, dev, dist):
     net = make_net('split_bf16')
     # the reference's arithmetic type: every matrix-core kernel of stages 1 and 2 on exact-fp32 operands
     # (cost volume: the fp32 chain of cfg2; PointNet / sparse U-Net: v3d_gemm_gather_f32 with V3D_PRECISION_FP32; hypothesis
-    # decoder: the unfused interpolation + conv1d chain on fp32 operands -- the fused kernel is split-bf16 only).  Stage 3's
-    # PropagationNets have no exact-fp32 variant: with --stage3 the figure is "stages 1-2 exact fp32, stage 3 split-bf16".
+    # decoder: the unfused interpolation + conv1d chain on fp32 operands -- the fused kernel is split-bf16 only; stage 3: the
+    # row-marching PropagationNet kernel on v_mfma_f32_16x16x4_f32).
     net32 = make_net('fp32') if getattr(args, 'fp32_exact', True) else None
     group = None
 
@@ -703,9 +703,8 @@ def bench_scene(args, rank, world, dev, dist):
         'higher_is_better': True,
         'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
         'config': {'value_fp32_exact': value32, 'ms_per_step_fp32_exact': ms32,
-                   'fp32_exact_note': 'stages 1-2 on exact-fp32 matrix operands (the hypothesis decoder as its unfused chain)'
-                                      + ('; stage 3 (PropagationNet) has no exact-fp32 variant and runs split-bf16 in both figures'
-                                         if stage3 else ''),
+                   'fp32_exact_note': 'every matrix-core kernel on exact-fp32 operands (the hypothesis decoder as its unfused chain'
+                                      + (', stage 3 as the same row-marching kernel on v_mfma_f32_16x16x4_f32)' if stage3 else ')'),
                    'workload': '%s: one %d-view scene of the 6x5x3 m box room, 256x320, %d edges/ref (ref-%d .. ref+%d), '
                                '96 planes, 56x56 plane grid, 4 cm voxels; stage A (timed) -> its depths replaced '
                                'by analytic wall depth + 2 cm noise -> 2 x (scene model + 3 point-flow sweeps)%s'

@@ -356,7 +356,8 @@ int v3d_decoder_head_f32(const float* act, int n_pts, int n_hyp, int C, const fl
  *   p = softmax over the 9 logits; out = sum_k p_k * unfold(replicate_pad(depth))_k.
  * v3d_propagation_pack takes HOST pointers to conv{1..4}.0.weight [Co, Ci, 3, 3] and conv{1..4}.1.{weight, bias,
  * running_mean, running_var}; in_dim = guide channels + 1 (33 for the feature-guided nets, 4 for the image-guided one).
- *   features [B, in_dim - 1, H, W], depth [B, 1, H, W] (= [B, H, W]), out [B, H, W]; split-bf16 MFMA operands.
+ *   features [B, in_dim - 1, H, W], depth [B, 1, H, W] (= [B, H, W]), out [B, H, W]; `precision` (ABI version 5) =
+ *   V3D_PRECISION_SPLIT_BF16 | V3D_PRECISION_FP32 (exact fp32 products on v_mfma_f32_16x16x4_f32, the reference's arithmetic).
  * ------------------------------------------------------------------------------------------ */
 typedef struct v3d_propagation_weights v3d_propagation_weights;
 int v3d_propagation_pack(const float* const* conv_weight_host, const float* const* bn_weight_host,
@@ -366,7 +367,7 @@ int v3d_propagation_pack(const float* const* conv_weight_host, const float* cons
 void v3d_propagation_free(v3d_propagation_weights* handle);
 size_t v3d_propagation_workspace_bytes(const v3d_propagation_weights* handle, int B, int H, int W);
 int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* features, const float* depth, int B, int Cf,
-                        int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
+                        int H, int W, float* out, int precision, void* workspace, size_t workspace_bytes, void* stream);
 /* The same network with the nearest-neighbour resize that precedes every call of stage 3 (F.interpolate(depth, size, 'nearest'),
  * mv3d/eval-3dvnet.py:103,111,119) folded into the kernel's addressing (ABI version 5): depth_lo [B, h0, w0] is the depth BEFORE
  * the resize, iy [H] / ix [W] (DEVICE int32) the source row / column of every output row / column -- the caller obtains them
@@ -374,7 +375,7 @@ int v3d_propagation_f32(const v3d_propagation_weights* handle, const float* feat
  * the four layers' activations stay in LDS, no workspace.  v3d_propagation_f32 runs the same kernel (developer option
  * "prop_fused" = 0: the per-layer kernels of round 4, other summation orders). */
 int v3d_propagation_up_f32(const v3d_propagation_weights* handle, const float* features, const float* depth_lo, int B, int Cf,
-                           int H, int W, int h0, int w0, const int32_t* iy, const int32_t* ix, float* out, void* stream);
+                           int H, int W, int h0, int w0, const int32_t* iy, const int32_t* ix, float* out, int precision, void* stream);
 
 /* Rows C2a + C2b + C3 fused: MinkowskiInterpolation of the three U-Net levels at the hypothesis
  * points (mv3d/subnetworks/refinement.py:28-41) -> the three Conv1d+BN+ReLU layers along the hypothesis axis (:16-23) ->

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument('--views', type=int, default=64)
 ap.add_argument('--tag', default='')
+ap.add_argument('--precision', default='split_bf16')
 args = ap.parse_args()
 libm = importlib.import_module('3dvnet_amd._lib')
 if os.environ.get('V3D_LIB_OVERRIDE'):
@@ -24,7 +25,7 @@ guides = [syn.make_features(n, 32, 64, 80, seed=1).to(dev), syn.make_features(n,
           syn.make_images(n, (256, 320), seed=3).to(dev)]
 out = []
 for (cin, seed), gd, lo in zip(((33, 5), (33, 6), (4, 7)), guides, ((56, 56), (64, 80), (128, 160))):
-    m = up.PropagationNet(cin, 32).eval()
+    m = up.PropagationNet(cin, 32, precision=args.precision).eval()
     m.load_state_dict(syn.propagation_weights(cin, 32, seed), strict=False)
     m = m.to(dev)
     d = 1 + torch.rand((n,) + lo, device=dev)

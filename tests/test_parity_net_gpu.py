@@ -249,6 +249,22 @@ def test_hip_propagation_net_matches_reference_golden_and_oracle_chain(cuda):
         o17 = n17.to(cuda)(g17.to(cuda), d17.to(cuda))
         r17 = osc.propagation_net(g17, d17, sd17)
     np.testing.assert_allclose(o17.cpu().numpy(), r17.numpy(), rtol=2e-5, atol=0)
+    # the reference's arithmetic type (round 6): the same kernel on exact-fp32 matrix instructions -- golden, the three-resolution
+    # chain with the folded resize, and the 17-channel net, an order of magnitude inside the split-bf16 bound
+    net32 = up.PropagationNet(33, 32, precision='fp32').eval()
+    net32.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        o32 = net32.to(cuda)(torch.from_numpy(g['features']).to(cuda), torch.from_numpy(g['depth']).to(cuda))
+        np.testing.assert_allclose(o32.cpu().numpy(), g['out'], rtol=3e-6, atol=0)
+        d32 = depth.to(cuda)
+        for sdi, cin, gd in zip(sds, (33, 33, 4), guides):
+            n32 = up.PropagationNet(cin, 32, precision='fp32').eval()
+            n32.load_state_dict(sdi, strict=False)
+            d32 = n32.to(cuda).forward_resized(gd.to(cuda), d32)
+        np.testing.assert_allclose(d32.cpu().numpy(), ref.numpy(), rtol=3e-6, atol=0)
+        n17f = up.PropagationNet(17, 32, precision='fp32').eval()
+        n17f.load_state_dict(sd17, strict=False)
+        np.testing.assert_allclose(n17f.to(cuda)(g17.to(cuda), d17.to(cuda)).cpu().numpy(), r17.numpy(), rtol=3e-6, atol=0)
 
 
 # ---- cached packed weights -----------------------------------------------------------------------------------------------
