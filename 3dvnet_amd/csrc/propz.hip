@@ -8,11 +8,11 @@
 // matrix instructions on a zero x tap (K = 4 x taps x 8 channels).  Here a workgroup owns a 40-column strip of one image and
 // marches down its rows; the activations of the four layers live in LDS as rings of four rows and never reach HBM:
 //
-//   waves 0..3 = layers 1..4, one per SIMD, each with its layer's split-bf16 weight fragments in REGISTERS for the whole kernel
+//   waves 0..3 = layers 1..4 (layer 1 shared with wave 7), each with its split-bf16 weight fragments in REGISTERS for the whole kernel
 //                (K step = one tap x all 32 input channels: no zero tap; layer 1 flattens (tap, channel) into K);
 //                layer l computes row t - 2 l at step t from rows r - 1 .. r + 1 of the ring below it and writes bias + ReLU +
 //                hi / lo split into its own ring; the layer-4 wave also does the softmax + 3 x 3 propagation and stores the row;
-//   waves 4..7 = helpers: load the guide features + depth of row t + 1 (the nearest-neighbour resize of the depth is two index
+//   waves 4..6 = helpers: load the guide features + depth of row t + 1 (the nearest-neighbour resize of the depth is two index
 //                tables in the addressing), split them and commit row t to the input ring.
 //   One barrier per step; H + 8 steps per strip.
 //
@@ -54,9 +54,7 @@ struct PZ {
   static constexpr int RING3 = RING2 + 4 * kRowB;
   static constexpr int DEPTH = RING3 + 4 * kRowB;          // [kDR][kPSL] floats
   static constexpr int LOGIT = DEPTH + kDR * kPSL * 4;     // [kTC][12] floats, private to the layer-4 wave
-  static constexpr int WLO = LOGIT + kTC * 12 * 4;         // G = 5: the lo weight fragments of layer 1 [KS1][2][64 lanes] x 16 bytes
-  static constexpr int ZERO_END = WLO;                     // what a strip's start clears
-  static constexpr int LDS = WLO + (G == 5 ? KS1 * 2 * 64 * 16 : 0);
+  static constexpr int LDS = LOGIT + kTC * 12 * 4;
   static_assert(PS0 % 16 == 0 && (PS0 / 4) % 8 == 4, "pixel stride = 4 banks (mod 8): 16 lanes, 16 bank groups");
   static_assert(LDS <= 160 * 1024, "one workgroup per CU");
 };
@@ -90,11 +88,16 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 // lane are channels 8 q .. 8 q + 3 and 8 q + 4 .. 8 q + 7, the two fragment registers of a (K step, 16-row block) hold the
 // weights of k slices 0..3 and 4..7 (slice s multiplies channel 8 kq + s): eight exact-fp32 matrix instructions per (block, co
 // block, K step) where the split path has three bf16 ones -- same registers, same LDS, 5.3x the matrix time.
-template <int G, int LAYER, bool F32>
+// CB0 / NCB: the 16-row blocks of output channels this wave computes.  Layer 1 is split over two waves on two SIMDs (wave 0:
+// channels 0..15, wave 7: 16..31): with (tap, channel) flattened into K the 40-channel nets give it 12 K steps -- 216 matrix
+// instructions per row against the 162 of layers 2 and 3, and 192 registers of fragments; one wave doing all of it set the pace
+// of the whole pipeline (6 300 cycles per row).
+template <int G, int LAYER, bool F32, int CB0, int NCB>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
   constexpr bool L1 = LAYER == 1;
-  constexpr int KS = L1 ? Z::KS1 : 9, NCB = LAYER == 4 ? 1 : 2;
+  constexpr int KS = L1 ? Z::KS1 : 9, NCBL = LAYER == 4 ? 1 : 2;      // K steps; 16-row blocks of the whole layer
+  static_assert(CB0 + NCB <= NCBL, "co blocks");
   constexpr int PSI = L1 ? Z::PS0 : kPS;                      // pixel stride / row bytes of the ring this layer reads
   constexpr int RBI = kPSL * PSI;
   constexpr int CGB = F32 ? 32 : 16;                          // bytes between the first reads of consecutive 8-channel groups
@@ -103,26 +106,19 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
   constexpr int ROUT = LAYER == 1 ? Z::RING1 : LAYER == 2 ? Z::RING2 : Z::RING3;
   const int kq = lane >> 4, jn = lane & 15;
 
-  // the layer's weight fragments: registers, once.  (Layer 1 of the 40-channel nets has 12 K steps = 192 registers of
-  // fragments, more than the 256-register budget of two waves per SIMD leaves beside everything else: its lo fragments -- one of
-  // the three products -- sit in 24 KB of LDS instead and are read beside the B fragments.  Streaming them from L2 with a ring of
-  // four K steps measured 7 000 cycles per row against the 3 500 of the matrix instructions.)
-  constexpr bool LO_LDS = L1 && G == 5;
-  u32x4 a[KS][NCB][LO_LDS ? 1 : 2];
+  // the wave's weight fragments: registers, once
+  u32x4 a[KS][NCB][2];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      a[ks][cb][0] = p.w[LAYER - 1][((ks * NCB + cb) * 2 + 0) * 64 + lane];
-      const u32x4 lo = p.w[LAYER - 1][((ks * NCB + cb) * 2 + 1) * 64 + lane];
-      if constexpr (LO_LDS) reinterpret_cast<u32x4*>(smem + Z::WLO)[(ks * NCB + cb) * 64 + lane] = lo;   // (never cleared: ZERO_END)
-      else a[ks][cb][1] = lo;
-    }
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) a[ks][cb][part] = p.w[LAYER - 1][((ks * NCBL + CB0 + cb) * 2 + part) * 64 + lane];
   float bias[NCB][4];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[cb][r] = p.bias[LAYER - 1][cb * 16 + 4 * kq + r];
+    for (int r = 0; r < 4; ++r) bias[cb][r] = p.bias[LAYER - 1][(CB0 + cb) * 16 + 4 * kq + r];
 
   // B-fragment addressing.  Layers 2..4: K step = tap (ky, kx), the lane's 8 k values = channels 8 kq .. 8 kq + 7 of pixel
   // (column jn + kx - 1): slot index 1 + blk * 16 + jn + kx - 1.  Layer 1: k = tap * CIN1P + channel, the lane's 8 k values =
@@ -178,10 +174,7 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
           }
           u32x4 alo[NCB];
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            if constexpr (LO_LDS) alo[cb] = reinterpret_cast<const u32x4*>(smem + Z::WLO)[(ks * NCB + cb) * 64 + lane];
-            else alo[cb] = a[ks][cb][LO_LDS ? 0 : 1];
-          }
+          for (int cb = 0; cb < NCB; ++cb) alo[cb] = a[ks][cb][1];
           if constexpr (F32) {
             // eight k slices per (block, co block), round robin over the accumulators
 #pragma unroll
@@ -196,8 +189,11 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
                 }
           } else {
           // three products per (block, co block), round robin over the accumulators (no back-to-back dependent pair)
+#ifndef V3D_PZ_ABLATE
+#define V3D_PZ_ABLATE 0      // developer ablation: 1 = two of the three split products (timing only: is the pipeline matrix-bound?)
+#endif
 #pragma unroll
-          for (int prod = 0; prod < 3; ++prod)
+          for (int prod = 0; prod < (V3D_PZ_ABLATE == 1 ? 2 : 3); ++prod)
 #pragma unroll
             for (int blk = 0; blk < kNBLK; ++blk)
 #pragma unroll
@@ -218,12 +214,12 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[blk][cb][q] + bias[cb][q], 0.f) * colmask[blk];
               if constexpr (F32) {
-                *reinterpret_cast<f32x4*>(orow + blk * 16 * kPS + cb * 64) = (f32x4){v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(orow + blk * 16 * kPS + (CB0 + cb) * 64) = (f32x4){v[0], v[1], v[2], v[3]};
               } else {
                 u32x2 hp, lp;
                 pz_split4(v[0], v[1], v[2], v[3], hp, lp);
-                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32) = hp;
-                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + cb * 32 + 64) = lp;
+                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + (CB0 + cb) * 32) = hp;
+                *reinterpret_cast<u32x2*>(orow + blk * 16 * kPS + (CB0 + cb) * 32 + 64) = lp;
               }
             }
         } else {
@@ -263,7 +259,7 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
           }
           __builtin_amdgcn_wave_barrier();                      // the scratch is free for the next row
         }
-      } else if (LAYER < 4 && r == p.H) {
+      } else if (LAYER < 4 && CB0 == 0 && r == p.H) {
         // the row below the image: zeros (the next layer's zero padding); the slot still holds row H - 4
         unsigned char* const orow = smem + ROUT + (r & 3) * kRowB;
         for (int i = lane; i < kRowB / 16; i += 64) reinterpret_cast<u32x4*>(orow)[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -278,26 +274,32 @@ template <int G, bool F32>
 __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned char* smem, int htid, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
   constexpr int NQ = Z::CIN1P / 4;                              // channel quads per pixel
-  constexpr int NTASK = kPSL * NQ, NT = (NTASK + 255) / 256;    // (pixel slot, quad) tasks per row, per helper thread
+  constexpr int HT = 192;                                       // helper threads: waves 4..6
+  constexpr int NTASK = kPSL * NQ, NT = (NTASK + HT - 1) / HT;  // (pixel slot, quad) tasks per row, per helper thread
   const size_t plane = (size_t)p.H * p.W;
   for (int item = item0; item < n_items; item += item_step) {
     const int b = item / p.nstrip, x0 = (item - b * p.nstrip) * kTWO;
     // everything the workgroup's LDS holds is zero at the start of a strip (rows -1 of every ring, guard slots)
-    for (int i = htid; i < Z::ZERO_END / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = htid; i < Z::LDS / 16; i += HT) reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
     __syncthreads();
     const float* const fimg = p.feat + (size_t)b * p.Cf * plane;
     const float* const dimg = p.depth + (size_t)b * p.h0 * p.w0;
     // per task: slot, quad, the source column of the features (clamped: replicate for the depth ring, masked for the conv input)
-    float val[NT][4];
-    float dval = 0.f;
-    auto issue = [&](int y) __attribute__((always_inline)) {
+    // kPF rows in flight: one row of prefetch (requested at step t, committed at step t + 1) left every step waiting for an HBM
+    // round trip -- 1.8 us per row whatever the matrix waves did
+    constexpr int kPF = 4;
+    float valr[kPF][NT][4];
+    float dvalr[kPF];
+    auto issue = [&](int y, float (&val)[NT][4], float& dval) __attribute__((always_inline)) {
       const bool row_ok = y >= 0 && y < p.H;
       const int yc = min(max(y, 0), p.H - 1);
       const int ys = p.iy ? p.iy[yc] : yc;
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const int task = htid + 256 * i;
-        const int ps = task / NQ, q = task - ps * NQ;
+        const int task = htid + HT * i;
+        // (pixel slot fastest: the lanes of a load walk along x inside one channel plane -- with the quad fastest a wave's load
+        // touched 60 cache lines and the helpers' loads took longer than a row of the matrix waves)
+        const int q = task / kPSL, ps = task - q * kPSL;
         const int x = x0 - 5 + ps;
         const bool ok = row_ok && task < NTASK && x >= 0 && x < p.W;
         const int xc = min(max(x, 0), p.W - 1);
@@ -316,13 +318,13 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
         dval = dimg[(size_t)ys * p.w0 + (p.ix ? p.ix[xc] : xc)];
       }
     };
-    auto commit = [&](int y) __attribute__((always_inline)) {
+    auto commit = [&](int y, const float (&val)[NT][4], float dval) __attribute__((always_inline)) {
       unsigned char* const row = smem + Z::RING0 + (y & 3) * Z::R0;
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const int task = htid + 256 * i;
+        const int task = htid + HT * i;
         if (task < NTASK) {
-          const int ps = task / NQ, q = task - ps * NQ;
+          const int q = task / kPSL, ps = task - q * kPSL;
           if constexpr (F32) {
             *reinterpret_cast<f32x4*>(row + ps * Z::PS0 + q * 16) = (f32x4){val[i][0], val[i][1], val[i][2], val[i][3]};
           } else {
@@ -335,11 +337,22 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
       }
       if (htid < kPSL && y >= 0 && y < p.H) reinterpret_cast<float*>(smem + Z::DEPTH)[(y & (kDR - 1)) * kPSL + htid] = dval;
     };
-    issue(0);
-    for (int t = 0; t < p.H + 4 * kLag; ++t) {
-      if (t <= p.H) commit(t);                                   // row H = the zero row below the image
-      if (t + 1 <= p.H) issue(t + 1);
-      __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+      dvalr[j] = 0.f;
+      issue(j, valr[j], dvalr[j]);                               // rows 0 .. kPF - 1 (rows >= H load nothing and give zeros)
+    }
+    const int steps = p.H + 4 * kLag;
+    for (int t0 = 0; t0 < steps; t0 += kPF) {
+#pragma unroll
+      for (int j = 0; j < kPF; ++j) {
+        const int t = t0 + j;
+        if (t < steps) {                                         // (wave-uniform; every wave of the workgroup runs `steps` barriers)
+          if (t <= p.H) commit(t, valr[j], dvalr[j]);            // row H = the zero row below the image
+          if (t + kPF <= p.H) issue(t + kPF, valr[j], dvalr[j]);
+          __syncthreads();
+        }
+      }
     }
   }
 }
@@ -351,10 +364,12 @@ __global__ __launch_bounds__(kThreads, 2) void propz_kernel(PropzParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_items = p.B * p.nstrip;
   const int item0 = (int)blockIdx.x, item_step = (int)gridDim.x;
-  if (wave == 0) pz_matrix_role<G, 1, F32>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 1) pz_matrix_role<G, 2, F32>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 2) pz_matrix_role<G, 3, F32>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 3) pz_matrix_role<G, 4, F32>(p, smem, lane, item0, item_step, n_items);
+  // (waves are dealt to the four SIMDs round robin: wave 7 shares SIMD 3 with the layer-4 wave, the lightest of the four)
+  if (wave == 0) pz_matrix_role<G, 1, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 1) pz_matrix_role<G, 2, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 2) pz_matrix_role<G, 3, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 3) pz_matrix_role<G, 4, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
+  else if (wave == 7) pz_matrix_role<G, 1, F32, 1, 1>(p, smem, lane, item0, item_step, n_items);
   else pz_helper_role<G, F32>(p, smem, tid - 256, item0, item_step, n_items);
 }
 
