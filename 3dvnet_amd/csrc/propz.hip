@@ -88,10 +88,16 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 // lane are channels 8 q .. 8 q + 3 and 8 q + 4 .. 8 q + 7, the two fragment registers of a (K step, 16-row block) hold the
 // weights of k slices 0..3 and 4..7 (slice s multiplies channel 8 kq + s): eight exact-fp32 matrix instructions per (block, co
 // block, K step) where the split path has three bf16 ones -- same registers, same LDS, 5.3x the matrix time.
-// CB0 / NCB: the 16-row blocks of output channels this wave computes.  Layer 1 is split over two waves on two SIMDs (wave 0:
-// channels 0..15, wave 7: 16..31): with (tap, channel) flattened into K the 40-channel nets give it 12 K steps -- 216 matrix
-// instructions per row against the 162 of layers 2 and 3, and 192 registers of fragments; one wave doing all of it set the pace
-// of the whole pipeline (6 300 cycles per row).
+// CB0 / NCB: the 16-row blocks of output channels this wave computes (see propz_kernel for who computes what).
+// Round-6 measurements behind the layout, 64 views, ms per net (64x80 cin 33 | 128x160 cin 33 | 256x320 cin 4):
+//   one wave per layer, layer 1's 40-channel fragments streamed from L2 through a ring of four K steps   0.239 | 0.475 | 0.967
+//   ... its lo fragments in 24 KB of LDS instead                                                         0.207 | 0.410 | 0.963
+//   layer 1 split by channel halves over waves 0 and 7, three helper waves, coalesced helper loads       0.163 | 0.345 | 1.04
+//   1 / 2 / 4 input rows of prefetch: no difference (the pipeline does not wait for the loads)
+//   two of the three split products (timing only): -17 % instead of -33 %: half of a row's time is the critical waves' LDS reads,
+//     epilogue and barrier, not matrix instructions
+//   EIGHT matrix waves (layers 2 / 3 by channel halves, layers 1 / 4 in column-block pieces on the loader waves)
+//     0.215 | 0.431 | 1.41: every B fragment is then read from LDS by two waves and the kernel becomes LDS-bound
 template <int G, int LAYER, bool F32, int CB0, int NCB>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
@@ -270,11 +276,10 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
 }
 
 // ---- helper waves: the input ring + the fp32 depth ring ---------------------------------------------------------------------------
-template <int G, bool F32>
+template <int G, bool F32, int HT>
 __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned char* smem, int htid, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
   constexpr int NQ = Z::CIN1P / 4;                              // channel quads per pixel
-  constexpr int HT = 192;                                       // helper threads: waves 4..6
   constexpr int NTASK = kPSL * NQ, NT = (NTASK + HT - 1) / HT;  // (pixel slot, quad) tasks per row, per helper thread
   const size_t plane = (size_t)p.H * p.W;
   for (int item = item0; item < n_items; item += item_step) {
@@ -285,9 +290,11 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
     const float* const fimg = p.feat + (size_t)b * p.Cf * plane;
     const float* const dimg = p.depth + (size_t)b * p.h0 * p.w0;
     // per task: slot, quad, the source column of the features (clamped: replicate for the depth ring, masked for the conv input)
-    // kPF rows in flight: one row of prefetch (requested at step t, committed at step t + 1) left every step waiting for an HBM
-    // round trip -- 1.8 us per row whatever the matrix waves did
-    constexpr int kPF = 4;
+    // kPF rows in flight; task -> (pixel slot, quad) with the slot fastest (the lanes of a load walk along x inside one channel
+    // plane).  Same-box A/B: both help the 33-channel nets (0.208 -> 0.163, 0.412 -> 0.343 ms with the layer-1 split) and cost the
+    // 4-channel net 11 % (0.99 -> 1.10 ms: half of its "quads" are padding and load nothing) -- so they depend on G.
+    constexpr int kPF = G > 1 ? 2 : 1;
+    constexpr bool kSlotFast = G > 1;
     float valr[kPF][NT][4];
     float dvalr[kPF];
     auto issue = [&](int y, float (&val)[NT][4], float& dval) __attribute__((always_inline)) {
@@ -297,9 +304,7 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int task = htid + HT * i;
-        // (pixel slot fastest: the lanes of a load walk along x inside one channel plane -- with the quad fastest a wave's load
-        // touched 60 cache lines and the helpers' loads took longer than a row of the matrix waves)
-        const int q = task / kPSL, ps = task - q * kPSL;
+        const int q = kSlotFast ? task / kPSL : task % NQ, ps = kSlotFast ? task - q * kPSL : task / NQ;
         const int x = x0 - 5 + ps;
         const bool ok = row_ok && task < NTASK && x >= 0 && x < p.W;
         const int xc = min(max(x, 0), p.W - 1);
@@ -324,7 +329,7 @@ __device__ __forceinline__ void pz_helper_role(const PropzParams& p, unsigned ch
       for (int i = 0; i < NT; ++i) {
         const int task = htid + HT * i;
         if (task < NTASK) {
-          const int q = task / kPSL, ps = task - q * kPSL;
+          const int q = kSlotFast ? task / kPSL : task % NQ, ps = kSlotFast ? task - q * kPSL : task / NQ;
           if constexpr (F32) {
             *reinterpret_cast<f32x4*>(row + ps * Z::PS0 + q * 16) = (f32x4){val[i][0], val[i][1], val[i][2], val[i][3]};
           } else {
@@ -364,13 +369,24 @@ __global__ __launch_bounds__(kThreads, 2) void propz_kernel(PropzParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_items = p.B * p.nstrip;
   const int item0 = (int)blockIdx.x, item_step = (int)gridDim.x;
-  // (waves are dealt to the four SIMDs round robin: wave 7 shares SIMD 3 with the layer-4 wave, the lightest of the four)
-  if (wave == 0) pz_matrix_role<G, 1, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 1) pz_matrix_role<G, 2, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 2) pz_matrix_role<G, 3, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 3) pz_matrix_role<G, 4, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
-  else if (wave == 7) pz_matrix_role<G, 1, F32, 1, 1>(p, smem, lane, item0, item_step, n_items);
-  else pz_helper_role<G, F32>(p, smem, tid - 256, item0, item_step, n_items);
+  // Waves are dealt to the four SIMDs round robin.  The image-guided net (G = 1: layer 1 has 54 matrix instructions per row) keeps
+  // layer 1 on wave 0 and four helper waves; the feature-guided nets (layer 1: 216 at G = 5) split it over wave 0 and wave 7 (SIMD 3,
+  // beside the layer-4 wave, the lightest) -- measured per net, 64 views: G = 1 0.96 ms either way round (1.04 with the split),
+  // G = 5 0.41 -> 0.345 ms (128 x 160) and 0.207 -> 0.163 ms (64 x 80) with it.
+  if constexpr (G == 1) {
+    if (wave == 0) pz_matrix_role<G, 1, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 1) pz_matrix_role<G, 2, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 2) pz_matrix_role<G, 3, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 3) pz_matrix_role<G, 4, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
+    else pz_helper_role<G, F32, 256>(p, smem, tid - 256, item0, item_step, n_items);
+  } else {
+    if (wave == 0) pz_matrix_role<G, 1, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 1) pz_matrix_role<G, 2, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 2) pz_matrix_role<G, 3, F32, 0, 2>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 3) pz_matrix_role<G, 4, F32, 0, 1>(p, smem, lane, item0, item_step, n_items);
+    else if (wave == 7) pz_matrix_role<G, 1, F32, 1, 1>(p, smem, lane, item0, item_step, n_items);
+    else pz_helper_role<G, F32, 192>(p, smem, tid - 256, item0, item_step, n_items);
+  }
 }
 
 template <int G, bool F32>
