@@ -47,7 +47,7 @@ PEAK_HBM_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # dense fp32 MFMA == fp32 vector peak
 DTYPE = 'f32 storage/accumulate; MFMA operands split-bf16x3 (hi*hi+hi*lo+lo*hi, 16 mantissa bits); warp/variance f32 VALU'
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 
 # (Cin, Cout, divisor of D*h*w giving the voxel count the 27*Cin*Cout MACs are spent on): output voxels
 # for the convs, INPUT voxels for the stride-2 transposed convs (SURVEY.md §8a row A5 MAC table)

@@ -53,7 +53,9 @@ def weighted(path, match):
 # kernel families with several template instances per scene: the sparse convolutions of the U-Net (pipeline kernel, 32- / 64-row
 # tiles, 64 / 128 channels) and the twelve conv launches of stage 3 (FLAT instances of convg_bf16x2_kernel: "..., true> >")
 FAMILIES = [('sparse_conv_gemm', lambda k: 'gemm_gather_pipe_kernel' in k),
-            ('propagation_conv', lambda k: 'convg_bf16x2_kernel' in k and k.rstrip().endswith('true> >'))]
+            ('propagation_conv', lambda k: 'convg_bf16x2_kernel' in k and k.rstrip().endswith('true> >')),
+            # round 6: one row-marching kernel per PropagationNet (csrc/propz.hip), three instances per scene
+            ('propagation_fused', lambda k: 'propz_kernel' in k and 'false>' in k)]
 
 
 def main():
