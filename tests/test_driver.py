@@ -373,12 +373,24 @@ def test_bench_line_carries_cfg5_and_cfg3_figures(cuda):
     assert len(e3['parity']['per_outer_iteration']) == 2 and 'points_in_different_cells_at_iteration_2' in e3['parity']['free_running']
     assert e3['parity']['max_abs_refinement_m'] > 0.01       # the sweeps really moved the depths
     assert 'replicas' in d['config']['multi_gpu_note']
-    # the stage-3 leg prices its twelve conv launches against the matrix peak and carries their HBM traffic from the committed
-    # PMC passes (profiles/<round>_traffic_cfg3.json); the from-images figure is the sum of the two timed stages
+    # the stage-3 leg prices its launches (round 6: one row-marching kernel per net) against the matrix peak and carries their HBM
+    # traffic from the committed PMC passes (profiles/<round>_traffic_cfg3.json); the from-images figure is the sum of the two
+    # timed stages
     s3 = d['extra']['cfg3_full']['stage3']
-    assert s3['roofline']['bound'] == 'mfma' and 0 < s3['roofline']['frac'] < 1 and s3['roofline']['traffic'] > 1e8
+    assert s3['roofline']['bound'] == 'mfma' and 0 < s3['roofline']['frac'] < 1 and s3['roofline']['traffic'] > 1e7
+    assert 'propagation_fused' in s3['roofline']['kernel']
     assert d['extra']['cfg3']['roofline']['traffic'] > 1e8
     assert d['extra']['from_images']['value'] > 0 and d['extra']['backbone']['ms_per_batch'] > 0
+    assert d['extra']['backbone']['ms_per_batch_240x320'] > 0
+    # the reference's arithmetic type beside every figure, and inside `config` (a record that keeps only the contract's keys)
+    assert d['config']['value_fp32_exact'] == d['value_fp32_exact'] and d['config']['ms_per_step_fp32_exact'] > d['ms_per_step']
+    oc = d['config']['other_configs']
+    for k in ('cfg5', 'cfg3', 'cfg3_full'):
+        assert oc[k]['value'] > 0 and 0 < oc[k]['value_fp32_exact'] < oc[k]['value'], k
+    fr = e3['parity']['free_running']
+    assert fr['stages_1_2_fp32_exact']['fraction_of_pixels_within_1e_4'] > 0.995 or \
+        sum(fr['stages_1_2_fp32_exact']['points_in_different_cells_per_outer_iteration']) > 0
+    assert e3['parity']['max_rel_depth_err_gpu_fp32_exact_vs_cpu'] < 2e-5
 
 
 def test_bench_rank_plumbing_dry_run():
