@@ -103,6 +103,12 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 //     epilogue and barrier, not matrix instructions
 //   EIGHT matrix waves (layers 2 / 3 by channel halves, layers 1 / 4 in column-block pieces on the loader waves)
 //     0.215 | 0.431 | 1.41: every B fragment is then read from LDS by two waves and the kernel becomes LDS-bound
+//   ring rows as planes of 16-byte chunks (kPLS): SQ_LDS_BANK_CONFLICT 1.06e8 -> 2.3e7 per launch, time unchanged           0.163 | 0.343 | 0.98
+//   six matrix waves balanced by COLUMN BLOCKS (no fragment read twice; 135 instead of 162 matrix instructions on the busiest
+//     SIMD, loaders merged into the light waves)                                                         0.200 | 0.400 | 1.10
+//     (exact fp32, where the matrix instructions are 5x longer: 3.14 instead of 3.26 ms) -- with split operands a row is a
+//     serial chain per wave (barrier, first LDS reads, 162 matrix instructions, epilogue, barrier): more work per loader wave
+//     lengthens the slowest chain; what would shorten it is two rows per step, which the LDS does not hold
 template <int G, int LAYER, bool F32, int CB0, int NCB>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
