@@ -109,6 +109,9 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 //     (exact fp32, where the matrix instructions are 5x longer: 3.14 instead of 3.26 ms) -- with split operands a row is a
 //     serial chain per wave (barrier, first LDS reads, 162 matrix instructions, epilogue, barrier): more work per loader wave
 //     lengthens the slowest chain; what would shorten it is two rows per step, which the LDS does not hold
+//   two passes over K (column blocks {0, 1}, then {2} with the first pass's epilogues between its K steps): +-0
+//   the step barrier as `s_waitcnt lgkmcnt(0); s_barrier` instead of __syncthreads() (no wait for the loaders' requests and
+//     layer 4's stores): +-0.  `SQ_VALU_MFMA_BUSY_CYCLES` says 44 % of all SIMD cycles = 62 % on the two SIMDs of layers 2 / 3
 template <int G, int LAYER, bool F32, int CB0, int NCB>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
