@@ -112,6 +112,10 @@ __device__ __forceinline__ void pz_split4(float a, float b, float c, float d, u3
 //   two passes over K (column blocks {0, 1}, then {2} with the first pass's epilogues between its K steps): +-0
 //   the step barrier as `s_waitcnt lgkmcnt(0); s_barrier` instead of __syncthreads() (no wait for the loaders' requests and
 //     layer 4's stores): +-0.  `SQ_VALU_MFMA_BUSY_CYCLES` says 44 % of all SIMD cycles = 62 % on the two SIMDs of layers 2 / 3
+//   ablations (-DV3D_PZ_ABLATE, timing only): two of three products 0.143 | 0.291 | 0.890; NO matrix instructions 0.099 | 0.186 |
+//     0.481 (then a row takes one global-load latency: the loaders' requests); no exp / division in the softmax: +-0.  A row of
+//     the full kernel = the layer-2 / layer-3 wave's chain: barrier -> first fragment reads -> 162 matrix instructions x 16
+//     cycles -> epilogue -> barrier, 1.8 us of which the matrix instructions are ~1.3
 template <int G, int LAYER, bool F32, int CB0, int NCB>
 __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned char* smem, int lane, int item0, int item_step, int n_items) {
   typedef PZ<G> Z;
@@ -210,10 +214,10 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
           } else {
           // three products per (block, co block), round robin over the accumulators (no back-to-back dependent pair)
 #ifndef V3D_PZ_ABLATE
-#define V3D_PZ_ABLATE 0      // developer ablation: 1 = two of the three split products (timing only: is the pipeline matrix-bound?)
+#define V3D_PZ_ABLATE 0      // developer ablations (timing only): 1 = two of the three split products, 2 = none (everything but the matrix instructions), 3 = none and no exp / division in the softmax, 4 = all products but that softmax
 #endif
 #pragma unroll
-          for (int prod = 0; prod < (V3D_PZ_ABLATE == 1 ? 2 : 3); ++prod)
+          for (int prod = 0; prod < ((V3D_PZ_ABLATE == 2 || V3D_PZ_ABLATE == 3) ? 0 : V3D_PZ_ABLATE == 1 ? 2 : 3); ++prod)
 #pragma unroll
             for (int blk = 0; blk < kNBLK; ++blk)
 #pragma unroll
@@ -266,14 +270,14 @@ __device__ __forceinline__ void pz_matrix_role(const PropzParams& p, unsigned ch
             for (int k = 0; k < 9; ++k) m = fmaxf(m, e[k]);
             float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { e[k] = expf(e[k] - m); sum += e[k]; }
+            for (int k = 0; k < 9; ++k) { e[k] = (V3D_PZ_ABLATE >= 3 ? e[k] - m : expf(e[k] - m)); sum += e[k]; }
             const float* const dr = reinterpret_cast<const float*>(smem + Z::DEPTH);
             float o = 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
               const int yy = min(max(r + k / 3 - 1, 0), p.H - 1);
               // (the depth ring's columns are already clamped to the image: slot 1 + c + dx holds x + dx clamped)
-              o += (e[k] / sum) * dr[(yy & (kDR - 1)) * kPSL + 1 + c + (k % 3 - 1)];
+              o += (V3D_PZ_ABLATE >= 3 ? e[k] * sum : e[k] / sum) * dr[(yy & (kDR - 1)) * kPSL + 1 + c + (k % 3 - 1)];
             }
             p.out[((size_t)b * p.H + r) * p.W + x] = o;
           }
