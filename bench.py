@@ -911,6 +911,7 @@ def main():
     ap.add_argument('--host-check-refs', type=int, default=16, help='views also compared with the plain torch oracle of '
                     'this host (-1 = all checked views; the pinned oracle checks every view of the step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32', dest='fp32_exact', action='store_false', help='cfg3/cfg4: skip the exact-fp32 legs (profiling runs)')
     ap.add_argument('--scene-window', default='4,3', help='cfg3/cfg4: source views before,after each reference view '
                     '(4,3 = SURVEY 8d: 1 ref + 7 src; 2,2 = the reference eval script)')
     ap.add_argument('--stage3', action='store_true', help='cfg3/cfg4: include stage 3 (PropagationNet upsampling to full '

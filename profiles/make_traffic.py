@@ -28,6 +28,10 @@ NAMES = [('psv_variance_window_kernel<true, false>', 'psv_variance'), ('psv_vari
          ('gemm_gather_rounds_kernel<2, 2, 4>', 'sparse_conv_gemm'),
          ('backproject_variance_kernel', 'backproject_variance')]
 FETCH_CORRECTION = 2.0
+# kernels whose bulk reads are 4-byte-per-lane loads: FETCH_SIZE is already the byte count (the x2 applies to 16-byte-per-lane reads
+# only).  propz_kernel's loaders read the guide features / image one float per lane (cross-check: its WRITE_SIZE is the output to the
+# byte, its raw FETCH_SIZE 1.3-1.4x the guide + depth bytes -- the 48 / 40 halo columns and the rows the strips share).
+NO_CORRECTION = {'propagation_fused'}
 
 
 def read(path):
@@ -53,7 +57,7 @@ def weighted(path, match):
 # kernel families with several template instances per scene: the sparse convolutions of the U-Net (pipeline kernel, 32- / 64-row
 # tiles, 64 / 128 channels) and the twelve conv launches of stage 3 (FLAT instances of convg_bf16x2_kernel: "..., true> >")
 FAMILIES = [('sparse_conv_gemm', lambda k: 'gemm_gather_pipe_kernel' in k),
-            ('propagation_conv', lambda k: 'convg_bf16x2_kernel' in k and k.rstrip().endswith('true> >')),
+            ('propagation_conv', lambda k: 'convg_bf16x2_kernel' in k and 'deconvg' not in k and k.rstrip().endswith('true> >')),
             # round 6: one row-marching kernel per PropagationNet (csrc/propz.hip), three instances per scene
             ('propagation_fused', lambda k: 'propz_kernel' in k and 'false>' in k)]
 
@@ -67,12 +71,13 @@ def main():
     kernels = {}
     for k in sorted(fetch.keys() | write.keys()):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-        kernels[k] = {'fetch_kb_raw': f, 'write_kb': w, 'fetch_bytes_corrected': FETCH_CORRECTION * f * 1024.0,
-                      'write_bytes': w * 1024.0, 'hbm_bytes': (FETCH_CORRECTION * f + w) * 1024.0}
+        corr = 1.0 if k in NO_CORRECTION else FETCH_CORRECTION
+        kernels[k] = {'fetch_kb_raw': f, 'write_kb': w, 'fetch_bytes_corrected': corr * f * 1024.0,
+                      'write_bytes': w * 1024.0, 'hbm_bytes': (corr * f + w) * 1024.0, 'fetch_correction': corr}
     json.dump({'refs_per_step_per_gpu': int(sys.argv[3]),
                'unit': 'per launch; fetch_kb_raw / write_kb = rocprofv3 FETCH_SIZE / WRITE_SIZE (KB); hbm_bytes = '
                        '(2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction for 16-byte-per-lane reads applied '
-                       'to every kernel (profiles/README.md)',
+                       'to every kernel that reads that way (fetch_correction; profiles/README.md)',
                'kernels': kernels}, open(sys.argv[4], 'w'), indent=1)
 
 

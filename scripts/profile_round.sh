@@ -5,7 +5,7 @@ bash scripts/profile_bench.sh cfg2 64 > gpurun_out/r6_profile_cfg2.log 2>&1
 bash scripts/profile_bench.sh cfg5 8 > gpurun_out/r6_profile_cfg5.log 2>&1
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/profile_cfg3full; T=/tmp/v3dprof_cfg3full; rm -rf $T; mkdir -p $O $T; cd /tmp
-rocprofv3 --kernel-trace --stats -d $T/kt -o r -- python $R/bench.py --config cfg3 --stage3 --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $T/kt -o r -- python $R/bench.py --config cfg3 --stage3 --no-cpu-baseline --no-fp32 --steps 10 --warmup 2 > $O/bench_under_rocprof.log 2>&1
 python $R/profiles/summarize_rocpd.py stats $T/kt/r_results.db $O/kernel_stats.csv
 cd $R; tail -2 gpurun_out/r6_profile_cfg2.log; head -25 gpurun_out/profile_cfg2/kernel_stats.csv | cut -c1-150
 bash scripts/profile_scene_pmc.sh > gpurun_out/r6_profile_cfg3_pmc.log 2>&1

@@ -3,7 +3,7 @@
 # the fused hypothesis decoder and the sparse-conv GEMMs (each --pmc pass its own run) -> gpurun_out/profile_cfg3/.
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/profile_cfg3; T=/tmp/v3dprof_cfg3; rm -rf $T; mkdir -p $O $T; cd /tmp
-B="python $R/bench.py --config cfg3 --stage3 --no-cpu-baseline --steps 3 --warmup 1"
+B="python $R/bench.py --config cfg3 --stage3 --no-cpu-baseline --no-fp32 --steps 3 --warmup 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d $T/$c -o r -- $B > /dev/null 2>&1
   python $R/profiles/summarize_rocpd.py pmc $T/$c/r_results.db $O/pmc_$c.csv
