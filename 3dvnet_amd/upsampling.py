@@ -2,10 +2,12 @@
 ``mv3d/eval-3dvnet.py:101-125``.  Host-side mirror of ``mv3d/subnetworks/upsampling.py::PropagationNet``: same
 constructor, ``forward(features, depth)`` signature and ``state_dict`` keys (``conv{1..4}.{0.weight,1.*}``).
 
-The arithmetic runs in the HIP library (``v3d_propagation_f32``, csrc/costreg.hip): the four 3x3 convolutions on
-split-bf16 matrix cores with eval-mode BatchNorm folded and ReLU in the epilogue, activations between the layers in the
-split channel-last layout, then one kernel for the 9-way softmax and the weighted sum over the replicate-padded 3x3
-depth neighbourhood (no unfold buffer).  No CPU fallback: tensors must live on a HIP device.
+The arithmetic runs in the HIP library (``v3d_propagation_f32`` / ``v3d_propagation_up_f32``, csrc/propz.hip): ONE launch
+per net marches down the image rows with one wave per layer -- the four 3x3 convolutions on matrix cores (split-bf16 or
+exact fp32 operands) with eval-mode BatchNorm folded and ReLU in the epilogue, the activations between the layers in
+LDS rings of four rows, then the 9-way softmax and the weighted sum over the replicate-padded 3x3 depth neighbourhood
+in the last layer's epilogue (no unfold buffer, no intermediate in HBM).  No CPU fallback: tensors must live on a HIP
+device.
 """
 import ctypes
 
