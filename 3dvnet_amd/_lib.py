@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: the lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib3dvnet_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISION = {'split_bf16': 0, 'fp32': 1}      # V3D_PRECISION_* of include/v3d.h
 
 
@@ -117,6 +117,10 @@ SIGNATURES = {
     'v3d_depthwise_nhwc_f32': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_void_p]),
     'v3d_stem_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'v3d_nhwc_to_nchw_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'v3d_irb_pack': (c_int, [c_float_p] * 6 + [c_int] * 6 + [ctypes.POINTER(c_void_p)]),
+    'v3d_irb_free': (None, [c_void_p]),
+    'v3d_irb_supported': (c_int, [c_void_p, c_int, c_int]),
+    'v3d_irb_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
 }

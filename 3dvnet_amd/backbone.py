@@ -189,24 +189,66 @@ class _Depthwise:
         return out
 
 
+class _Block:
+    """An inverted-residual block as ONE kernel (csrc/irb.hip, v3d_irb_*): split-bf16 matrix operands, the expanded tensor never
+    reaches HBM.  ``supported(H, W)`` says whether the library has a kernel instance for this block at that input size."""
+
+    def __init__(self, blk, device):
+        lib = _lib.load()
+        L = blk.layers
+        we, be = _fold(L[0], L[1])
+        wd, bd = _fold(L[3], L[4])
+        wp, bp = _fold(L[6], L[7])
+        mid, cin = we.shape[0], we.shape[1]
+        self.cin, self.mid, self.cout, self.k, self.stride = cin, mid, wp.shape[0], wd.shape[-1], L[3].stride[0]
+        host = [t.float().contiguous().cpu() for t in (we.reshape(mid, cin), be, wd.reshape(mid, -1), bd, wp.reshape(self.cout, mid), bp)]
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.v3d_irb_pack(*[ctypes.cast(t.data_ptr(), _lib.c_float_p) for t in host], cin, mid, self.cout, self.k,
+                                        self.stride, int(blk.apply_residual), ctypes.byref(self.handle)), 'v3d_irb_pack')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None) and self.handle.value and _lib is not None:
+                _lib.load().v3d_irb_free(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def supported(self, H, W):
+        return bool(_lib.load().v3d_irb_supported(self.handle, H, W))
+
+    def __call__(self, x):
+        n, H, W, _ = x.shape
+        s = self.stride
+        out = torch.empty((n, (H + s - 1) // s, (W + s - 1) // s, self.cout), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().v3d_irb_nhwc_f32(self.handle, x.data_ptr(), n, H, W, out.data_ptr(), _lib.stream_ptr(x.device)),
+                   'v3d_irb_nhwc_f32')
+        return out
+
+
 class NativeBackbone:
     """``(feat_extractor, feat_shrinker)`` on the HIP kernels: ``forward(images [n, 3, H, W]) -> (half, quarter, eighth,
     sixteenth, thirtysecond)`` in the reference layout [n, feat_dim, h, w] -- what ``feat_shrinker(*feat_extractor(images))``
     returns (mvsnet.py:66-73, 89-105).  H and W must be multiples of 8 (round 6: the reference's default 240 x 320 gives 15 x 20
     and 8 x 10 maps at 1/16 and 1/32 -- odd sizes are handled by the strided kernels and by the FPN's nearest top-down
-    addition) and ``feat_dim`` a multiple of 32; ``why_not()`` names the reason when a call does not qualify."""
+    addition) and ``feat_dim`` a multiple of 32; ``why_not()`` names the reason when a call does not qualify.
 
-    def __init__(self, feat_extractor, feat_shrinker):
-        self.fe, self.fs = feat_extractor, feat_shrinker
+    ``precision`` (as everywhere in this package): 'split_bf16' runs every inverted-residual block the library has a fused kernel
+    for as ONE launch (csrc/irb.hip); 'fp32' keeps the exact-fp32 three-launch blocks of round 5."""
+
+    def __init__(self, feat_extractor, feat_shrinker, precision='split_bf16'):
+        _lib.precision_code(precision)
+        self.fe, self.fs, self.precision = feat_extractor, feat_shrinker, precision
         self._key, self._ops = None, None
 
     # (the packed kernels' weight images are a cache: a copy of the owning MVSNet packs again)
     def __deepcopy__(self, memo):
         import copy
-        return NativeBackbone(copy.deepcopy(self.fe, memo), copy.deepcopy(self.fs, memo))
+        return NativeBackbone(copy.deepcopy(self.fe, memo), copy.deepcopy(self.fs, memo), self.precision)
 
     def __reduce__(self):
-        return (NativeBackbone, (self.fe, self.fs))
+        return (NativeBackbone, (self.fe, self.fs, self.precision))
 
     def is_package_pair(self):
         """The two modules are this package's own containers (torchvision's module tree restated): the pair the kernels serve."""
@@ -237,7 +279,7 @@ class NativeBackbone:
 
     def _build(self, device):
         from .mvsnet import module_state_key
-        key = (str(device),) + module_state_key(self.fe) + module_state_key(self.fs)
+        key = (str(device), self.precision) + module_state_key(self.fe) + module_state_key(self.fs)
         if key == self._key:
             return self._ops
         l1 = self.fe.layer1
@@ -254,7 +296,7 @@ class NativeBackbone:
                     L = blk.layers
                     wd, bd = _fold(L[3], L[4])
                     blocks.append((_Gemm(*_fold(L[0], L[1]), device), _Depthwise(wd, bd, L[3].stride[0], device), _Gemm(*_fold(L[6], L[7]), device),
-                                   blk.apply_residual))
+                                   blk.apply_residual, _Block(blk, device) if self.precision == 'split_bf16' else None))
             stages.append(blocks)
         ops['stages'] = stages
         fpn = self.fs.fpn
@@ -275,7 +317,10 @@ class NativeBackbone:
         x = ops['stem_pw'](ops['stem_dw'](x, relu=True), relu=False)
         maps = [x]                                                  # C1 .. C5, channels-last
         for blocks in ops['stages']:
-            for expand, dw, project, residual in blocks:
+            for expand, dw, project, residual, fused in blocks:
+                if fused is not None and fused.supported(x.shape[1], x.shape[2]):
+                    x = fused(x)
+                    continue
                 y = project(dw(expand(x, relu=True), relu=True), relu=False, res=x if residual else None, res_mode=1 if residual else 0)
                 x = y
             maps.append(x)

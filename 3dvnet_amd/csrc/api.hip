@@ -8,7 +8,7 @@
 
 #include "v3d_common.h"
 
-extern "C" int v3d_version(void) { return 5; }
+extern "C" int v3d_version(void) { return 6; }
 
 extern "C" const char* v3d_last_error(void) { return v3d::err_buf(); }
 

@@ -451,9 +451,9 @@ class MVSNet(nn.Module):
             # explicit opt-in: `net.native_backbone = False`.  A foreign pair of modules (anything else the caller injected)
             # is the caller's own code and runs as given.
             if getattr(self, '_native_backbone', None) is None or self._native_backbone.fe is not self.feat_extractor \
-                    or self._native_backbone.fs is not self.feat_shrinker:
+                    or self._native_backbone.fs is not self.feat_shrinker or self._native_backbone.precision != self.cnn_3d.precision:
                 from .backbone import NativeBackbone
-                self._native_backbone = NativeBackbone(self.feat_extractor, self.feat_shrinker)
+                self._native_backbone = NativeBackbone(self.feat_extractor, self.feat_shrinker, precision=self.cnn_3d.precision)
             nb = self._native_backbone
             if self.native_backbone and nb.is_package_pair():
                 why = nb.why_not(batch.images)

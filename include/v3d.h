@@ -424,6 +424,22 @@ int v3d_depthwise_nhwc_f32(const float* x, const float* w, const float* bias, in
 int v3d_stem_f32(const float* image, const float* w, const float* bias, int n, int H, int W, float* out, void* stream);
 int v3d_nhwc_to_nchw_f32(const float* in, float* out, int n, int C, int HW, void* stream);
 
+/* An inverted-residual block of the trunk (torchvision mnasnet._InvertedResidual: 1x1 expand + BN + ReLU -> k x k depthwise,
+ * stride s, + BN + ReLU -> 1x1 project + BN, + x when `residual`) as ONE kernel (csrc/irb.hip; ABI version 6, round 6): the
+ * expanded tensor never reaches HBM.  Split-bf16 matrix operands, fp32 depthwise taps; the exact-fp32 block is the three calls above.
+ *   v3d_irb_pack       HOST weights with BatchNorm folded: w_expand [mid, cin], w_dw [mid, k, k], w_project [cout, mid], biases
+ *                      [mid], [mid], [cout]; cin, mid, cout multiples of 8; k 3 | 5; stride 1 | 2; residual needs cin == cout, stride 1
+ *   v3d_irb_supported  1 when a kernel instance exists for this block at input size H x W (the MnasNet-1.0 blocks at image sides
+ *                      that are multiples of 32 and at 240 x 320), else 0: the caller then runs the three-call path
+ *   v3d_irb_nhwc_f32   x [n, H, W, cin] -> out [n, ceil(H / s), ceil(W / s), cout], channels-last fp32 */
+typedef struct v3d_irb_weights v3d_irb_weights;
+int v3d_irb_pack(const float* w_expand, const float* b_expand, const float* w_dw, const float* b_dw, const float* w_project,
+                 const float* b_project, int cin, int mid, int cout, int ksize, int stride, int residual,
+                 v3d_irb_weights** out_handle);
+void v3d_irb_free(v3d_irb_weights* handle);
+int v3d_irb_supported(const v3d_irb_weights* handle, int H, int W);
+int v3d_irb_nhwc_f32(const v3d_irb_weights* handle, const float* x, int n, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
