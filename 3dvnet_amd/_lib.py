@@ -121,6 +121,9 @@ SIGNATURES = {
     'v3d_irb_free': (None, [c_void_p]),
     'v3d_irb_supported': (c_int, [c_void_p, c_int, c_int]),
     'v3d_irb_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'v3d_fpn_pack': (c_int, [c_float_p] * 4 + [c_int, ctypes.POINTER(c_void_p)]),
+    'v3d_fpn_free': (None, [c_void_p]),
+    'v3d_fpn_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'v3d_decoder_head_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
 }

@@ -227,6 +227,41 @@ class _Block:
         return out
 
 
+class _PyramidLevel:
+    """One level of the feature pyramid as ONE kernel (csrc/fpn.hip, v3d_fpn_*): lateral 1x1 + top-down addition + 3x3 output
+    convolution, the result in the reference layout; feat_dim 32 and at most 48 input channels (the three fine levels)."""
+
+    @staticmethod
+    def fits(lateral, output):
+        return lateral.out_channels == 32 and output.out_channels == 32 and lateral.in_channels % 8 == 0 and lateral.in_channels <= 48
+
+    def __init__(self, lateral, output, device):
+        lib = _lib.load()
+        self.cin = lateral.in_channels
+        host = [t.detach().float().contiguous().cpu() for t in (lateral.weight.reshape(32, self.cin), lateral.bias, output.weight, output.bias)]
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.v3d_fpn_pack(*[ctypes.cast(t.data_ptr(), _lib.c_float_p) for t in host], self.cin, ctypes.byref(self.handle)),
+                       'v3d_fpn_pack')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None) and self.handle.value and _lib is not None:
+                _lib.load().v3d_fpn_free(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def __call__(self, x, coarse_inner, want_inner):
+        """x [n, H, W, cin], coarse_inner [n, ceil(H/2), ceil(W/2), 32] or None -> (inner [n, H, W, 32] or None, out [n, 32, H, W])"""
+        n, H, W, _ = x.shape
+        inner = torch.empty((n, H, W, 32), dtype=torch.float32, device=x.device) if want_inner else None
+        out = torch.empty((n, 32, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().v3d_fpn_level_f32(self.handle, x.data_ptr(), _lib.ptr(coarse_inner), n, H, W, _lib.ptr(inner), out.data_ptr(),
+                                                 _lib.stream_ptr(x.device)), 'v3d_fpn_level_f32')
+        return inner, out
+
+
 class NativeBackbone:
     """``(feat_extractor, feat_shrinker)`` on the HIP kernels: ``forward(images [n, 3, H, W]) -> (half, quarter, eighth,
     sixteenth, thirtysecond)`` in the reference layout [n, feat_dim, h, w] -- what ``feat_shrinker(*feat_extractor(images))``
@@ -302,6 +337,8 @@ class NativeBackbone:
         fpn = self.fs.fpn
         ops['inner'] = [_Gemm(m.weight.detach(), m.bias.detach(), device) for m in fpn.inner_blocks]
         ops['outer'] = [_Gemm(m.weight.detach(), m.bias.detach(), device) for m in fpn.layer_blocks]
+        ops['level'] = [_PyramidLevel(a, b, device) if self.precision == 'split_bf16' and i < 3 and _PyramidLevel.fits(a, b) else None
+                        for i, (a, b) in enumerate(zip(fpn.inner_blocks, fpn.layer_blocks))]
         self._key, self._ops = key, ops
         return ops
 
@@ -328,10 +365,16 @@ class NativeBackbone:
         outs = [None] * 5
         outs[4] = ops['outer'][4](inner)
         for i in (3, 2, 1, 0):
+            if ops['level'][i] is not None:                         # one launch, the result already in the reference layout
+                inner, outs[i] = ops['level'][i](maps[i], inner, want_inner=i > 0)
+                continue
             inner = ops['inner'][i](maps[i], res=inner, res_mode=2)
             outs[i] = ops['outer'][i](inner)
         res = []
-        for o in outs:                                              # -> the reference layout [n, C, h, w]
+        for i, o in enumerate(outs):                                # -> the reference layout [n, C, h, w]
+            if ops['level'][i] is not None:
+                res.append(o)
+                continue
             nn_, h, w, c = o.shape
             t = torch.empty((nn_, c, h, w), dtype=torch.float32, device=dev)
             _lib.check(lib.v3d_nhwc_to_nchw_f32(o.data_ptr(), t.data_ptr(), nn_, c, h * w, _lib.stream_ptr(dev)), 'v3d_nhwc_to_nchw_f32')

@@ -440,6 +440,20 @@ void v3d_irb_free(v3d_irb_weights* handle);
 int v3d_irb_supported(const v3d_irb_weights* handle, int H, int W);
 int v3d_irb_nhwc_f32(const v3d_irb_weights* handle, const float* x, int n, int H, int W, float* out, void* stream);
 
+
+/* One level of the feature pyramid (torchvision FeaturePyramidNetwork, mvsnet.py:83-105) as ONE kernel (csrc/fpn.hip; ABI version 6):
+ * inner = lateral 1x1 (x) + bias + nearest-upsampled inner of the coarser level; out = 3x3 / pad 1 (inner) + bias, written in the
+ * reference layout.  feat_dim 32, cin a multiple of 8 and <= 48 (the levels at 1/2, 1/4, 1/8); split-bf16 matrix operands.
+ *   v3d_fpn_pack       HOST w_lateral [32, cin], b_lateral [32], w_out [32, 32, 3, 3], b_out [32]
+ *   v3d_fpn_level_f32  x [n, H, W, cin] channels-last; coarse_inner [n, ceil(H/2), ceil(W/2), 32] channels-last or NULL;
+ *                      inner_out [n, H, W, 32] channels-last or NULL (not needed for the finest level); out [n, 32, H, W] */
+typedef struct v3d_fpn_weights v3d_fpn_weights;
+int v3d_fpn_pack(const float* w_lateral, const float* b_lateral, const float* w_out, const float* b_out, int cin,
+                 v3d_fpn_weights** out_handle);
+void v3d_fpn_free(v3d_fpn_weights* handle);
+int v3d_fpn_level_f32(const v3d_fpn_weights* handle, const float* x, const float* coarse_inner, int n, int H, int W,
+                      float* inner_out, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

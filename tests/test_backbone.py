@@ -310,3 +310,43 @@ def test_fused_block_reports_what_it_cannot_take(cuda):
     assert not fused.supported(32, 40)
     with pytest.raises(libm.V3DLibraryError):
         fused(torch.zeros(1, 32, 40, 64, device=cuda))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,H,W,coarse,want_inner', [(16, 128, 160, True, False), (24, 64, 80, True, True), (40, 32, 40, True, True),
+                                                       (24, 60, 80, True, True), (16, 23, 37, True, True), (40, 8, 16, False, True),
+                                                       (8, 5, 3, True, False), (48, 15, 20, True, True)])
+def test_pyramid_level_kernel(cin, H, W, coarse, want_inner, cuda):
+    """csrc/fpn.hip through the C ABI (v3d_fpn_pack / v3d_fpn_level_f32) against torch on the CPU: lateral 1x1 + bias + nearest-
+    upsampled coarser inner map (ceil(H/2) x ceil(W/2), even and odd sides) -> 3x3 / pad 1 + bias, the result in the reference
+    layout; ragged tiles, images smaller than a tile, the level without a coarser one, the inner map only where asked for; 2e-5 of the
+    range (split-bf16 operands); repeated launches bit-identical."""
+    bb = v3d('backbone')
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    lat = torch.nn.Conv2d(cin, 32, 1)
+    outc = torch.nn.Conv2d(32, 32, 3, padding=1)
+    with torch.no_grad():
+        for m in (lat, outc):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.2)
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g))
+    n = 3
+    x = torch.randn(n, H, W, cin, generator=g)
+    ci = torch.randn(n, (H + 1) // 2, (W + 1) // 2, 32, generator=g) if coarse else None
+    with torch.no_grad():
+        inner_ref = lat(x.permute(0, 3, 1, 2))
+        if coarse:
+            inner_ref = inner_ref + torch.nn.functional.interpolate(ci.permute(0, 3, 1, 2), size=(H, W), mode='nearest')
+        out_ref = outc(inner_ref)
+    assert bb._PyramidLevel.fits(lat, outc)
+    lvl = bb._PyramidLevel(lat, outc, cuda)
+    inner, out = lvl(x.to(cuda), ci.to(cuda) if coarse else None, want_inner)
+    inner2, out2 = lvl(x.to(cuda), ci.to(cuda) if coarse else None, want_inner)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (n, 32, H, W) and torch.isfinite(out).all()
+    assert float((out.cpu() - out_ref).abs().max() / out_ref.abs().max()) < 2e-5
+    assert torch.equal(out, out2)
+    if want_inner:
+        assert float((inner.cpu().permute(0, 3, 1, 2) - inner_ref).abs().max() / inner_ref.abs().max()) < 2e-5
+        assert torch.equal(inner, inner2)
+    else:
+        assert inner is None
