@@ -222,7 +222,10 @@ class _Block:
         n, H, W, _ = x.shape
         s = self.stride
         out = torch.empty((n, (H + s - 1) // s, (W + s - 1) // s, self.cout), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().v3d_irb_nhwc_f32(self.handle, x.data_ptr(), n, H, W, out.data_ptr(), _lib.stream_ptr(x.device)),
+        lib = _lib.load()
+        nbytes = lib.v3d_irb_workspace_bytes(self.handle, n, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None      # (the caching allocator: no device call)
+        _lib.check(lib.v3d_irb_nhwc_f32(self.handle, x.data_ptr(), n, H, W, out.data_ptr(), _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device)),
                    'v3d_irb_nhwc_f32')
         return out
 

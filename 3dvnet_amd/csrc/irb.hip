@@ -53,6 +53,8 @@ struct IrbParams {
   const char* pw;        // [ns][ncbo][2 steps][hi, lo][64 lanes][16 B]
   const float* bp;       // [ncbo * 32]
   int n, H, W, Ho, Wo, cin, cout, ns, residual, tiles_x, tiles_y;
+  int nsg;               // slice groups: workgroup (tile, group) walks ns / nsg slices and leaves a partial sum in `part`
+  float* part;           // [nsg][n * Ho * Wo][cout] when nsg > 1
 };
 
 __device__ __forceinline__ unsigned irb_pack_bf16x2(float a, float b) {
@@ -137,6 +139,9 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, i = lane & 31;
   int b = v3d::xcd_contiguous_block();
+  const int sg = b % p.nsg;                               // (the groups of a tile are neighbours: they read the same input rows)
+  b /= p.nsg;
+  const int s_begin = (p.ns * sg) / p.nsg, s_end = (p.ns * (sg + 1)) / p.nsg;
   const int tx0 = (b % p.tiles_x) * TW;
   b /= p.tiles_x;
   const int ty0 = (b % p.tiles_y) * C::TH;
@@ -167,10 +172,11 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   {
     u32x4 xw0[C::NXP], pw0[NCBO], dw0;
 #pragma unroll
-    for (int k = 0; k < C::NXP; ++k) xw0[k] = reinterpret_cast<const u32x4*>(p.xw)[min(tid + 256 * k, C::XW_BYTES / 16 - 1)];
+    for (int k = 0; k < C::NXP; ++k)
+      xw0[k] = reinterpret_cast<const u32x4*>(p.xw + (size_t)s_begin * C::XW_BYTES)[min(tid + 256 * k, C::XW_BYTES / 16 - 1)];
 #pragma unroll
-    for (int k = 0; k < NCBO; ++k) pw0[k] = reinterpret_cast<const u32x4*>(p.pw)[tid + 256 * k];
-    dw0 = reinterpret_cast<const u32x4*>(p.dw)[min(tid, C::DW_BYTES / 16 - 1)];
+    for (int k = 0; k < NCBO; ++k) pw0[k] = reinterpret_cast<const u32x4*>(p.pw + (size_t)s_begin * C::PW_BYTES)[tid + 256 * k];
+    dw0 = reinterpret_cast<const u32x4*>(p.dw + (size_t)s_begin * C::DW_BYTES)[min(tid, C::DW_BYTES / 16 - 1)];
     // ... and the LDS set-up while they travel
     for (int k = tid; k < C::E_BYTES / 16; k += 256) reinterpret_cast<u32x4*>(E)[k] = (u32x4){0u, 0u, 0u, 0u};
     for (int k = tid; k < C::D_BYTES / 16; k += 256) reinterpret_cast<u32x4*>(D)[k] = (u32x4){0u, 0u, 0u, 0u};
@@ -209,8 +215,8 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   const unsigned e_lds = irb_lds_addr(E), dw_lds = irb_lds_addr(DWL), ro_lds = irb_lds_addr(rowofs);
   u32x4 pw_reg[NCBO];                                     // the NEXT slice's project image, a whole slice in flight
 #pragma unroll 1
-  for (int s = 0; s < p.ns; ++s) {
-    const bool more = s + 1 < p.ns;
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool more = s + 1 < s_end;
     // (1) the next slice's images on their way.  Expand + depthwise (s + 1) are parked in LDS behind this slice's W; the project
     // image (s + 1) behind the NEXT slice's first barrier, when every wave is done with P (s).
     u32x4 xw_reg[C::NXP], dw_reg;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
     IRB_PH(1);
     __syncthreads();
     // (4) every wave is done with P (s - 1): the project image of this slice (requested a slice ago) takes its buffer
-    if (s > 0) {
+    if (s > s_begin) {
 #pragma unroll
       for (int k = 0; k < NCBO; ++k) reinterpret_cast<u32x4*>(PW)[tid + 256 * k] = pw_reg[k];
     }
@@ -364,6 +370,10 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
       const int oy = ty0 + ty, ox = tx0 + tx;
       if (t >= C::T || oy >= p.Ho || ox >= p.Wo) continue;
       const size_t idx = ((size_t)(img * p.Ho + oy) * p.Wo + ox) * p.cout + co;
+      if (p.nsg > 1) {                                     // partial sum of this slice group; irb_reduce_kernel finishes
+        p.part[(size_t)sg * ((size_t)p.n * p.Ho * p.Wo * p.cout) + idx] = pacc[q][r16];
+        continue;
+      }
       float v = pacc[q][r16] + bs;
       if (p.residual) v += p.x[idx];
       p.out[idx] = v;
@@ -371,6 +381,18 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   }
   IRB_PH(6);
   IRB_PH_FLUSH;
+}
+
+// out = sum of the slice groups' partial sums (in group order) + bias (+ x): one thread per 4 output channels
+__global__ __launch_bounds__(256) void irb_reduce_kernel(const float* __restrict__ part, int nsg, size_t total, const float* __restrict__ bias,
+                                                         const float* __restrict__ x, int cout, float* __restrict__ out) {
+  const size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (k >= total) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + k);
+  for (int g = 1; g < nsg; ++g) v += *reinterpret_cast<const f32x4*>(part + (size_t)g * total + k);
+  v += *reinterpret_cast<const f32x4*>(bias + k % (size_t)cout);
+  if (x) v += *reinterpret_cast<const f32x4*>(x + k);
+  *reinterpret_cast<f32x4*>(out + k) = v;
 }
 
 unsigned irb_rne(float x) {
@@ -398,9 +420,8 @@ const IrbVariant kIrbVariants[] = {
     V3D_IRB_VARIANT(3, 2, 1, 8, 1, 3, 2),   V3D_IRB_VARIANT(3, 1, 1, 8, 2, 1, 3),   V3D_IRB_VARIANT(5, 2, 2, 8, 2, 3, 2),
     V3D_IRB_VARIANT(5, 1, 2, 8, 3, 2, 2),   V3D_IRB_VARIANT(5, 2, 3, 10, 3, 4, 2),  V3D_IRB_VARIANT(5, 1, 3, 10, 5, 1, 2),
     V3D_IRB_VARIANT(3, 1, 3, 10, 5, 1, 2),  V3D_IRB_VARIANT(3, 1, 3, 10, 6, 1, 2),
-#ifdef V3D_IRB_LOWRES      // the 1/32-resolution blocks: one tile per image = 71 workgroups; measured slower than the three launches
+    // the 1/32-resolution blocks: one tile per image; the expanded channels are shared out over slice groups (irb_groups)
     V3D_IRB_VARIANT(5, 2, 6, 10, 6, 3, 1),  V3D_IRB_VARIANT(5, 1, 6, 10, 12, 1, 1), V3D_IRB_VARIANT(3, 1, 10, 10, 12, 1, 1),
-#endif
 };
 #undef V3D_IRB_VARIANT
 
@@ -512,12 +533,35 @@ extern "C" int v3d_debug_irb_phase(unsigned long long* out8, int reset) {
 }
 #endif
 
+namespace {
+// Slice groups per tile: a map with fewer tiles than the chip has CUs (71 images of 8 x 10 = 71 tiles) hands the slices of a tile to
+// several workgroups, as many as keep every workgroup on its own CU; their partial sums meet in the workspace.
+int irb_groups(const v3d_irb_weights* h, long long tiles) {
+  int n_cu = (int)v3d::persistent_grid(1 << 20, 1);
+  long long g = n_cu / (tiles > 0 ? tiles : 1);
+  if (g > h->ns / 4) g = h->ns / 4;                       // at least four slices per group: the prologue is paid per group
+  return g < 1 ? 1 : (int)g;
+}
+}  // namespace
+
+// bytes of workspace v3d_irb_nhwc_f32 needs for n images of H x W (0 for most maps)
+extern "C" size_t v3d_irb_workspace_bytes(const v3d_irb_weights* h, int n, int H, int W) {
+  if (!h || n <= 0 || H <= 0 || W <= 0) return 0;
+  const IrbVariant* v = irb_pick(h, H, W);
+  if (!v) return 0;
+  const int Ho = (H + h->stride - 1) / h->stride, Wo = (W + h->stride - 1) / h->stride;
+  const long long tiles = (long long)n * ((Wo + v->tw - 1) / v->tw) * ((Ho + 7) / 8);
+  const int nsg = irb_groups(h, tiles);
+  return nsg > 1 ? (size_t)nsg * n * Ho * Wo * h->cout * sizeof(float) : 0;
+}
+
 // 1 when v3d_irb_nhwc_f32 has a kernel for this block at input size H x W
 extern "C" int v3d_irb_supported(const v3d_irb_weights* h, int H, int W) {
   return h && H >= 1 && W >= 1 && irb_pick(h, H, W) != nullptr;
 }
 
-extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n, int H, int W, float* out, void* stream) {
+extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n, int H, int W, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(h && x && out, V3D_ERR_BAD_ARG, "v3d_irb_nhwc_f32: null argument");
   V3D_REQUIRE(n >= 0 && H >= 1 && W >= 1, V3D_ERR_BAD_SHAPE, "v3d_irb_nhwc_f32: n=%d H=%d W=%d", n, H, W);
   V3D_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, V3D_ERR_BAD_ARG, "v3d_irb_nhwc_f32: x must be 16-byte aligned");
@@ -531,7 +575,13 @@ extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n,
   p.n = n; p.H = H; p.W = W; p.Ho = (H + h->stride - 1) / h->stride; p.Wo = (W + h->stride - 1) / h->stride;
   p.cin = h->cin; p.cout = h->cout; p.ns = h->ns; p.residual = h->residual;
   p.tiles_x = (p.Wo + v->tw - 1) / v->tw; p.tiles_y = (p.Ho + 7) / 8;
-  const long long blocks = (long long)n * p.tiles_x * p.tiles_y;
+  const long long tiles = (long long)n * p.tiles_x * p.tiles_y;
+  p.nsg = irb_groups(h, tiles);
+  p.part = reinterpret_cast<float*>(workspace);
+  const size_t need = p.nsg > 1 ? (size_t)p.nsg * n * p.Ho * p.Wo * h->cout * sizeof(float) : 0;
+  V3D_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && (reinterpret_cast<size_t>(workspace) & 15) == 0)), V3D_ERR_BAD_ARG,
+              "v3d_irb_nhwc_f32: workspace of %zu bytes, %zu needed (v3d_irb_workspace_bytes), 16-byte aligned", workspace_bytes, need);
+  const long long blocks = tiles * p.nsg;
   V3D_REQUIRE(blocks < (1ll << 31) && (long long)n * H * W * (h->cin > h->cout ? h->cin : h->cout) < (1ll << 40), V3D_ERR_BAD_SHAPE,
               "v3d_irb_nhwc_f32: %lld tiles", blocks);
   hipStream_t s = (hipStream_t)stream;
@@ -547,5 +597,10 @@ extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n,
   v3d::TimedScope ts("backbone_block", s);
   v->kernel<<<(unsigned)blocks, 256, v->lds, s>>>(p);
   V3D_CHECK_LAUNCH("irb_kernel");
+  if (p.nsg > 1) {
+    const size_t total = (size_t)n * p.Ho * p.Wo * h->cout;
+    irb_reduce_kernel<<<(unsigned)((total / 4 + 255) / 256), 256, 0, s>>>(p.part, p.nsg, total, p.bp, h->residual ? x : nullptr, h->cout, out);
+    V3D_CHECK_LAUNCH("irb_reduce_kernel");
+  }
   return V3D_OK;
 }

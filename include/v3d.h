@@ -431,14 +431,19 @@ int v3d_nhwc_to_nchw_f32(const float* in, float* out, int n, int C, int HW, void
  *                      [mid], [mid], [cout]; cin, mid, cout multiples of 8; k 3 | 5; stride 1 | 2; residual needs cin == cout, stride 1
  *   v3d_irb_supported  1 when a kernel instance exists for this block at input size H x W (the MnasNet-1.0 blocks at image sides
  *                      that are multiples of 32 and at 240 x 320), else 0: the caller then runs the three-call path
- *   v3d_irb_nhwc_f32   x [n, H, W, cin] -> out [n, ceil(H / s), ceil(W / s), cout], channels-last fp32 */
+ *   v3d_irb_nhwc_f32   x [n, H, W, cin] -> out [n, ceil(H / s), ceil(W / s), cout], channels-last fp32; `workspace` of
+ *                      v3d_irb_workspace_bytes(handle, n, H, W) bytes (16-byte aligned; 0 bytes / NULL for most maps): a map with fewer
+ *                      tiles than the chip has CUs (71 images at 1/32 resolution) shares a tile's expanded channels out over several
+ *                      workgroups whose partial sums meet there, summed in a fixed order by a second launch */
 typedef struct v3d_irb_weights v3d_irb_weights;
 int v3d_irb_pack(const float* w_expand, const float* b_expand, const float* w_dw, const float* b_dw, const float* w_project,
                  const float* b_project, int cin, int mid, int cout, int ksize, int stride, int residual,
                  v3d_irb_weights** out_handle);
 void v3d_irb_free(v3d_irb_weights* handle);
 int v3d_irb_supported(const v3d_irb_weights* handle, int H, int W);
-int v3d_irb_nhwc_f32(const v3d_irb_weights* handle, const float* x, int n, int H, int W, float* out, void* stream);
+size_t v3d_irb_workspace_bytes(const v3d_irb_weights* handle, int n, int H, int W);
+int v3d_irb_nhwc_f32(const v3d_irb_weights* handle, const float* x, int n, int H, int W, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 
 /* One level of the feature pyramid (torchvision FeaturePyramidNetwork, mvsnet.py:83-105) as ONE kernel (csrc/fpn.hip; ABI version 6):

@@ -260,6 +260,8 @@ def test_conv_entry_point_against_the_plain_convolution(taps, cin, cout, H, W, r
 
 BLOCKS = [(16, 24, 3, 2, 3, 128, 160), (24, 24, 3, 1, 3, 64, 80), (24, 40, 5, 2, 3, 64, 80), (40, 40, 5, 1, 3, 32, 40), (40, 80, 5, 2, 6, 32, 40),
           (80, 80, 5, 1, 6, 16, 20), (80, 96, 3, 1, 6, 16, 20), (96, 96, 3, 1, 6, 16, 20),
+          # 1/32 resolution: few tiles, the expanded channels of a tile shared out over slice groups + the reducing launch
+          (96, 192, 5, 2, 6, 16, 20), (192, 192, 5, 1, 6, 8, 10), (192, 320, 3, 1, 6, 8, 10), (96, 192, 5, 2, 6, 15, 20),
           # the reference's default 240 x 320 (odd 15 x 20 level, ragged tiles) and sizes whose tiles hang over two borders
           (16, 24, 3, 2, 3, 120, 160), (24, 24, 3, 1, 3, 60, 80), (40, 40, 5, 1, 3, 30, 40), (80, 80, 5, 1, 6, 15, 20), (40, 80, 5, 2, 6, 30, 40),
           (24, 24, 3, 1, 3, 13, 19), (24, 40, 5, 2, 3, 21, 11), (40, 40, 5, 1, 3, 9, 9), (16, 24, 3, 2, 3, 24, 40)]
