@@ -121,6 +121,8 @@ SIGNATURES = {
     'v3d_irb_free': (None, [c_void_p]),
     'v3d_irb_supported': (c_int, [c_void_p, c_int, c_int]),
     'v3d_irb_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    'v3d_stem_block_pack': (c_int, [c_float_p] * 6 + [ctypes.POINTER(c_void_p)]),
+    'v3d_stem_block_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'v3d_irb_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'v3d_fpn_pack': (c_int, [c_float_p] * 4 + [c_int, ctypes.POINTER(c_void_p)]),
     'v3d_fpn_free': (None, [c_void_p]),

@@ -230,6 +230,37 @@ class _Block:
         return out
 
 
+class _StemBlock:
+    """``FeatureExtractor.layer1`` (mnasnet layers 0-7: stem convolution, depthwise, pointwise; image -> 16 channels at half
+    resolution) as ONE kernel (csrc/irb.hip, v3d_stem_block_*), split-bf16 matrix operands."""
+
+    def __init__(self, layer1, device):
+        lib = _lib.load()
+        ws, bs = _fold(layer1[0], layer1[1])
+        wd, bd = _fold(layer1[3], layer1[4])
+        wp, bp = _fold(layer1[6], layer1[7])
+        host = [t.float().contiguous().cpu() for t in (ws.reshape(32, 27), bs, wd.reshape(32, 9), bd, wp.reshape(16, 32), bp)]
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.v3d_stem_block_pack(*[ctypes.cast(t.data_ptr(), _lib.c_float_p) for t in host], ctypes.byref(self.handle)),
+                       'v3d_stem_block_pack')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None) and self.handle.value and _lib is not None:
+                _lib.load().v3d_irb_free(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def __call__(self, img):
+        n, _, H, W = img.shape
+        out = torch.empty((n, H // 2, W // 2, 16), dtype=torch.float32, device=img.device)
+        _lib.check(_lib.load().v3d_stem_block_f32(self.handle, img.data_ptr(), n, H, W, out.data_ptr(), _lib.stream_ptr(img.device)),
+                   'v3d_stem_block_f32')
+        return out
+
+
 class _PyramidLevel:
     """One level of the feature pyramid as ONE kernel (csrc/fpn.hip, v3d_fpn_*): lateral 1x1 + top-down addition + 3x3 output
     convolution, the result in the reference layout; feat_dim 32 and at most 48 input channels (the three fine levels)."""
@@ -326,6 +357,7 @@ class NativeBackbone:
         w1, b1 = _fold(l1[3], l1[4])
         ops['stem_dw'] = _Depthwise(w1, b1, 1, device)
         ops['stem_pw'] = _Gemm(*_fold(l1[6], l1[7]), device)
+        ops['stem_block'] = _StemBlock(l1, device) if self.precision == 'split_bf16' else None
         stages = []
         for layer in (self.fe.layer2, self.fe.layer3, self.fe.layer4, self.fe.layer5):
             blocks = []
@@ -351,10 +383,13 @@ class NativeBackbone:
         ops = self._build(dev)
         img = images.contiguous().float()
         n, _, H, W = img.shape
-        x = torch.empty((n, H // 2, W // 2, 32), dtype=torch.float32, device=dev)
-        _lib.check(lib.v3d_stem_f32(img.data_ptr(), ops['stem_w'].data_ptr(), ops['stem_b'].data_ptr(), n, H, W, x.data_ptr(),
-                                    _lib.stream_ptr(dev)), 'v3d_stem_f32')
-        x = ops['stem_pw'](ops['stem_dw'](x, relu=True), relu=False)
+        if ops['stem_block'] is not None:
+            x = ops['stem_block'](img)
+        else:
+            x = torch.empty((n, H // 2, W // 2, 32), dtype=torch.float32, device=dev)
+            _lib.check(lib.v3d_stem_f32(img.data_ptr(), ops['stem_w'].data_ptr(), ops['stem_b'].data_ptr(), n, H, W, x.data_ptr(),
+                                        _lib.stream_ptr(dev)), 'v3d_stem_f32')
+            x = ops['stem_pw'](ops['stem_dw'](x, relu=True), relu=False)
         maps = [x]                                                  # C1 .. C5, channels-last
         for blocks in ops['stages']:
             for expand, dw, project, residual, fused in blocks:

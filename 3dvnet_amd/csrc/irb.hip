@@ -28,12 +28,15 @@
 #include "v3d_common.h"
 
 struct v3d_irb_weights {
-  int cin, mid, cout, ks, stride, residual;
+  int cin, mid, cout, ks, stride, residual, stem;
   int ns, csteps, ncbo;              // slices of 32 expanded channels, 16-channel K steps of the expansion, 32-channel blocks of cout
   char* dev;
   size_t xw_ofs, dw_ofs, pw_ofs, bp_ofs;
   size_t xw_slice, dw_slice, pw_slice;
 };
+
+int v3d_irb_launch(const v3d_irb_weights* h, const float* x, int n, int H, int W, int ih, int iw, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 namespace {
 
@@ -53,6 +56,7 @@ struct IrbParams {
   const char* pw;        // [ns][ncbo][2 steps][hi, lo][64 lanes][16 B]
   const float* bp;       // [ncbo * 32]
   int n, H, W, Ho, Wo, cin, cout, ns, residual, tiles_x, tiles_y;
+  int ih, iw;            // STEM: the image's sides (x = image [n, 3, ih, iw], H x W = the stem convolution's output)
   int nsg;               // slice groups: workgroup (tile, group) walks ns / nsg slices and leaves a partial sum in `part`
   float* part;           // [nsg][n * Ho * Wo][cout] when nsg > 1
 };
@@ -123,7 +127,10 @@ __device__ unsigned long long g_irb_phase[8];
 
 // OCC: waves per SIMD the register allocation must leave room for (= workgroups per CU; the high-resolution blocks have many small
 // tiles and hide each other's barriers and LDS round trips, the low-resolution ones have one tile per CU at most)
-template <int KS, int S, int NCBO, int TW, int CSTEPS, int RBW, int OCC>
+// STEM: the block is the trunk's first three layers (mvsnet.py:60, torchvision mnasnet layers 0-7): the "expansion" is the 3x3 /
+// stride 2 / pad 1 convolution 3 -> 32 of the NCHW image -- its 27 (channel, ky, kx) taps gathered as the K dimension of the same
+// matrix product -- followed by the 3x3 depthwise and the 1x1 projection to 16 channels.
+template <int KS, int S, int NCBO, int TW, int CSTEPS, int RBW, int OCC, bool STEM = false>
 __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   using C = IrbCfg<KS, S, NCBO, TW, CSTEPS, RBW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,6 +167,21 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
   for (int q = 0; q < RBW; ++q) {
     const int v = min((wave + 4 * q) * 32 + i, nv - 1);
     const int vy = vy0 + v / vw, vx = vx0 + v % vw;
+    if constexpr (STEM) {
+      // k = 16 st + 8 g + e = 9 c + 3 ky + kx: pixel (2 vy + ky - 1, 2 vx + kx - 1) of channel c, zero outside the image / for k >= 27
+      const float* const im = p.x + (size_t)img * 3 * p.ih * p.iw;
+#pragma unroll
+      for (int st = 0; st < CSTEPS; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ka = 16 * st + e, kb = ka + 8;                        // the lane's k for g = 0 / 1
+          const int c = g ? kb / 9 : ka / 9, ky = g ? (kb % 9) / 3 : (ka % 9) / 3, kx = g ? kb % 3 : ka % 3;
+          const int iy = 2 * vy + ky - 1, ix = 2 * vx + kx - 1;
+          const bool ok = (g ? kb : ka) < 27 && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
+          const float v = im[((size_t)(ok ? c : 0) * p.ih + (ok ? iy : 0)) * p.iw + (ok ? ix : 0)];
+          araw[q][st][e >> 2][e & 3] = ok ? v : 0.f;
+        }
+    } else {
     const float* const xr = p.x + ((size_t)(img * p.H + vy) * p.W + vx) * p.cin;
 #pragma unroll
     for (int st = 0; st < CSTEPS; ++st) {
@@ -167,6 +189,7 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
       const int ko = k0 < p.cin ? k0 : 0;              // (cin is a multiple of 8: the eight channels are inside or outside together)
       araw[q][st][0] = *reinterpret_cast<const f32x4*>(xr + ko);
       araw[q][st][1] = *reinterpret_cast<const f32x4*>(xr + ko + 4);
+    }
     }
   }
   {
@@ -410,13 +433,14 @@ float irb_bf16_value(unsigned h) {
 // the instantiations the MnasNet-1.0 trunk needs at image sides that are multiples of 32 (and at 240 x 320); anything else takes
 // the three-launch path
 struct IrbVariant {
-  int ks, s, ncbo, tw, csteps, rbw;
+  int stem, ks, s, ncbo, tw, csteps, rbw;
   void (*kernel)(IrbParams);
   int lds;
 };
 #define V3D_IRB_VARIANT(KS_, S_, NCBO_, TW_, CSTEPS_, RBW_, OCC_) \
-  {KS_, S_, NCBO_, TW_, CSTEPS_, RBW_, irb_kernel<KS_, S_, NCBO_, TW_, CSTEPS_, RBW_, OCC_>, IrbCfg<KS_, S_, NCBO_, TW_, CSTEPS_, RBW_>::LDS}
+  {0, KS_, S_, NCBO_, TW_, CSTEPS_, RBW_, irb_kernel<KS_, S_, NCBO_, TW_, CSTEPS_, RBW_, OCC_>, IrbCfg<KS_, S_, NCBO_, TW_, CSTEPS_, RBW_>::LDS}
 const IrbVariant kIrbVariants[] = {
+    {1, 3, 1, 1, 8, 2, 1, irb_kernel<3, 1, 1, 8, 2, 1, 3, true>, IrbCfg<3, 1, 1, 8, 2, 1>::LDS},      // the stem
     V3D_IRB_VARIANT(3, 2, 1, 8, 1, 3, 2),   V3D_IRB_VARIANT(3, 1, 1, 8, 2, 1, 3),   V3D_IRB_VARIANT(5, 2, 2, 8, 2, 3, 2),
     V3D_IRB_VARIANT(5, 1, 2, 8, 3, 2, 2),   V3D_IRB_VARIANT(5, 2, 3, 10, 3, 4, 2),  V3D_IRB_VARIANT(5, 1, 3, 10, 5, 1, 2),
     V3D_IRB_VARIANT(3, 1, 3, 10, 5, 1, 2),  V3D_IRB_VARIANT(3, 1, 3, 10, 6, 1, 2),
@@ -446,7 +470,7 @@ const IrbVariant* irb_pick(const v3d_irb_weights* h, int H, int W) {
   const int pref = (Wo % 10 == 0 && Wo <= 20) ? 10 : 8;
   for (int tw : {pref, 18 - pref})
     for (const IrbVariant& v : kIrbVariants)
-      if (v.ks == h->ks && v.s == h->stride && v.ncbo == h->ncbo && v.csteps == h->csteps && v.tw == tw &&
+      if (v.stem == h->stem && v.ks == h->ks && v.s == h->stride && v.ncbo == h->ncbo && v.csteps == h->csteps && v.tw == tw &&
           irb_max_valid(H, W, Ho, Wo, h->ks, h->stride, tw) <= 4 * v.rbw * 32)
         return &v;
   return nullptr;
@@ -455,15 +479,12 @@ const IrbVariant* irb_pick(const v3d_irb_weights* h, int H, int W) {
 }  // namespace
 
 // HOST weights with eval-mode BatchNorm folded: w_expand [mid, cin], w_dw [mid, k, k], w_project [cout, mid], biases [mid] / [mid] / [cout]
-extern "C" int v3d_irb_pack(const float* w_expand, const float* b_expand, const float* w_dw, const float* b_dw, const float* w_project,
-                            const float* b_project, int cin, int mid, int cout, int ksize, int stride, int residual,
-                            v3d_irb_weights** out_handle) {
-  V3D_REQUIRE(w_expand && b_expand && w_dw && b_dw && w_project && b_project && out_handle, V3D_ERR_BAD_ARG, "v3d_irb_pack: null argument");
-  V3D_REQUIRE(cin >= 8 && cin % 8 == 0 && mid >= 8 && mid % 8 == 0 && cout >= 8 && cout % 8 == 0 && (ksize == 3 || ksize == 5) &&
-                  (stride == 1 || stride == 2) && (!residual || (cin == cout && stride == 1)),
-              V3D_ERR_BAD_SHAPE, "v3d_irb_pack: cin=%d mid=%d cout=%d k=%d stride=%d residual=%d", cin, mid, cout, ksize, stride, residual);
+namespace {
+int irb_pack_impl(const float* w_expand, const float* b_expand, const float* w_dw, const float* b_dw, const float* w_project,
+                  const float* b_project, int cin, int mid, int cout, int ksize, int stride, int residual, int stem,
+                  v3d_irb_weights** out_handle) {
   v3d_irb_weights* h = new v3d_irb_weights();
-  h->cin = cin; h->mid = mid; h->cout = cout; h->ks = ksize; h->stride = stride; h->residual = residual;
+  h->cin = cin; h->mid = mid; h->cout = cout; h->ks = ksize; h->stride = stride; h->residual = residual; h->stem = stem;
   h->ns = (mid + 31) / 32; h->csteps = (cin + 15) / 16; h->ncbo = (cout + 31) / 32;
   h->xw_slice = (size_t)h->csteps * 2048 + 128;
   h->dw_slice = (size_t)(ksize * ksize + 1) * 128;
@@ -517,6 +538,36 @@ extern "C" int v3d_irb_pack(const float* w_expand, const float* b_expand, const 
   *out_handle = h;
   return V3D_OK;
 }
+}  // namespace
+
+extern "C" int v3d_irb_pack(const float* w_expand, const float* b_expand, const float* w_dw, const float* b_dw, const float* w_project,
+                            const float* b_project, int cin, int mid, int cout, int ksize, int stride, int residual,
+                            v3d_irb_weights** out_handle) {
+  V3D_REQUIRE(w_expand && b_expand && w_dw && b_dw && w_project && b_project && out_handle, V3D_ERR_BAD_ARG, "v3d_irb_pack: null argument");
+  V3D_REQUIRE(cin >= 8 && cin % 8 == 0 && mid >= 8 && mid % 8 == 0 && cout >= 8 && cout % 8 == 0 && (ksize == 3 || ksize == 5) &&
+                  (stride == 1 || stride == 2) && (!residual || (cin == cout && stride == 1)),
+              V3D_ERR_BAD_SHAPE, "v3d_irb_pack: cin=%d mid=%d cout=%d k=%d stride=%d residual=%d", cin, mid, cout, ksize, stride, residual);
+  return irb_pack_impl(w_expand, b_expand, w_dw, b_dw, w_project, b_project, cin, mid, cout, ksize, stride, residual, 0, out_handle);
+}
+
+// The trunk's first three layers as one block: w_stem [32, 3, 3, 3] (= [32, 27], (channel, ky, kx) order), w_dw [32, 3, 3], w_pw [16, 32],
+// BatchNorm folded, biases [32] / [32] / [16]
+extern "C" int v3d_stem_block_pack(const float* w_stem, const float* b_stem, const float* w_dw, const float* b_dw, const float* w_pw,
+                                   const float* b_pw, v3d_irb_weights** out_handle) {
+  V3D_REQUIRE(w_stem && b_stem && w_dw && b_dw && w_pw && b_pw && out_handle, V3D_ERR_BAD_ARG, "v3d_stem_block_pack: null argument");
+  std::vector<float> we(32 * 32, 0.f);                   // K padded from 27 to 32 with zero weights
+  for (int m = 0; m < 32; ++m)
+    for (int k = 0; k < 27; ++k) we[m * 32 + k] = w_stem[m * 27 + k];
+  return irb_pack_impl(we.data(), b_stem, w_dw, b_dw, w_pw, b_pw, 32, 32, 16, 3, 1, 0, 1, out_handle);
+}
+
+// image [n, 3, IH, IW] (NCHW, even sides) -> out [n, IH / 2, IW / 2, 16] channels-last
+extern "C" int v3d_stem_block_f32(const v3d_irb_weights* h, const float* image, int n, int IH, int IW, float* out, void* stream) {
+  V3D_REQUIRE(h && h->stem && image && out, V3D_ERR_BAD_ARG, "v3d_stem_block_f32: null argument or not a stem handle");
+  V3D_REQUIRE(n >= 0 && IH >= 2 && IW >= 2 && IH % 2 == 0 && IW % 2 == 0, V3D_ERR_BAD_SHAPE, "v3d_stem_block_f32: n=%d image %d x %d (even sides)", n, IH, IW);
+  if (n == 0) return V3D_OK;
+  return v3d_irb_launch(h, image, n, IH / 2, IW / 2, IH, IW, out, nullptr, 0, stream);
+}
 
 extern "C" void v3d_irb_free(v3d_irb_weights* h) {
   if (!h) return;
@@ -562,6 +613,12 @@ extern "C" int v3d_irb_supported(const v3d_irb_weights* h, int H, int W) {
 
 extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n, int H, int W, float* out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(h && !h->stem && x && out, V3D_ERR_BAD_ARG, "v3d_irb_nhwc_f32: null argument (or a stem handle: v3d_stem_block_f32)");
+  return v3d_irb_launch(h, x, n, H, W, 0, 0, out, workspace, workspace_bytes, stream);
+}
+
+int v3d_irb_launch(const v3d_irb_weights* h, const float* x, int n, int H, int W, int ih, int iw, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream) {
   V3D_REQUIRE(h && x && out, V3D_ERR_BAD_ARG, "v3d_irb_nhwc_f32: null argument");
   V3D_REQUIRE(n >= 0 && H >= 1 && W >= 1, V3D_ERR_BAD_SHAPE, "v3d_irb_nhwc_f32: n=%d H=%d W=%d", n, H, W);
   V3D_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, V3D_ERR_BAD_ARG, "v3d_irb_nhwc_f32: x must be 16-byte aligned");
@@ -573,7 +630,7 @@ extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n,
   p.x = x; p.out = out;
   p.xw = h->dev + h->xw_ofs; p.dw = h->dev + h->dw_ofs; p.pw = h->dev + h->pw_ofs; p.bp = reinterpret_cast<const float*>(h->dev + h->bp_ofs);
   p.n = n; p.H = H; p.W = W; p.Ho = (H + h->stride - 1) / h->stride; p.Wo = (W + h->stride - 1) / h->stride;
-  p.cin = h->cin; p.cout = h->cout; p.ns = h->ns; p.residual = h->residual;
+  p.cin = h->cin; p.cout = h->cout; p.ns = h->ns; p.residual = h->residual; p.ih = ih; p.iw = iw;
   p.tiles_x = (p.Wo + v->tw - 1) / v->tw; p.tiles_y = (p.Ho + 7) / 8;
   const long long tiles = (long long)n * p.tiles_x * p.tiles_y;
   p.nsg = irb_groups(h, tiles);
@@ -594,7 +651,7 @@ extern "C" int v3d_irb_nhwc_f32(const v3d_irb_weights* h, const float* x, int n,
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)v->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds));
     attr_set[dev][vi] = true;
   }
-  v3d::TimedScope ts("backbone_block", s);
+  v3d::TimedScope ts(h->stem ? "backbone_stem_block" : "backbone_block", s);
   v->kernel<<<(unsigned)blocks, 256, v->lds, s>>>(p);
   V3D_CHECK_LAUNCH("irb_kernel");
   if (p.nsg > 1) {

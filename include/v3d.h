@@ -441,6 +441,13 @@ int v3d_irb_pack(const float* w_expand, const float* b_expand, const float* w_dw
                  v3d_irb_weights** out_handle);
 void v3d_irb_free(v3d_irb_weights* handle);
 int v3d_irb_supported(const v3d_irb_weights* handle, int H, int W);
+/* The trunk's first three layers (mnasnet layers 0-7: 3x3 / stride 2 convolution 3 -> 32 + BN + ReLU, 3x3 depthwise + BN + ReLU, 1x1 -> 16
+ * + BN) as the same kernel: the 27 (channel, ky, kx) taps of the first convolution are the K dimension of its first matrix product.
+ *   v3d_stem_block_pack  HOST w_stem [32, 27] (Conv2d weight [32, 3, 3, 3] flattened), w_dw [32, 3, 3], w_pw [16, 32], BatchNorm folded
+ *   v3d_stem_block_f32   image [n, 3, IH, IW] (NCHW, even sides) -> out [n, IH/2, IW/2, 16] channels-last; free with v3d_irb_free */
+int v3d_stem_block_pack(const float* w_stem, const float* b_stem, const float* w_dw, const float* b_dw, const float* w_pw,
+                        const float* b_pw, v3d_irb_weights** out_handle);
+int v3d_stem_block_f32(const v3d_irb_weights* handle, const float* image, int n, int IH, int IW, float* out, void* stream);
 size_t v3d_irb_workspace_bytes(const v3d_irb_weights* handle, int n, int H, int W);
 int v3d_irb_nhwc_f32(const v3d_irb_weights* handle, const float* x, int n, int H, int W, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);

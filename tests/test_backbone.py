@@ -352,3 +352,26 @@ def test_pyramid_level_kernel(cin, H, W, coarse, want_inner, cuda):
         assert torch.equal(inner, inner2)
     else:
         assert inner is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W', [(256, 320), (240, 320), (32, 48), (18, 14), (8, 8)])
+def test_stem_block_kernel(H, W, cuda):
+    """The trunk's first three layers as one kernel (v3d_stem_block_*: the stride-2 3x3 convolution's 27 taps gathered as the K
+    dimension of the first matrix product, depthwise, pointwise) against ``FeatureExtractor.layer1`` on the CPU: image borders, ragged
+    tiles, an image smaller than a tile; 2e-5 of the range; repeated launches bit-identical."""
+    bb, syn = v3d('backbone'), v3d('synthetic')
+    fe, _ = bb.build_backbone(32)
+    sd_e, _ = syn.backbone_weights(32, seed=6)
+    fe.load_state_dict(sd_e, strict=False)
+    fe = fe.eval()
+    img = syn.make_images(2, (H, W), seed=H)
+    with torch.no_grad():
+        ref = fe.layer1(img).permute(0, 2, 3, 1).contiguous()
+    stem = bb._StemBlock(fe.layer1, cuda)
+    y = stem(img.to(cuda))
+    y2 = stem(img.to(cuda))
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert torch.equal(y, y2)
