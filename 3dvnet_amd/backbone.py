@@ -14,9 +14,13 @@ reference checkpoint carries under ``mvsnet.feat_extractor.*`` / ``mvsnet.feat_s
 
 The ``nn.Module`` classes are the PARAMETER CONTAINERS (torchvision's key names) and, on the CPU, the restated arithmetic the
 device path is tested against.  On a HIP device ``NativeBackbone`` runs both networks on the library's own kernels
-(csrc/backbone.hip, round 5): channels-last fp32 activations, eval-mode BatchNorm folded into weights / bias, bias + ReLU +
-residual (inverted-residual skip, FPN top-down addition) in the epilogues, 1x1 / 3x3 convolutions as GEMMs on exact-fp32 matrix
-instructions, depthwise and stem kernels -- 2.x ms per 71 images at 256 x 320 where the stock modules on MIOpen took 8.0.
+on channels-last fp32 activations with eval-mode BatchNorm folded into weights / bias.  ``precision='split_bf16'`` (the default,
+round 6): ONE kernel per inverted-residual block and for the stem's three layers (csrc/irb.hip: expand on matrix cores into an LDS
+slice, depthwise taps out of LDS, projection accumulated in registers -- the expanded tensor never reaches HBM) and per fine pyramid
+level (csrc/fpn.hip: lateral + top-down + 3x3, output in the reference layout): 1.44 ms per 71 images at 256 x 320, 26 launches.
+``precision='fp32'``: the per-layer kernels of round 5 (csrc/backbone.hip: 1x1 / 3x3 convolutions as GEMMs on exact-fp32 matrix
+instructions, depthwise and stem kernels, bias + ReLU + residual / top-down addition in the epilogues): 3.3 ms, 55 launches.  The
+stock modules on MIOpen took 8.0 ms.
 PARITY UNPINNED: torchvision is not installed, so neither the module tree nor the arithmetic can be compared with the real
 package here; ``tests/test_backbone.py`` pins shapes, strides and key names as documented for torchvision 0.8.2 and the device
 kernels against these modules on the CPU.  Pretrained ImageNet weights are unavailable offline: ``synthetic.backbone_weights``

@@ -67,6 +67,9 @@ def build(force=False, verbose=False, strict=False):
         try:
             import isa_check
             isa_check.check(os.path.join(objdir, 'decoder.o'), strict=strict)
+            # the fused backbone kernels: every 16-byte LDS read must be the operand of a matrix instruction
+            isa_check.check_wide_lds(os.path.join(objdir, 'irb.o'), 'irb_kernel', strict=strict)
+            isa_check.check_wide_lds(os.path.join(objdir, 'fpn.o'), 'fpn_level_kernel', strict=strict)
         finally:
             sys.path.pop(0)
     if force or procs or linked != tag or _stale(LIB, objs):

@@ -17,6 +17,10 @@
 //   * the input rows of a wave's region row blocks are loaded and split ONCE: they stay in registers as A fragments for all slices;
 //   * the slice's weight images (expand fragments + bias, depthwise taps + bias, project fragments) are fetched one slice ahead
 //     into registers and parked in LDS behind the barrier that frees their buffer; two barriers per slice;
+//   * measured and withdrawn: the expansion with matrix rows = channels (a lane then holds four consecutive channels of its position:
+//     four 16-byte E stores behind one address instead of sixteen 4-byte stores, 60 instead of 100 vector instructions per row block
+//     and slice, E slots padded to 144 bytes against the 16-lanes-on-4-banks conflict): the 1/2-resolution blocks and the stem lost
+//     10-20 % (10 more registers and 1.6 KB more LDS per workgroup: four instead of five workgroups per CU), the others gained 5 %;
 //   * LDS reads that feed vector instructions are 8 bytes per lane (16-byte reads beside matrix instructions in
 //     flight have returned stale lanes on this chip); the 16-byte reads here all feed matrix instructions.
 // Arithmetic: split-bf16 matrix operands (hi*hi + hi*lo + lo*hi, fp32 accumulation) as everywhere on this path; the exact-fp32

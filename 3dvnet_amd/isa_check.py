@@ -104,8 +104,76 @@ def check(obj, strict=False):
     return sig
 
 
+# ----------------------------------------------------------------------------------------------------------------------------
+# Round 6: the fused backbone kernels (csrc/irb.hip, csrc/fpn.hip) follow the same rule by construction -- every LDS read that
+# returns 16 bytes per lane is an operand fragment of a matrix instruction, everything vector instructions consume is read 8
+# bytes at a time by hand-written ds_read_b64 -- and the guard checks the RULE rather than a count: in program order, the first
+# reader of any register written by a ds_read_b128 / ds_read2_b64 must be a v_mfma.
+WIDE_LDS = ('ds_read_b128', 'ds_read2_b64', 'ds_read2st64_b64', 'ds_read_b96')
+ALL_SOURCES = ('ds_write', 'global_store', 'buffer_store', 'flat_store', 'scratch_store', 'v_cmp', 'v_cmpx', 's_', 'global_atomic',
+               'ds_add', 'ds_max', 'ds_min', 'exp')
+
+
+def _regs(operand):
+    """VGPR numbers named by one operand: v7 -> {7}, v[4:7] -> {4..7}; accumulator registers and everything else -> {}."""
+    m = re.fullmatch(r'v(\d+)', operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def wide_lds_consumers(obj, kernel_pattern):
+    """-> list of (kernel, wide read, first consumer) where the first consumer is NOT a matrix instruction."""
+    bad, inside, name, pending = [], False, None, {}
+    for line in disassemble(obj).splitlines():
+        m = re.match(r'^[0-9a-f]+ <(.*)>:', line)
+        if m:
+            inside, name, pending = re.search(kernel_pattern, m.group(1)) is not None, m.group(1), {}
+            continue
+        if not inside:
+            continue
+        m = re.match(r'^\s*([a-z][a-z0-9_]*)\s*(.*?)\s*(//.*)?$', line)
+        if not m or not m.group(1):
+            continue
+        mnem = m.group(1)
+        ops = [o.strip() for o in re.split(r',\s*(?![^\[]*\])', m.group(2).split(' offset')[0]) if o.strip()]
+        ops = [o.split()[0] for o in ops if o.split()]
+        all_src = mnem.startswith(ALL_SOURCES)
+        srcs = set().union(*[_regs(o) for o in (ops if all_src else ops[1:])]) if ops else set()
+        dst = set() if all_src or not ops else _regs(ops[0])
+        hit = [pending[r] for r in srcs if r in pending]
+        if hit and not mnem.startswith('v_mfma'):
+            bad.append((name, hit[0], line.strip()))
+        for r in srcs | dst:                       # consumed (by a matrix instruction or reported) or overwritten: no longer tracked
+            pending.pop(r, None)
+        if mnem in WIDE_LDS:
+            for r in dst:
+                pending[r] = line.strip()
+    return bad
+
+
+def check_wide_lds(obj, kernel_pattern, strict=False):
+    try:
+        bad = wide_lds_consumers(obj, kernel_pattern)
+    except GuardUnavailable as e:
+        if strict:
+            raise RuntimeError('ISA guard (%s) could not run: %s' % (kernel_pattern, e))
+        sys.stderr.write('isa_check: guard NOT run (%s)\n' % e)
+        return None
+    if bad:
+        raise RuntimeError('a 16-byte LDS read feeds a non-matrix instruction (DESIGN.md §8.4) in %s:\n  %s\n  -> %s\n(%d such reads)'
+                           % (bad[0][0], bad[0][1], bad[0][2], len(bad)))
+    return 0
+
+
 if __name__ == '__main__':
-    if '--print' in sys.argv:
+    if '--wide' in sys.argv:
+        for b in wide_lds_consumers(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 else '.'):
+            print(b)
+    elif '--print' in sys.argv:
         print(compiler_id())
         print(signature(sys.argv[1]))
     else:
