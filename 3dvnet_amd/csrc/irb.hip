@@ -21,6 +21,8 @@
 //     four 16-byte E stores behind one address instead of sixteen 4-byte stores, 60 instead of 100 vector instructions per row block
 //     and slice, E slots padded to 144 bytes against the 16-lanes-on-4-banks conflict): the 1/2-resolution blocks and the stem lost
 //     10-20 % (10 more registers and 1.6 KB more LDS per workgroup: four instead of five workgroups per CU), the others gained 5 %;
+//     8 x 16 tiles for the stride-1 blocks at 1/4 and 1/8 resolution and the stem (half the tiles, balanced projection tasks, 49 KB of
+//     LDS = three instead of five workgroups per CU): blocks 0.98 -> 1.01 ms, stem 0.169 -> 0.164;
 //   * LDS reads that feed vector instructions are 8 bytes per lane (16-byte reads beside matrix instructions in
 //     flight have returned stale lanes on this chip); the 16-byte reads here all feed matrix instructions.
 // Arithmetic: split-bf16 matrix operands (hi*hi + hi*lo + lo*hi, fp32 accumulation) as everywhere on this path; the exact-fp32
