@@ -385,7 +385,7 @@ def test_bench_line_carries_cfg5_and_cfg3_figures(cuda):
     # round 6: the backbone in both arithmetic types (fused split-bf16 blocks by default, the exact-fp32 per-layer kernels beside them)
     bbk = d['extra']['backbone']
     assert 0 < bbk['ms_per_batch'] < bbk['ms_per_batch_fp32_exact'] and bbk['launches_per_batch'] <= 30
-    assert bbk['max_diff_vs_stock_modules_of_range'] < 5e-5 and bbk['max_diff_vs_stock_modules_of_range_fp32_exact'] < 2e-5
+    assert bbk['max_diff_vs_stock_modules_of_range'] < 1e-4 and bbk['max_diff_vs_stock_modules_of_range_fp32_exact'] < 2e-5
     assert any('block' in k for k in bbk['kernels'])
     assert 0 < d['extra']['from_images']['value_fp32_exact'] < d['extra']['from_images']['value']
     # the reference's arithmetic type beside every figure, and inside `config` (a record that keeps only the contract's keys)
