@@ -592,7 +592,9 @@ extern "C" int v3d_debug_irb_phase(unsigned long long* out8, int reset) {
 
 namespace {
 // Slice groups per tile: a map with fewer tiles than the chip has CUs (71 images of 8 x 10 = 71 tiles) hands the slices of a tile to
-// several workgroups, as many as keep every workgroup on its own CU; their partial sums meet in the workspace.
+// several workgroups, as many as keep every workgroup on its own CU; their partial sums meet in the workspace.  (Aiming at two or
+// three workgroups per CU -- which would also split the 284 tiles of the 1/16-resolution maps -- measured 0.98 -> 1.05 / 1.10 ms
+// for the trunk's 16 blocks: the prologue and the reducing launch cost more than the tail they remove.)
 int irb_groups(const v3d_irb_weights* h, long long tiles) {
   int n_cu = (int)v3d::persistent_grid(1 << 20, 1);
   long long g = n_cu / (tiles > 0 ? tiles : 1);
