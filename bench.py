@@ -769,7 +769,7 @@ def bench_backbone(dev, n_img=71, iters=10):
             'max_diff_vs_stock_modules_of_range': agree, 'max_diff_vs_stock_modules_of_range_fp32_exact': agree32,
             'quarter_features': list(out[1].shape),
             'note': 'parity with torchvision unpinned (absent here); tests/test_backbone.py pins the kernels against oracle/backbone.py '
-                    'on the CPU (256x320, 240x320, 248x328): 5e-5 of range split-bf16, 2e-5 exact fp32'}
+                    'on the CPU (256x320, 240x320, 248x328): 8e-5 of range split-bf16 (measured <= 4.0e-5), 2e-5 exact fp32'}
 
 
 def compact(line):

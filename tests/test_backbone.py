@@ -185,10 +185,11 @@ def test_native_backbone_matches_the_oracle(cuda):
     fe, fs = fe.eval().to(cuda), fs.eval().to(cuda)
     # 'split_bf16' (the default, as everywhere in the package): fused inverted-residual blocks (csrc/irb.hip) on split-bf16 matrix
     # operands -- an operand pair (hi, lo) carries 16 mantissa bits, 2^-17 relative per operand, and the finest map sits behind 17
-    # blocks and four top-down additions: 5e-5 of the range (measured: at most 4.0e-5, P1 at 240 x 320); 'fp32': the exact-fp32
+    # blocks and four top-down additions: 8e-5 of the range (measured: at most 4.0e-5 at these sizes, P1 at 240 x 320; 5.3e-5 over 30
+    # random sizes, scripts/fuzz_backbone.py); 'fp32': the exact-fp32
     # three-launch blocks, 2e-5 (summation orders only).  The depth the cost volume makes of these features is held to the path's
     # 1e-4 in test_mvsnet_forward_from_images.
-    for precision, bound in (('split_bf16', 5e-5), ('fp32', 2e-5)):
+    for precision, bound in (('split_bf16', 8e-5), ('fp32', 2e-5)):
         nb = bb.NativeBackbone(fe, fs, precision=precision)
         for n, size, seed in ((3, (256, 320), 4), (2, (96, 160), 5), (2, (240, 320), 6), (1, (248, 328), 7)):
             img = syn.make_images(n, size, seed=seed)
