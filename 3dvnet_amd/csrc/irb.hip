@@ -107,7 +107,11 @@ struct IrbCfg {
   static constexpr int NXP = (XW_BYTES / 16 + 255) / 256, NDP = (DW_BYTES / 16 + 255) / 256;
   // LDS map (bytes)
   static constexpr int E_OFS = 0, E_BYTES = (R + 1) * 128;                    // [region slot][32] fp32; slot R = dump row
-  static constexpr int D_OFS = E_OFS + E_BYTES, D_BYTES = 8 * RBP * 32 * 16;  // [step][hi, lo][k half][row][16 B]
+  // D: eight planes [step][hi, lo][k half] of [row][16 B]; a plane is 32 bytes longer than its rows so that the planes start 8 banks
+  // apart (the depthwise role stores 4 bytes per lane into four planes at once: with plane starts 1 KB apart they were 8 lanes per bank;
+  // time unchanged: the LDS is not what the kernel waits for)
+  static constexpr int DP = RBP * 32 * 16 + 32;
+  static constexpr int D_OFS = E_OFS + E_BYTES, D_BYTES = 8 * DP;
   static constexpr int XW_OFS = D_OFS + D_BYTES;
   static constexpr int PW_OFS = XW_OFS + XW_BYTES;
   static constexpr int DW_OFS = PW_OFS + PW_BYTES;
@@ -342,14 +346,14 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
       }
       // ReLU, split, -> the A-operand layout of the projection: channels 2 cp, 2 cp + 1 = bytes [4 (cp & 3), + 4) of the 16-byte chunk
       // (k half (cp >> 2) & 1) of step cp >> 3
-      unsigned char* const d = D + ((((cp >> 3) * 2 + 0) * 2 + ((cp >> 2) & 1)) * (C::RBP * 32) + ty * TW + txh) * 16 + (cp & 3) * 4;
+      unsigned char* const d = D + (((cp >> 3) * 2 + 0) * 2 + ((cp >> 2) & 1)) * C::DP + (ty * TW + txh) * 16 + (cp & 3) * 4;
 #pragma unroll
       for (int o = 0; o < NX; ++o) {
         const f32x2 r = __builtin_elementwise_max(acc[o], (f32x2){0.f, 0.f});
         unsigned hi, lo;
         irb_split2(r.x, r.y, hi, lo);
         *reinterpret_cast<unsigned*>(d + o * 16) = hi;
-        *reinterpret_cast<unsigned*>(d + o * 16 + 2 * (C::RBP * 32) * 16) = lo;
+        *reinterpret_cast<unsigned*>(d + o * 16 + 2 * C::DP) = lo;
       }
     }
     IRB_PH(3);
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(256, OCC) void irb_kernel(IrbParams p) {
       const int rbp = k / NCBO, cb = k - rbp * NCBO;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bf16x8 dh = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(D + (((st * 2 + 0) * 2 + g) * (C::RBP * 32) + rbp * 32) * 16)[i]);
-        const bf16x8 dl = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(D + (((st * 2 + 1) * 2 + g) * (C::RBP * 32) + rbp * 32) * 16)[i]);
+        const bf16x8 dh = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(D + ((st * 2 + 0) * 2 + g) * C::DP + rbp * 32 * 16)[i]);
+        const bf16x8 dl = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(D + ((st * 2 + 1) * 2 + g) * C::DP + rbp * 32 * 16)[i]);
         const bf16x8 wh = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(PW + ((cb * 2 + st) * 2 + 0) * 1024)[lane]);
         const bf16x8 wl = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(PW + ((cb * 2 + st) * 2 + 1) * 1024)[lane]);
         pacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, wh, pacc[q], 0, 0, 0);
